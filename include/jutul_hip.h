@@ -1,0 +1,208 @@
+/*
+ * jutul_hip.h -- C ABI of libjutul_hip.so: the MI355X (gfx950) implementation of Jutul.jl's per-Newton
+ * hot path (TPFA residual/Jacobian assembly into (block-)CSR, CSR SpMV, ILU(0) factor/apply, BiCGStab,
+ * ghost-cell halo exchange) behind Jutul's own operator surface.
+ *
+ * Jutul.jl has no FFI: its extension points are Julia dispatch seams.  Every entry point below names the
+ * reference seam it replaces (file:line relative to the Jutul.jl source tree); the Julia-side binding
+ * (`ccall`) a maintainer would add is shown in INTEGRATION.md and julia/JutulHIP.jl.
+ *
+ * Conventions
+ *  - every function returns int32: 0 = OK, < 0 = error; jh_last_error() gives the message (thread-local).
+ *    The Julia glue turns non-zero into `error(...)`, preserving the reference's exception semantics
+ *    (e.g. failure_cuts_timestep, simulator.jl:509-518).
+ *  - host index arrays cross the boundary as the reference stores them: Int64, 1-BASED (context.jl:76-78).
+ *    They are converted once to 0-based int32 on the device.
+ *  - host floating-point arrays are Float64 in the reference's layouts ([N, nc] column-major for block /
+ *    entity-major vectors; flat jac_buffer for Jacobian values, linsolve/default.jl:166-226).
+ *  - handles are opaque; a handle is not re-entrant; all work on one context is ordered on one HIP
+ *    stream; calls that return host-visible data synchronise that stream.
+ *  - device-resident vectors are `jh_vec` handles so the Krylov loop never leaves HBM.
+ */
+#ifndef JUTUL_HIP_H
+#define JUTUL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jh_context_s *jh_context; /* JutulContext (core_types.jl:86-88; contexts/csr.jl:3-23)        */
+typedef struct jh_tpfa_s *jh_tpfa;       /* TwoPointPotentialFlowHardCoded + pattern + positions (a-1..a-4) */
+typedef struct jh_csr_s *jh_csr;         /* StaticSparsityMatrixCSR on the device (StaticCSR/mat.jl:1-8)    */
+typedef struct jh_vec_s *jh_vec;         /* r_buffer / dx_buffer-like device vector (default.jl:188-226)    */
+typedef struct jh_law_s *jh_law;         /* ConservationLaw + ConservationLawTPFAStorage (conservation.jl:101-135) */
+typedef struct jh_ilu_s *jh_ilu;         /* ILUFactorCSR / ParallelILUFactorCSR (ilu0.jl:190-203, par_ilu0.jl:2-5) */
+typedef struct jh_krylov_s *jh_krylov;   /* GenericKrylov(:bicgstab) workspace (linsolve/krylov.jl:27-58)   */
+
+/* ---- errors / context ------------------------------------------------------------------------------- */
+int32_t jh_last_error(char *buf, int64_t cap);
+int32_t jh_version(void);
+/* device_id: HIP device ordinal.  Mirrors SingleCUDAContext's role (contexts/cuda.jl). */
+int32_t jh_context_create(int32_t device_id, jh_context *out);
+int32_t jh_context_destroy(jh_context ctx);
+int32_t jh_synchronize(jh_context ctx); /* synchronize(ctx), context.jl:72 */
+/* GPU timer on the context stream (HIP events) -- feeds report[:equations_time] & co (simulator.jl:427-433) */
+int32_t jh_timer_start(jh_context ctx);
+int32_t jh_timer_stop_ms(jh_context ctx, double *ms);
+
+/* ---- a-1..a-4: connectivity, pattern, positions ------------------------------------------------------- */
+/* reorder modes for the DEVICE cell numbering (host numbering is never changed; all host-facing arrays
+ * are in host numbering). */
+#define JH_REORDER_NONE 0   /* device order == host order: ILU(0) identical to the reference's ordering     */
+#define JH_REORDER_BLOCKS 1 /* compact graph blocks, BFS inside/between blocks (locality + block-Jacobi)    */
+/* TwoPointPotentialFlowHardCoded(N, nc) (flux.jl:172-190) via get_facepos (utils.jl:813-874) and
+ * get_connection (flux.jl:128-142); CSR pattern per declare_pattern (conservation.jl:486-505) +
+ * static_sparsity_sparse (StaticCSR/mat.jl:73-76).
+ * N: 2 x nf neighborship, column-major, 1-based.  block_n: equations = primary variables per cell.
+ * partition (may be NULL): nc entries, 1-based part id per cell; cells of one part become contiguous on the
+ * device (used as the block-Jacobi ILU(0) partition, precond/ilu.jl:37-60).  block_rows: target rows per
+ * automatically grown block when partition == NULL and reorder == JH_REORDER_BLOCKS (0 = default).
+ * n_owned: for a rank-local subdomain whose cells are [owned..., ghosts...] (ext/JutulPartitionedArraysExt/
+ * utils.jl:178-184) the number of owned cells; ghosts stay the last device rows.  <= 0 or nc: no ghosts. */
+int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const int64_t *N, int32_t block_n, int32_t reorder,
+                       const int64_t *partition, int64_t block_rows, int64_t n_owned, jh_tpfa *out);
+int32_t jh_tpfa_destroy(jh_tpfa d);
+int32_t jh_tpfa_sizes(jh_tpfa d, int64_t *nc, int64_t *nf, int64_t *nhf, int64_t *nnzb, int32_t *block_n);
+/* conn_pos / conn_data (flux.jl:161-190): face_pos[nc+1]; self/other/face/face_sign [nhf] */
+int32_t jh_tpfa_get_conn(jh_tpfa d, int64_t *face_pos, int64_t *self, int64_t *other, int64_t *face, int64_t *face_sign);
+/* block pattern: rowptr[nc+1], colidx[nnzb], ascending columns, diagonal present */
+int32_t jh_tpfa_get_pattern(jh_tpfa d, int64_t *rowptr, int64_t *colidx);
+/* jacobian_positions (conservation.jl:143-216, equations.jl:95-113): pos_acc [N*N, nc], pos_flux [N*N, nhf],
+ * partial index fastest ((e-1)*np + d), BlockMajorLayout flat index into jac_buffer (1-based). */
+int32_t jh_tpfa_get_positions(jh_tpfa d, int64_t *pos_acc, int64_t *pos_flux);
+/* device cell order: perm[i] = host cell (1-based) stored at device position i; block_ptr (nblocks+1,
+ * 0-based device rows) of the contiguous blocks.  Pass NULL to skip an output. */
+int32_t jh_tpfa_get_ordering(jh_tpfa d, int64_t *perm, int64_t *nblocks, int64_t *block_ptr, int64_t block_ptr_cap);
+
+/* ---- device vectors ------------------------------------------------------------------------------------- */
+/* A vector of nc*block_n doubles attached to a discretisation (cell-ordered: upload/download apply the device
+ * permutation) or a plain vector of n doubles attached to a matrix created from a raw pattern. */
+int32_t jh_vec_create(jh_tpfa d, jh_vec *out);
+int32_t jh_vec_create_for(jh_csr A, jh_vec *out);
+int32_t jh_vec_destroy(jh_vec v);
+int32_t jh_vec_upload(jh_vec v, const double *host);  /* host layout [N, nc] (block/entity major) */
+int32_t jh_vec_download(jh_vec v, double *host);
+int32_t jh_vec_fill(jh_vec v, double value);
+int32_t jh_vec_copy(jh_vec dst, jh_vec src);
+int32_t jh_vec_axpby(jh_vec y, double a, jh_vec x, double b); /* y = a*x + b*y */
+int32_t jh_vec_dot(jh_vec a, jh_vec b, double *out);
+int32_t jh_vec_length(jh_vec v, int64_t *n);
+
+/* ---- Jacobian / sparse operators (a-10) -------------------------------------------------------------------- */
+/* LinearizedSystem.jac + jac_buffer for a TPFA discretisation (linsolve/default.jl:113-129,166-186) */
+int32_t jh_csr_create(jh_tpfa d, jh_csr *out);
+/* StaticSparsityMatrixCSR(m, n, rowptr, cols, nzval) (StaticCSR/mat.jl:79-83): square n x n, block size bs,
+ * 1-based rowptr/colidx with ascending columns; nz may be NULL. */
+int32_t jh_csr_create_from_pattern(jh_context ctx, int64_t n, int32_t bs, const int64_t *rowptr, const int64_t *colidx,
+                                   const double *nz, jh_csr *out);
+int32_t jh_csr_destroy(jh_csr A);
+int32_t jh_csr_sizes(jh_csr A, int64_t *n, int64_t *nnzb, int32_t *bs);
+/* nonzeros(A) in the HOST pattern order (flat jac_buffer: block k, entry (e,d) at (k-1)N^2 + N(d-1) + e) */
+int32_t jh_csr_set_values(jh_csr A, const double *nz);
+int32_t jh_csr_get_values(jh_csr A, double *nz);
+/* mul!(y, A, x, alpha, beta) (StaticCSR/mat.jl:24-39; block: linsolve/block_cpu.jl:1-17) */
+int32_t jh_spmv(jh_csr A, jh_vec x, jh_vec y, double alpha, double beta);
+/* unit_diagonalize!(r, J, n_self) (ext/JutulPartitionedArraysExt/linalg.jl:18-35): rows of ghost cells -> -I,
+ * r_ghost -> 0.  ghost rows are the device rows >= n_owned of a distributed discretisation. */
+int32_t jh_unit_diagonalize(jh_csr A, jh_vec r, int64_t n_owned);
+
+/* ---- a-5/a-6/a-8/a-9/a-15: conservation law --------------------------------------------------------------- */
+#define JH_LAW_POISSON 0      /* VariablePoissonEquation(TimeDependent) (variable_poisson.jl:90-133), N = 1 */
+#define JH_LAW_COMPRESSIBLE 1 /* single-phase slightly compressible, N = 1 (build-defined from flux.jl:335-375) */
+#define JH_LAW_TWOPHASE 2     /* immiscible two-phase (p, S_w), N = 2, SPU upwind (flux.jl:382-405)            */
+/* params: rho0[2], compressibility[2], viscosity[2], p_ref (7 doubles; NULL = ones/zeros) */
+int32_t jh_law_create(jh_tpfa d, int32_t kind, const double *params, jh_law *out);
+int32_t jh_law_destroy(jh_law L);
+#define JH_FACE_TRANS 0 /* T_f [nf]   (compute_face_trans, finite-volume.jl:224-233)  */
+#define JH_FACE_GDZ 1   /* gdz_f [nf] (compute_face_gdz, finite-volume.jl:304-313)    */
+#define JH_CELL_VOLUME 2 /* accumulation coefficient vol*phi [nc] (1 for the Poisson law) */
+int32_t jh_law_set_data(jh_law L, int32_t which, const double *host);
+int32_t jh_law_set_state(jh_law L, const double *X);   /* primary variables [N, nc]                      */
+int32_t jh_law_set_state0(jh_law L, const double *X0); /* previous-step state (state0)                   */
+int32_t jh_law_get_state(jh_law L, double *X);
+int32_t jh_law_update_state0(jh_law L);                /* state0 <- state (update_after_step!, models.jl:983-1011) */
+int32_t jh_law_reset_state(jh_law L);                  /* state <- state0 (timestep cut)                 */
+/* forces: PoissonSource-style cell sources added to the residual (models.jl:889-901; variable_poisson.jl:78-84).
+ * cells 1-based [n], values [N, n]. */
+int32_t jh_law_set_sources(jh_law L, int64_t n, const int64_t *cells, const double *values);
+/* update_equation! (conservation.jl:572-626) + update_linearized_system_equation! (conservation.jl:298-430)
+ * fused: one pass over the CSR-ordered half-faces; writes every nzval slot of A and r. dt <= 0 selects the
+ * stationary Poisson variant. */
+int32_t jh_assemble(jh_law L, double dt, jh_csr A, jh_vec r);
+/* convergence_criterion (equations.jl:619-629): err[e] = max_cells |r[e, cell]| over the first n_owned cells
+ * (n_owned <= 0: all) */
+int32_t jh_convergence(jh_law L, jh_vec r, int64_t n_owned, double *err);
+/* update_primary_variables! (models.jl:928-953, variables/utils.jl:110-174): X += clamp-chain(w*dx) with
+ * per-variable scale / abs_max / rel_max / minimum / maximum (5*N doubles, NaN = unset; NULL = no limits). */
+int32_t jh_update_primary(jh_law L, jh_vec dx, double w, const double *limits);
+
+/* ---- a-11..a-13: ILU(0) ----------------------------------------------------------------------------------- */
+/* ilu0_csr(A) (StaticCSR/ilu0.jl:213-221) when partition == NULL and nparts <= 1; ilu0_csr(A, partition)
+ * (par_ilu0.jl:47-55) otherwise.  partition: n entries, 1-based, HOST row numbering; or NULL with nparts == -1
+ * to use the discretisation's own device blocks (jh_tpfa_create).  Symbolic phase only. */
+int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t nparts, jh_ilu *out);
+int32_t jh_ilu0_destroy(jh_ilu M);
+/* ilu0_csr!(LU, A) (ilu0.jl:223-231): numeric factorisation from A's current values */
+int32_t jh_ilu0_factor(jh_ilu M);
+/* ldiv!(x, LU, b) (ilu0.jl:233-236; apply!, precond/ilu.jl:62-94) */
+int32_t jh_ilu0_apply(jh_ilu M, jh_vec b, jh_vec x);
+/* factor values scattered to A's HOST pattern: L multipliers below the diagonal, inv(U_ii) on it, U above */
+int32_t jh_ilu0_get_factor(jh_ilu M, double *lu);
+int32_t jh_ilu0_info(jh_ilu M, int64_t *nblocks, int64_t *max_block_rows, int64_t *max_levels);
+
+/* ---- a-14: Krylov ---------------------------------------------------------------------------------------------- */
+#define JH_SIDE_NONE 0
+#define JH_SIDE_LEFT 1  /* M = prec (distributed path, ext/JutulPartitionedArraysExt/krylov.jl:60)        */
+#define JH_SIDE_RIGHT 2 /* N = prec (IterativeSolverConfig default precond_side = :right, linsolve/utils.jl:25) */
+int32_t jh_krylov_create(jh_csr A, jh_krylov *out);
+int32_t jh_krylov_destroy(jh_krylov K);
+/* linear_solve!(sys, GenericKrylov(:bicgstab), ...) core (linsolve/krylov.jl:71-182) = Krylov.jl bicgstab!
+ * with x0 = 0, c = r0, stop on ||r|| <= atol + rtol*||r0||, history = true.
+ * status: 0 solved, 1 itmax reached, 2 breakdown.  hist: ||r_k||, k = 0..iters (at most hist_cap entries). */
+int32_t jh_bicgstab(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh_vec x, double rtol, double atol, int64_t itmax,
+                    int64_t *iters, int32_t *status, double *hist, int64_t hist_cap);
+/* update_dx_from_vector! (linsolve/default.jl:444-446): dx = -x */
+int32_t jh_vec_negate_into(jh_vec dx, jh_vec x);
+
+/* ---- Newton convenience (perform_step!, simulator.jl:392-455) -------------------------------------------------- */
+typedef struct {
+  double assembly_ms;      /* equations_time + linear_system_time */
+  double convergence_ms;   /* convergence_time */
+  double precond_ms;       /* update_preconditioner! */
+  double linear_solve_ms;  /* linear_solve_time (excl. precond update) */
+  double update_ms;        /* update_time */
+  double error[2];         /* max|r| per equation before the solve */
+  double lin_res0, lin_res; /* first / last Krylov residual norm */
+  int64_t linear_iterations;
+  int32_t linear_status;
+  int32_t converged;       /* all(error < tol) (and solve skipped, check_before_solve = true) */
+} jh_newton_report;
+/* One Newton iteration: assemble -> convergence check -> (if not converged or force_solve) ILU factor +
+ * BiCGStab + dx = -x + primary update.  tol: per-equation residual tolerance (1e-3 default in the reference). */
+int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_vec r, jh_vec dx, double dt, double tol,
+                       int32_t force_solve, double rtol, double atol, int64_t itmax, int32_t side,
+                       jh_newton_report *rep);
+
+/* ---- a-16/a-17: domain decomposition, halo exchange (RCCL over xGMI) ------------------------------------------- */
+/* One process per GPU.  The host side (torch.distributed / MPI / Julia Distributed) only has to broadcast the
+ * 128-byte unique id; all data-path collectives run inside the library on the context stream. */
+int32_t jh_comm_unique_id(char *id128);
+int32_t jh_comm_init(jh_context ctx, int32_t nranks, int32_t rank, const char *id128);
+int32_t jh_comm_finalize(jh_context ctx);
+/* Halo plan of a rank-local discretisation whose cells are [owned..., ghosts...] in HOST numbering
+ * (ext/JutulPartitionedArraysExt/utils.jl:9-56,178-184).  For each neighbour rank: the local (1-based) owned
+ * cells to send and the local ghost cells to receive, in matching order on both sides. */
+int32_t jh_halo_create(jh_tpfa d, int64_t n_owned, int32_t n_nbr, const int32_t *nbr_rank, const int64_t *send_ptr,
+                       const int64_t *send_cells, const int64_t *recv_ptr, const int64_t *recv_cells);
+/* consistent!(v) (ext/.../linalg.jl:46, krylov.jl:54,75; interface.jl:200): owner values -> ghosts */
+int32_t jh_halo_exchange(jh_tpfa d, jh_vec v);
+int32_t jh_halo_exchange_state(jh_law L);
+/* mpi_scalar_allreduce (ext/.../utils.jl:232-234): op 0 sum, 1 max; n doubles in place on the host */
+int32_t jh_allreduce(jh_context ctx, double *values, int32_t n, int32_t op);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

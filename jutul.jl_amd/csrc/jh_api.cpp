@@ -1,0 +1,435 @@
+// C-ABI glue: contexts, vectors, matrices, laws.  See include/jutul_hip.h for the reference seams.
+#include <cmath>
+#include <cstring>
+
+#include "jh_internal.hpp"
+
+namespace jh {
+void halo_exchange(jh_tpfa d, double *v, int bs);
+}
+using namespace jh;
+
+// ---- context --------------------------------------------------------------------------------------------------
+extern "C" int32_t jh_context_create(int32_t device_id, jh_context *out) {
+  return guard([&] {
+    if (!out) JH_THROW("null argument");
+    int ndev = 0;
+    JH_HIP(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) JH_THROW("no such HIP device: " + std::to_string(device_id));
+    JH_HIP(hipSetDevice(device_id));
+    auto c = std::make_unique<jh_context_s>();
+    c->device = device_id;
+    JH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    JH_HIP(hipEventCreate(&c->ev0));
+    JH_HIP(hipEventCreate(&c->ev1));
+    c->scalars.alloc(32);
+    JH_HIP(hipMemsetAsync(c->scalars.p, 0, 32 * sizeof(double), c->stream));
+    JH_HIP(hipHostMalloc((void **)&c->h_scalars, 32 * sizeof(double), hipHostMallocDefault));
+    JH_HIP(hipStreamSynchronize(c->stream));
+    *out = c.release();
+  });
+}
+extern "C" int32_t jh_context_destroy(jh_context ctx) {
+  return guard([&] {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)jh_comm_finalize(ctx);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+    ctx->partials.release();
+    ctx->scalars.release();
+    ctx->stage.release();
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+  });
+}
+extern "C" int32_t jh_synchronize(jh_context ctx) {
+  return guard([&] {
+    if (!ctx) JH_THROW("null context");
+    JH_HIP(hipSetDevice(ctx->device));
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+extern "C" int32_t jh_timer_start(jh_context ctx) {
+  return guard([&] { JH_HIP(hipEventRecord(ctx->ev0, ctx->stream)); });
+}
+extern "C" int32_t jh_timer_stop_ms(jh_context ctx, double *ms) {
+  return guard([&] {
+    JH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    JH_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0;
+    JH_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = f;
+  });
+}
+
+// ---- vectors ----------------------------------------------------------------------------------------------------
+static jh_vec make_vec(jh_context ctx, std::shared_ptr<Pattern> pat) {
+  auto v = std::make_unique<jh_vec_s>();
+  v->ctx = ctx;
+  v->pat = pat;
+  v->bs = pat->bs;
+  v->len = pat->n * pat->bs;
+  JH_HIP(hipSetDevice(ctx->device));
+  v->d.alloc(v->len);
+  JH_HIP(hipMemsetAsync(v->d.p, 0, v->len * sizeof(double), ctx->stream));
+  return v.release();
+}
+extern "C" int32_t jh_vec_create(jh_tpfa d, jh_vec *out) {
+  return guard([&] {
+    if (!d || !out) JH_THROW("null argument");
+    *out = make_vec(d->ctx, d->pat);
+  });
+}
+extern "C" int32_t jh_vec_create_for(jh_csr A, jh_vec *out) {
+  return guard([&] {
+    if (!A || !out) JH_THROW("null argument");
+    *out = make_vec(A->ctx, A->pat);
+  });
+}
+extern "C" int32_t jh_vec_destroy(jh_vec v) {
+  return guard([&] { delete v; });
+}
+static void upload_cells(jh_context ctx, const Pattern &P, double *dst, const double *host, int64_t n, int bs) {
+  JH_HIP(hipSetDevice(ctx->device));
+  if (P.perm.empty()) {
+    JH_HIP(hipMemcpyAsync(dst, host, n * bs * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    ctx->ensure_stage(n * bs);
+    JH_HIP(hipMemcpyAsync(ctx->stage.p, host, n * bs * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    k_permute_in(ctx->stream, dst, ctx->stage.p, P.d_perm.p, n, bs);
+  }
+  JH_HIP(hipStreamSynchronize(ctx->stream));
+}
+static void download_cells(jh_context ctx, const Pattern &P, double *host, const double *src, int64_t n, int bs) {
+  JH_HIP(hipSetDevice(ctx->device));
+  if (P.perm.empty()) {
+    JH_HIP(hipMemcpyAsync(host, src, n * bs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    ctx->ensure_stage(n * bs);
+    k_permute_out(ctx->stream, ctx->stage.p, src, P.d_perm.p, n, bs);
+    JH_HIP(hipMemcpyAsync(host, ctx->stage.p, n * bs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  JH_HIP(hipStreamSynchronize(ctx->stream));
+}
+extern "C" int32_t jh_vec_upload(jh_vec v, const double *host) {
+  return guard([&] {
+    if (!v || !host) JH_THROW("null argument");
+    upload_cells(v->ctx, *v->pat, v->d.p, host, v->pat->n, v->bs);
+  });
+}
+extern "C" int32_t jh_vec_download(jh_vec v, double *host) {
+  return guard([&] {
+    if (!v || !host) JH_THROW("null argument");
+    download_cells(v->ctx, *v->pat, host, v->d.p, v->pat->n, v->bs);
+  });
+}
+extern "C" int32_t jh_vec_fill(jh_vec v, double value) {
+  return guard([&] { k_fill(v->ctx->stream, v->d.p, v->len, value); });
+}
+extern "C" int32_t jh_vec_copy(jh_vec dst, jh_vec src) {
+  return guard([&] {
+    if (dst->len != src->len) JH_THROW("dimension mismatch");
+    k_copy(dst->ctx->stream, dst->d.p, src->d.p, dst->len);
+  });
+}
+extern "C" int32_t jh_vec_axpby(jh_vec y, double a, jh_vec x, double b) {
+  return guard([&] {
+    if (y->len != x->len) JH_THROW("dimension mismatch");
+    k_axpby(y->ctx->stream, y->d.p, a, x->d.p, b, y->len);
+  });
+}
+extern "C" int32_t jh_vec_negate_into(jh_vec dx, jh_vec x) {
+  return guard([&] {
+    if (dx->len != x->len) JH_THROW("dimension mismatch");
+    k_negate(dx->ctx->stream, dx->d.p, x->d.p, dx->len);
+  });
+}
+extern "C" int32_t jh_vec_dot(jh_vec a, jh_vec b, double *out) {
+  return guard([&] {
+    if (a->len != b->len) JH_THROW("dimension mismatch");
+    JH_HIP(hipSetDevice(a->ctx->device));
+    k_dot(a->ctx, a->d.p, b->d.p, a->len, 10);
+    *out = read_scalar(a->ctx, 10);
+  });
+}
+extern "C" int32_t jh_vec_length(jh_vec v, int64_t *n) {
+  return guard([&] { *n = v->len; });
+}
+
+// ---- matrices ---------------------------------------------------------------------------------------------------
+extern "C" int32_t jh_csr_create(jh_tpfa d, jh_csr *out) {
+  return guard([&] {
+    if (!d || !out) JH_THROW("null argument");
+    JH_HIP(hipSetDevice(d->ctx->device));
+    auto A = std::make_unique<jh_csr_s>();
+    A->ctx = d->ctx;
+    A->pat = d->pat;
+    A->disc = d;
+    size_t cnt = (size_t)d->nnzb * d->N * d->N;
+    A->val.alloc(cnt);
+    JH_HIP(hipMemsetAsync(A->val.p, 0, cnt * sizeof(double), d->ctx->stream));
+    *out = A.release();
+  });
+}
+extern "C" int32_t jh_csr_create_from_pattern(jh_context ctx, int64_t n, int32_t bs, const int64_t *rowptr,
+                                              const int64_t *colidx, const double *nz, jh_csr *out) {
+  return guard([&] {
+    if (!ctx || !rowptr || !colidx || !out) JH_THROW("null argument");
+    if (bs < 1 || bs > 3) JH_THROW("block size must be 1..3");
+    if (rowptr[0] != 1) JH_THROW("rowptr must be 1-based");
+    JH_HIP(hipSetDevice(ctx->device));
+    auto pat = std::make_shared<Pattern>();
+    pat->ctx = ctx;
+    pat->n = n;
+    pat->bs = bs;
+    pat->nnzb = rowptr[n] - 1;
+    if (pat->nnzb > 2000000000LL) JH_THROW("too many non-zeros for 32-bit device indices");
+    pat->rowptr.resize(n + 1);
+    pat->col.resize(pat->nnzb);
+    pat->diag.assign(n, -1);
+    for (int64_t i = 0; i <= n; ++i) pat->rowptr[i] = (int32_t)(rowptr[i] - 1);
+    for (int64_t i = 0; i < n; ++i)
+      for (int64_t k = rowptr[i] - 1; k < rowptr[i + 1] - 1; ++k) {
+        int64_t c = colidx[k] - 1;
+        if (c < 0 || c >= n) JH_THROW("column index out of range");
+        if (k > rowptr[i] - 1 && colidx[k] <= colidx[k - 1]) JH_THROW("columns must be ascending within a row (mat.jl:73-76)");
+        pat->col[k] = (int32_t)c;
+        if (c == i) pat->diag[i] = (int32_t)k;
+      }
+    pat->build_tiles();
+    pat->upload();
+    auto A = std::make_unique<jh_csr_s>();
+    A->ctx = ctx;
+    A->pat = pat;
+    size_t cnt = (size_t)pat->nnzb * bs * bs;
+    A->val.alloc(cnt);
+    if (nz) JH_HIP(hipMemcpyAsync(A->val.p, nz, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    else JH_HIP(hipMemsetAsync(A->val.p, 0, cnt * sizeof(double), ctx->stream));
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+    *out = A.release();
+  });
+}
+extern "C" int32_t jh_csr_destroy(jh_csr A) {
+  return guard([&] { delete A; });
+}
+extern "C" int32_t jh_csr_sizes(jh_csr A, int64_t *n, int64_t *nnzb, int32_t *bs) {
+  return guard([&] {
+    if (!A) JH_THROW("null handle");
+    if (n) *n = A->pat->n;
+    if (nnzb) *nnzb = A->pat->nnzb;
+    if (bs) *bs = A->pat->bs;
+  });
+}
+extern "C" int32_t jh_csr_set_values(jh_csr A, const double *nz) {
+  return guard([&] {
+    if (!A || !nz) JH_THROW("null argument");
+    jh_context ctx = A->ctx;
+    JH_HIP(hipSetDevice(ctx->device));
+    const Pattern &P = *A->pat;
+    int bb = P.bs * P.bs;
+    size_t cnt = (size_t)P.nnzb * bb;
+    if (P.nz_hslot.empty()) {
+      JH_HIP(hipMemcpyAsync(A->val.p, nz, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      ctx->ensure_stage(cnt);
+      JH_HIP(hipMemcpyAsync(ctx->stage.p, nz, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      k_gather_blocks(ctx->stream, A->val.p, ctx->stage.p, P.d_nz_hslot.p, P.nnzb, bb, false);
+    }
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+extern "C" int32_t jh_csr_get_values(jh_csr A, double *nz) {
+  return guard([&] {
+    if (!A || !nz) JH_THROW("null argument");
+    jh_context ctx = A->ctx;
+    JH_HIP(hipSetDevice(ctx->device));
+    const Pattern &P = *A->pat;
+    int bb = P.bs * P.bs;
+    size_t cnt = (size_t)P.nnzb * bb;
+    if (P.nz_hslot.empty()) {
+      JH_HIP(hipMemcpyAsync(nz, A->val.p, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+      ctx->ensure_stage(cnt);
+      k_gather_blocks(ctx->stream, ctx->stage.p, A->val.p, P.d_nz_hslot.p, P.nnzb, bb, true);
+      JH_HIP(hipMemcpyAsync(nz, ctx->stage.p, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+extern "C" int32_t jh_spmv(jh_csr A, jh_vec x, jh_vec y, double alpha, double beta) {
+  return guard([&] {
+    if (!A || !x || !y) JH_THROW("null argument");
+    int64_t len = A->pat->n * A->pat->bs;
+    if (x->len != len || y->len != len) JH_THROW("DimensionMismatch (mat.jl:27-28)");
+    if (x == y) JH_THROW("x and y must not alias");
+    JH_HIP(hipSetDevice(A->ctx->device));
+    k_spmv(A->ctx, *A->pat, A->val.p, x->d.p, y->d.p, alpha, beta);
+    JH_HIP(hipGetLastError());
+  });
+}
+extern "C" int32_t jh_unit_diagonalize(jh_csr A, jh_vec r, int64_t n_owned) {
+  return guard([&] {
+    if (!A || !r) JH_THROW("null argument");
+    k_unit_diag(A->ctx->stream, *A->pat, A->val.p, r->d.p, n_owned);
+  });
+}
+
+// ---- conservation law -----------------------------------------------------------------------------------------------
+extern "C" int32_t jh_law_create(jh_tpfa d, int32_t kind, const double *params, jh_law *out) {
+  return guard([&] {
+    if (!d || !out) JH_THROW("null argument");
+    int N = (kind == JH_LAW_TWOPHASE) ? 2 : 1;
+    if (kind < 0 || kind > 2) JH_THROW("unknown law kind");
+    if (N != d->N) JH_THROW("law needs block_n = " + std::to_string(N) + " but the discretisation has " + std::to_string(d->N));
+    JH_HIP(hipSetDevice(d->ctx->device));
+    auto L = std::make_unique<jh_law_s>();
+    L->ctx = d->ctx;
+    L->disc = d;
+    L->kind = kind;
+    L->N = N;
+    if (params) std::memcpy(L->par, params, 7 * sizeof(double));
+    L->X.alloc((size_t)d->nc * N);
+    L->X0.alloc((size_t)d->nc * N);
+    L->Tnz.alloc(d->nnzb);
+    hipStream_t s = d->ctx->stream;
+    JH_HIP(hipMemsetAsync(L->X.p, 0, L->X.n * sizeof(double), s));
+    JH_HIP(hipMemsetAsync(L->X0.p, 0, L->X0.n * sizeof(double), s));
+    JH_HIP(hipMemsetAsync(L->Tnz.p, 0, L->Tnz.n * sizeof(double), s));
+    k_set_diag_data(s, L->Tnz.p, d->pat->d_diag.p, nullptr, nullptr, d->nc, true, 1.0);  // vol = 1 (Poisson default)
+    JH_HIP(hipStreamSynchronize(s));
+    *out = L.release();
+  });
+}
+extern "C" int32_t jh_law_destroy(jh_law L) {
+  return guard([&] { delete L; });
+}
+extern "C" int32_t jh_law_set_data(jh_law L, int32_t which, const double *host) {
+  return guard([&] {
+    if (!L || !host) JH_THROW("null argument");
+    jh_context ctx = L->ctx;
+    jh_tpfa d = L->disc;
+    JH_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (which == JH_FACE_TRANS || which == JH_FACE_GDZ) {
+      ctx->ensure_stage(std::max<size_t>(d->nf, 1));
+      JH_HIP(hipMemcpyAsync(ctx->stage.p, host, d->nf * sizeof(double), hipMemcpyHostToDevice, s));
+      if (which == JH_FACE_TRANS) {
+        k_gather_face_data(s, L->Tnz.p, d->d_nz_face.p, ctx->stage.p, d->nnzb, false);
+      } else {
+        if (L->gnz.n == 0) { L->gnz.alloc(d->nnzb); JH_HIP(hipMemsetAsync(L->gnz.p, 0, d->nnzb * sizeof(double), s)); }
+        k_gather_face_data(s, L->gnz.p, d->d_nz_face.p, ctx->stage.p, d->nnzb, true);
+        L->has_gdz = true;
+      }
+    } else if (which == JH_CELL_VOLUME) {
+      ctx->ensure_stage(d->nc);
+      JH_HIP(hipMemcpyAsync(ctx->stage.p, host, d->nc * sizeof(double), hipMemcpyHostToDevice, s));
+      k_set_diag_data(s, L->Tnz.p, d->pat->d_diag.p, d->pat->perm.empty() ? nullptr : d->pat->d_perm.p, ctx->stage.p, d->nc, false, 0.0);
+    } else {
+      JH_THROW("unknown data id");
+    }
+    JH_HIP(hipStreamSynchronize(s));
+  });
+}
+extern "C" int32_t jh_law_set_state(jh_law L, const double *X) {
+  return guard([&] {
+    if (!L || !X) JH_THROW("null argument");
+    upload_cells(L->ctx, *L->disc->pat, L->X.p, X, L->disc->nc, L->N);
+  });
+}
+extern "C" int32_t jh_law_set_state0(jh_law L, const double *X0) {
+  return guard([&] {
+    if (!L || !X0) JH_THROW("null argument");
+    upload_cells(L->ctx, *L->disc->pat, L->X0.p, X0, L->disc->nc, L->N);
+  });
+}
+extern "C" int32_t jh_law_get_state(jh_law L, double *X) {
+  return guard([&] {
+    if (!L || !X) JH_THROW("null argument");
+    download_cells(L->ctx, *L->disc->pat, X, L->X.p, L->disc->nc, L->N);
+  });
+}
+extern "C" int32_t jh_law_update_state0(jh_law L) {
+  return guard([&] { k_copy(L->ctx->stream, L->X0.p, L->X.p, (int64_t)L->X.n); });
+}
+extern "C" int32_t jh_law_reset_state(jh_law L) {
+  return guard([&] { k_copy(L->ctx->stream, L->X.p, L->X0.p, (int64_t)L->X.n); });
+}
+extern "C" int32_t jh_law_set_sources(jh_law L, int64_t n, const int64_t *cells, const double *values) {
+  return guard([&] {
+    if (!L) JH_THROW("null argument");
+    JH_HIP(hipSetDevice(L->ctx->device));
+    const Pattern &P = *L->disc->pat;
+    // pre-sum duplicates: the reference adds every source in sequence (variable_poisson.jl:78-84)
+    std::vector<int32_t> cs;
+    std::vector<double> vs;
+    std::vector<int64_t> where(L->disc->nc, -1);
+    for (int64_t i = 0; i < n; ++i) {
+      int64_t c = cells[i] - 1;
+      if (c < 0 || c >= L->disc->nc) JH_THROW("source cell out of range");
+      if (where[c] < 0) {
+        where[c] = (int64_t)cs.size();
+        cs.push_back(P.iperm.empty() ? (int32_t)c : P.iperm[c]);
+        for (int e = 0; e < L->N; ++e) vs.push_back(values[i * L->N + e]);
+      } else {
+        for (int e = 0; e < L->N; ++e) vs[where[c] * L->N + e] += values[i * L->N + e];
+      }
+    }
+    L->nsrc = (int64_t)cs.size();
+    if (L->nsrc) {
+      L->src_cell.upload(cs, L->ctx->stream);
+      L->src_val.upload(vs, L->ctx->stream);
+      JH_HIP(hipStreamSynchronize(L->ctx->stream));
+    }
+  });
+}
+extern "C" int32_t jh_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
+  return guard([&] {
+    if (!L || !A || !r) JH_THROW("null argument");
+    if (A->pat != L->disc->pat) JH_THROW("matrix does not belong to the law's discretisation");
+    if (r->len != L->disc->nc * L->N) JH_THROW("residual has wrong length");
+    if (L->kind != JH_LAW_POISSON && !(dt > 0)) JH_THROW("dt must be positive");
+    JH_HIP(hipSetDevice(L->ctx->device));
+    k_assemble(L, dt, A, r);
+    JH_HIP(hipGetLastError());
+  });
+}
+extern "C" int32_t jh_convergence(jh_law L, jh_vec r, int64_t n_owned, double *err) {
+  return guard([&] {
+    if (!L || !r || !err) JH_THROW("null argument");
+    JH_HIP(hipSetDevice(L->ctx->device));
+    if (n_owned <= 0) n_owned = L->disc->nc;
+    k_absmax_strided(L->ctx, r->d.p, n_owned, L->N, 12);
+    read_scalars(L->ctx, 12, L->N, err);
+  });
+}
+extern "C" int32_t jh_update_primary(jh_law L, jh_vec dx, double w, const double *limits) {
+  return guard([&] {
+    if (!L || !dx) JH_THROW("null argument");
+    JH_HIP(hipSetDevice(L->ctx->device));
+    const double *lim_dev = nullptr;
+    if (limits) {
+      JH_HIP(hipMemcpyAsync(L->ctx->scalars.p + 16, limits, 5 * L->N * sizeof(double), hipMemcpyHostToDevice, L->ctx->stream));
+      lim_dev = L->ctx->scalars.p + 16;
+      JH_HIP(hipStreamSynchronize(L->ctx->stream));
+    }
+    k_update_primary(L, dx->d.p, w, lim_dev);
+    JH_HIP(hipGetLastError());
+  });
+}
+extern "C" int32_t jh_halo_exchange(jh_tpfa d, jh_vec v) {
+  return guard([&] {
+    if (!d || !v) JH_THROW("null argument");
+    JH_HIP(hipSetDevice(d->ctx->device));
+    halo_exchange(d, v->d.p, v->bs);
+  });
+}
+extern "C" int32_t jh_halo_exchange_state(jh_law L) {
+  return guard([&] {
+    if (!L) JH_THROW("null argument");
+    JH_HIP(hipSetDevice(L->ctx->device));
+    halo_exchange(L->disc, L->X.p, L->N);
+  });
+}

@@ -1,0 +1,307 @@
+// Fused TPFA flux + residual/Jacobian assembly (a-5 + a-6) for gfx950.
+//
+// Reference: update_half_face_flux_tpfa! materialises Dual arrays acc[ne,nc], hf[ne,nhf] (conservation.jl:
+// 558-626) and fill_conservation_eq! re-reads them and scatters through 8-byte position tables
+// (conservation.jl:373-430).  Here the half-face data is permuted ONCE at setup into the Jacobian's CSR
+// order ("sorted half-face permutation": per device nnz a transmissibility and a signed face id), so that
+// the flux of cell `row` towards `col[k]` and ALL its derivatives are produced while streaming row `row`:
+//     r[row]            = acc + sum_k q(row -> col_k)
+//     J[row,row]        = d acc/d x_row + sum_k d q_k / d x_row
+//     J[row,col_k]      = d q_k / d x_col_k   ( == -d q(col_k -> row)/d x_col_k, what the reference stores
+//                                               from the neighbour's half-face; two-point fluxes are
+//                                               antisymmetric, conservation.jl:397-415)
+// Every nzval slot is written exactly once, coalesced, with no position table and no intermediate Dual
+// arrays.  A 256-thread workgroup owns a tile of consecutive rows (<= 1024 entries): lanes stream
+// (col, T) pairs, gather the neighbour's primary variables, stage flux values/derivatives in LDS and one
+// lane per row reduces its row segment.  Bound: HBM; algorithmic bytes 44*nc + 20*nhf for N = 1.
+#include "jh_internal.hpp"
+
+namespace jh {
+
+__device__ __forceinline__ int xcd_tile_a(int b, int ntiles) {
+  int chunk = (ntiles + NUM_XCD - 1) / NUM_XCD;
+  return (b % NUM_XCD) * chunk + b / NUM_XCD;
+}
+
+// ---- forward-mode duals over the 2N primary variables of (self, other) ------------------------------------------
+template <int NP>
+struct Dual {
+  double v;
+  double d[NP];
+};
+template <int NP> __device__ __forceinline__ Dual<NP> dconst(double v) {
+  Dual<NP> r; r.v = v;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = 0.0;
+  return r;
+}
+template <int NP> __device__ __forceinline__ Dual<NP> dvar(double v, int idx) {
+  Dual<NP> r = dconst<NP>(v);
+  r.d[idx] = 1.0;
+  return r;
+}
+template <int NP> __device__ __forceinline__ Dual<NP> operator+(Dual<NP> a, Dual<NP> b) {
+  Dual<NP> r; r.v = a.v + b.v;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] + b.d[i];
+  return r;
+}
+template <int NP> __device__ __forceinline__ Dual<NP> operator-(Dual<NP> a, Dual<NP> b) {
+  Dual<NP> r; r.v = a.v - b.v;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] - b.d[i];
+  return r;
+}
+template <int NP> __device__ __forceinline__ Dual<NP> operator*(Dual<NP> a, Dual<NP> b) {
+  Dual<NP> r; r.v = a.v * b.v;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+  return r;
+}
+template <int NP> __device__ __forceinline__ Dual<NP> operator*(double s, Dual<NP> a) {
+  Dual<NP> r; r.v = s * a.v;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = s * a.d[i];
+  return r;
+}
+template <int NP> __device__ __forceinline__ Dual<NP> ddiv(Dual<NP> a, double s) {
+  Dual<NP> r; r.v = a.v / s;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] / s;
+  return r;
+}
+template <int NP> __device__ __forceinline__ Dual<NP> dexp(Dual<NP> a) {
+  double e = exp(a.v);
+  Dual<NP> r; r.v = e;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = e * a.d[i];
+  return r;
+}
+
+struct LawPar {
+  double rho0[2], comp[2], mu[2], p_ref;
+};
+template <int NP> __device__ __forceinline__ Dual<NP> density(const LawPar &P, int ph, Dual<NP> p) {
+  return P.rho0[ph] * dexp(P.comp[ph] * (p - dconst<NP>(P.p_ref)));  // rho0*exp(c*(p-p0))
+}
+
+// ---- the kernel -------------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
+    const int32_t *__restrict__ tile_row, int ntiles, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ diag, const double *__restrict__ Tnz, const double *__restrict__ gnz, const double *__restrict__ X,
+    const double *__restrict__ X0, double *__restrict__ nz, double *__restrict__ r, double dt, LawPar par, int reg_row) {
+  constexpr int N = (KIND == JH_LAW_TWOPHASE) ? 2 : 1;
+  constexpr int NN = N * N;
+  __shared__ double qv[TILE_NNZ * N];    // flux values per entry
+  __shared__ double dsv[TILE_NNZ * NN];  // d q / d x_self per entry (column-major N x N)
+  __shared__ double xs[TILE_ROWS * N];   // primary variables of the tile's rows
+  __shared__ int32_t rp[TILE_ROWS + 1];
+  __shared__ uint8_t rowof[TILE_NNZ];
+  const int t = xcd_tile_a(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int r0 = tile_row[t], r1 = tile_row[t + 1];
+  const int nrows = r1 - r0;
+  const int base = rowptr[r0];
+  const int cnt = rowptr[r1] - base;  // TPFA rows are short: cnt <= TILE_NNZ is guaranteed by the host (checked)
+  const int tid = threadIdx.x;
+  for (int i = tid; i <= nrows; i += TILE_THREADS) rp[i] = rowptr[r0 + i] - base;
+  for (int i = tid; i < nrows * N; i += TILE_THREADS) xs[i] = X[(size_t)r0 * N + i];
+  __syncthreads();
+  if (tid < nrows)
+    for (int j = rp[tid]; j < rp[tid + 1]; ++j) rowof[j] = (uint8_t)tid;
+  __syncthreads();
+  // ---- phase 1: one lane per CSR entry -------------------------------------------------------------------
+  for (int k = tid; k < cnt; k += TILE_THREADS) {
+    const int lr = rowof[k];
+    const int c = col[base + k];
+    const double T = Tnz[base + k];
+    if (c == r0 + lr) {  // diagonal slot: no flux; written by the row lane in phase 2
+#pragma unroll
+      for (int e = 0; e < N; ++e) qv[k * N + e] = 0.0;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) dsv[k * NN + i] = 0.0;
+      continue;
+    }
+    if (KIND == JH_LAW_POISSON) {
+      // q = -K[face]*(U_other - U_self)  (variable_poisson.jl:99,124); dq/dU_self = K, dq/dU_other = -K
+      const double Us = xs[lr];
+      const double Uo = (c >= r0 && c < r1) ? xs[c - r0] : X[c];
+      qv[k] = -(T * (Uo - Us));
+      dsv[k] = T;
+      nz[base + k] = -T;
+    } else if (KIND == JH_LAW_COMPRESSIBLE) {
+      const double gz = gnz ? gnz[base + k] : 0.0;
+      Dual<2> ps = dvar<2>(xs[lr], 0);
+      Dual<2> po = dvar<2>((c >= r0 && c < r1) ? xs[c - r0] : X[c], 1);
+      Dual<2> rs = density(par, 0, ps), ro = density(par, 0, po);
+      Dual<2> ravg = 0.5 * (rs + ro);             // face_average (flux.jl:372-375)
+      Dual<2> dphi = (ps - po) + gz * ravg;       // two_point_potential_drop (flux.jl:335-338)
+      Dual<2> q = (T / par.mu[0]) * (ravg * dphi);
+      qv[k] = q.v;
+      dsv[k] = q.d[0];
+      nz[base + k] = q.d[1];
+    } else {
+      const double gz = gnz ? gnz[base + k] : 0.0;
+      const bool inl = (c >= r0 && c < r1);
+      Dual<4> ps = dvar<4>(xs[lr * 2], 0), ss_w = dvar<4>(xs[lr * 2 + 1], 1);
+      Dual<4> po = dvar<4>(inl ? xs[(c - r0) * 2] : X[(size_t)c * 2], 2);
+      Dual<4> so_w = dvar<4>(inl ? xs[(c - r0) * 2 + 1] : X[(size_t)c * 2 + 1], 3);
+      double *blk = nz + (size_t)(base + k) * 4;
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        Dual<4> rs = density(par, ph, ps), ro = density(par, ph, po);
+        Dual<4> ravg = 0.5 * (rs + ro);
+        Dual<4> dphi = (ps - po) + gz * ravg;
+        Dual<4> ss = ph == 0 ? ss_w : dconst<4>(1.0) - ss_w;
+        Dual<4> so = ph == 0 ? so_w : dconst<4>(1.0) - so_w;
+        Dual<4> ms = (1.0 / par.mu[ph]) * ((ss * ss) * rs);
+        Dual<4> mo = (1.0 / par.mu[ph]) * ((so * so) * ro);
+        Dual<4> up = (dphi.v < 0.0) ? mo : ms;  // SPU upwind (flux.jl:382-405)
+        Dual<4> q = T * (up * dphi);
+        qv[k * 2 + ph] = q.v;
+        dsv[k * 4 + 0 * 2 + ph] = q.d[0];  // (e=ph, d=0) column-major
+        dsv[k * 4 + 1 * 2 + ph] = q.d[1];
+        blk[0 * 2 + ph] = q.d[2];
+        blk[1 * 2 + ph] = q.d[3];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: one lane per row ----------------------------------------------------------------------------------
+  if (tid < nrows) {
+    const int row = r0 + tid;
+    double ar[N], ap[NN];
+    int dk = -1;
+    // accumulation term (update_accumulation!, conservation.jl:558-568): (M - M0)/dt as a Dual wrt own cell
+    {
+      // diagonal slot of Tnz carries the accumulation coefficient vol*phi of this row
+      dk = diag[row] - base;
+      const double vol = Tnz[base + dk];
+      if (KIND == JH_LAW_POISSON) {
+        const double U = xs[tid];
+        if (dt > 0.0) {
+          ar[0] = (vol * U - vol * X0[row]) / dt;
+          ap[0] = vol / dt;
+        } else {  // stationary variant with the 1e-10*U regulariser on host cell 1 (variable_poisson.jl:101-104)
+          ar[0] = (row == reg_row) ? 1e-10 * U : 0.0;
+          ap[0] = (row == reg_row) ? 1e-10 : 0.0;
+        }
+      } else if (KIND == JH_LAW_COMPRESSIBLE) {
+        Dual<2> p = dvar<2>(xs[tid], 0);
+        Dual<2> M = vol * density(par, 0, p);
+        double M0 = vol * density(par, 0, dconst<2>(X0[row])).v;
+        Dual<2> a = ddiv(M - dconst<2>(M0), dt);
+        ar[0] = a.v;
+        ap[0] = a.d[0];
+      } else {
+        Dual<4> p = dvar<4>(xs[tid * 2], 0), sw = dvar<4>(xs[tid * 2 + 1], 1);
+        Dual<4> so = dconst<4>(1.0) - sw;
+        const double p0 = X0[(size_t)row * 2], sw0 = X0[(size_t)row * 2 + 1];
+        Dual<4> Mw = vol * (density(par, 0, p) * sw);
+        Dual<4> Mo = vol * (density(par, 1, p) * so);
+        double Mw0 = vol * (density(par, 0, dconst<4>(p0)).v * sw0);
+        double Mo0 = vol * (density(par, 1, dconst<4>(p0)).v * (1.0 - sw0));
+        Dual<4> aw = ddiv(Mw - dconst<4>(Mw0), dt), ao = ddiv(Mo - dconst<4>(Mo0), dt);
+        ar[0] = aw.v; ar[1] = ao.v;
+        ap[0] = aw.d[0]; ap[1] = ao.d[0]; ap[2] = aw.d[1]; ap[3] = ao.d[1];  // column-major (e, d)
+      }
+    }
+    for (int j = rp[tid]; j < rp[tid + 1]; ++j) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) ar[e] = ar[e] + qv[j * N + e];
+#pragma unroll
+      for (int i = 0; i < NN; ++i) ap[i] = ap[i] + dsv[j * NN + i];
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) r[(size_t)row * N + e] = ar[e];
+    if (dk >= 0) {
+      double *blk = nz + (size_t)(base + dk) * NN;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) blk[i] = ap[i];
+    }
+  }
+}
+
+__global__ void sources_kernel(double *r, const int32_t *cell, const double *val, int64_t n, int N) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n * N) return;
+  int64_t s = i / N;
+  int e = (int)(i - s * N);
+  // one source entry per (cell, e); duplicates of the same cell must be pre-summed by the host wrapper
+  r[(size_t)cell[s] * N + e] += val[i];
+}
+
+__global__ void gather_face_kernel(double *nzdata, const int32_t *nz_face, const double *face_data, int64_t nnzb, bool sgn) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < nnzb; k += (int64_t)gridDim.x * blockDim.x) {
+    int f = nz_face[k];
+    if (f == 0) continue;  // diagonal slot holds cell data
+    double v = face_data[(f > 0 ? f : -f) - 1];
+    nzdata[k] = (sgn && f < 0) ? -v : v;
+  }
+}
+__global__ void set_diag_kernel(double *nzdata, const int32_t *diag, const int32_t *perm, const double *cell_data, int64_t n,
+                                bool use_const, double cval) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    nzdata[diag[i]] = use_const ? cval : cell_data[perm ? perm[i] : i];
+}
+
+void k_gather_face_data(hipStream_t s, double *nzdata, const int32_t *nz_face, const double *face_data, int64_t nnzb, bool sgn) {
+  int g = (int)std::min<int64_t>((nnzb + 255) / 256, 4096);
+  if (nnzb) hipLaunchKernelGGL(gather_face_kernel, dim3(g), dim3(256), 0, s, nzdata, nz_face, face_data, nnzb, sgn);
+}
+void k_set_diag_data(hipStream_t s, double *nzdata, const int32_t *diag, const int32_t *perm, const double *cell_data, int64_t n,
+                     bool use_const, double cval) {
+  int g = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  if (n) hipLaunchKernelGGL(set_diag_kernel, dim3(g), dim3(256), 0, s, nzdata, diag, perm, cell_data, n, use_const, cval);
+}
+
+void k_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
+  const Pattern &P = *A->pat;
+  jh_context ctx = L->ctx;
+  LawPar par;
+  par.rho0[0] = L->par[0]; par.rho0[1] = L->par[1];
+  par.comp[0] = L->par[2]; par.comp[1] = L->par[3];
+  par.mu[0] = L->par[4]; par.mu[1] = L->par[5];
+  par.p_ref = L->par[6];
+  int reg_row = P.iperm.empty() ? 0 : P.iperm[0];
+  int chunk = (P.ntiles + NUM_XCD - 1) / NUM_XCD;
+  dim3 grid(chunk * NUM_XCD), block(TILE_THREADS);
+  const double *g = L->has_gdz ? L->gnz.p : nullptr;
+#define JH_ASM_ARGS P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, P.d_diag.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row
+  switch (L->kind) {
+    case JH_LAW_POISSON: hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_POISSON>, grid, block, 0, ctx->stream, JH_ASM_ARGS); break;
+    case JH_LAW_COMPRESSIBLE: hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_COMPRESSIBLE>, grid, block, 0, ctx->stream, JH_ASM_ARGS); break;
+    case JH_LAW_TWOPHASE: hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_TWOPHASE>, grid, block, 0, ctx->stream, JH_ASM_ARGS); break;
+    default: JH_THROW("unknown law kind");
+  }
+#undef JH_ASM_ARGS
+  if (L->nsrc)
+    hipLaunchKernelGGL(sources_kernel, dim3((unsigned)((L->nsrc * L->N + 255) / 256)), dim3(256), 0, ctx->stream, r->d.p,
+                       L->src_cell.p, L->src_val.p, L->nsrc, L->N);
+}
+
+// update_primary_variables! / choose_increment (variables/utils.jl:146-174): scale -> abs -> rel -> lower -> upper
+__global__ void update_primary_kernel(double *X, const double *dx, double w, int64_t n, int N, const double *lim) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * N; i += (int64_t)gridDim.x * blockDim.x) {
+    int e = (int)(i % N);
+    double v = X[i];
+    double dv = w * dx[i];
+    if (lim) {
+      const double scale = lim[5 * e + 0], amax = lim[5 * e + 1], rmax = lim[5 * e + 2], lo = lim[5 * e + 3], hi = lim[5 * e + 4];
+      if (scale == scale) dv = dv * scale;
+      if (amax == amax) dv = copysign(1.0, dv) * fmin(fabs(dv), amax) * (dv == 0.0 ? 0.0 : 1.0);
+      if (rmax == rmax) { double a = rmax * fabs(v); dv = copysign(1.0, dv) * fmin(fabs(dv), a) * (dv == 0.0 ? 0.0 : 1.0); }
+      if (lo == lo) dv = fmax(dv, lo - v);
+      if (hi == hi) dv = fmin(dv, hi - v);
+    }
+    X[i] = v + dv;
+  }
+}
+void k_update_primary(jh_law L, const double *dx, double w, const double *limits_dev) {
+  int64_t n = L->disc->nc;
+  int g = (int)std::min<int64_t>((n * L->N + 255) / 256, 2048);
+  hipLaunchKernelGGL(update_primary_kernel, dim3(g), dim3(256), 0, L->ctx->stream, L->X.p, dx, w, n, L->N, limits_dev);
+}
+
+}  // namespace jh

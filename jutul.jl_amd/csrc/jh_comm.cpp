@@ -1,0 +1,184 @@
+// RCCL-over-xGMI communication for the domain-decomposed path (a-16/a-17).
+//
+// Reference semantics (ext/JutulPartitionedArraysExt): `consistent!(v)` copies owner values to the ghost copies
+// on neighbouring ranks (linalg.jl:46, krylov.jl:54,75, interface.jl:200); dots/norms are local sums over OWNED
+// entries + a scalar all-reduce.  One process per GPU; the library talks RCCL directly on the context's HIP
+// stream so the Krylov loop never returns to the host language between collectives.  librccl is dlopen'ed
+// lazily: single-GPU use has no RCCL dependency, and inside a PyTorch process the already-loaded librccl.so.1
+// is reused.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "jh_internal.hpp"
+
+namespace jh {
+
+struct Rccl {
+  void *h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static Rccl &rccl() {
+  static Rccl R;
+  if (R.h) return R;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *nm : names) {
+    R.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (R.h) break;
+  }
+  if (!R.h) JH_THROW(std::string("cannot dlopen librccl: ") + dlerror());
+#define JH_SYM(field, name)                                     \
+  *(void **)(&R.field) = dlsym(R.h, name);                      \
+  if (!R.field) JH_THROW(std::string("librccl lacks ") + name);
+  JH_SYM(GetUniqueId, "ncclGetUniqueId");
+  JH_SYM(CommInitRank, "ncclCommInitRank");
+  JH_SYM(CommDestroy, "ncclCommDestroy");
+  JH_SYM(AllReduce, "ncclAllReduce");
+  JH_SYM(Send, "ncclSend");
+  JH_SYM(Recv, "ncclRecv");
+  JH_SYM(GroupStart, "ncclGroupStart");
+  JH_SYM(GroupEnd, "ncclGroupEnd");
+  JH_SYM(GetErrorString, "ncclGetErrorString");
+#undef JH_SYM
+  return R;
+}
+
+#define JH_NCCL(expr)                                                                              \
+  do {                                                                                             \
+    ncclResult_t _r = (expr);                                                                      \
+    if (_r != ncclSuccess) JH_THROW(std::string("RCCL error: ") + rccl().GetErrorString(_r) + " in " #expr); \
+  } while (0)
+
+struct Comm {
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+};
+
+int comm_size(jh_context ctx) { return ctx->comm ? ctx->comm->nranks : 1; }
+int comm_rank(jh_context ctx) { return ctx->comm ? ctx->comm->rank : 0; }
+
+// in-stream all-reduce of n doubles living in device memory; no-op without a communicator
+void comm_allreduce_dev(jh_context ctx, double *p, int n, int op) {
+  if (!ctx->comm || ctx->comm->nranks == 1) return;
+  JH_NCCL(rccl().AllReduce(p, p, (size_t)n, ncclFloat64, op == 1 ? ncclMax : ncclSum, ctx->comm->comm, ctx->stream));
+}
+
+void halo_pack_launch(hipStream_t s, double *buf, const double *v, const int32_t *idx, int64_t n, int bs);
+void halo_unpack_launch(hipStream_t s, double *v, const double *buf, const int32_t *idx, int64_t n, int bs);
+
+// consistent!(v): pack owned values -> grouped ncclSend/ncclRecv per neighbour -> unpack into ghost rows
+void halo_exchange(jh_tpfa d, double *v, int bs) {
+  auto &H = d->halo;
+  if (!H.active) return;
+  jh_context ctx = d->ctx;
+  if (!ctx->comm) JH_THROW("halo exchange without a communicator (jh_comm_init)");
+  hipStream_t s = ctx->stream;
+  if (H.n_send) halo_pack_launch(s, H.d_send_buf.p, v, H.d_send_idx.p, H.n_send, bs);
+  Rccl &R = rccl();
+  JH_NCCL(R.GroupStart());
+  for (size_t i = 0; i < H.nbr.size(); ++i) {
+    int64_t ns = H.send_ptr[i + 1] - H.send_ptr[i], nr = H.recv_ptr[i + 1] - H.recv_ptr[i];
+    if (ns) JH_NCCL(R.Send(H.d_send_buf.p + H.send_ptr[i] * bs, (size_t)(ns * bs), ncclFloat64, H.nbr[i], ctx->comm->comm, s));
+    if (nr) JH_NCCL(R.Recv(H.d_recv_buf.p + H.recv_ptr[i] * bs, (size_t)(nr * bs), ncclFloat64, H.nbr[i], ctx->comm->comm, s));
+  }
+  JH_NCCL(R.GroupEnd());
+  if (H.n_recv) halo_unpack_launch(s, v, H.d_recv_buf.p, H.d_recv_idx.p, H.n_recv, bs);
+}
+
+}  // namespace jh
+
+using namespace jh;
+
+extern "C" int32_t jh_comm_unique_id(char *id128) {
+  return guard([&] {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    JH_NCCL(rccl().GetUniqueId(&id));
+    std::memcpy(id128, &id, 128);
+  });
+}
+
+extern "C" int32_t jh_comm_init(jh_context ctx, int32_t nranks, int32_t rank, const char *id128) {
+  return guard([&] {
+    if (!ctx) JH_THROW("null context");
+    if (ctx->comm) JH_THROW("communicator already initialised");
+    JH_HIP(hipSetDevice(ctx->device));
+    auto c = std::make_unique<Comm>();
+    c->nranks = nranks;
+    c->rank = rank;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, 128);
+    JH_NCCL(rccl().CommInitRank(&c->comm, nranks, id, rank));
+    ctx->comm = c.release();
+  });
+}
+
+extern "C" int32_t jh_comm_finalize(jh_context ctx) {
+  return guard([&] {
+    if (!ctx || !ctx->comm) return;
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm->comm) rccl().CommDestroy(ctx->comm->comm);
+    delete ctx->comm;
+    ctx->comm = nullptr;
+  });
+}
+
+extern "C" int32_t jh_allreduce(jh_context ctx, double *values, int32_t n, int32_t op) {
+  return guard([&] {
+    if (!ctx) JH_THROW("null context");
+    if (!ctx->comm || ctx->comm->nranks == 1) return;
+    if (n > 16) JH_THROW("jh_allreduce handles at most 16 scalars");
+    JH_HIP(hipSetDevice(ctx->device));
+    double *dev = ctx->scalars.p + 16;
+    JH_HIP(hipMemcpyAsync(dev, values, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    comm_allreduce_dev(ctx, dev, n, op);
+    JH_HIP(hipMemcpyAsync(values, dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+// Halo plan: host gives, per neighbour rank, the local owned cells to send and the local ghost cells to receive
+// (1-based HOST numbering of this rank's discretisation).
+extern "C" int32_t jh_halo_create(jh_tpfa d, int64_t n_owned, int32_t n_nbr, const int32_t *nbr_rank, const int64_t *send_ptr,
+                                  const int64_t *send_cells, const int64_t *recv_ptr, const int64_t *recv_cells) {
+  return guard([&] {
+    if (!d) JH_THROW("null handle");
+    const Pattern &P = *d->pat;
+    auto &H = d->halo;
+    H.n_owned = n_owned;
+    H.nbr.assign(nbr_rank, nbr_rank + n_nbr);
+    H.send_ptr.assign(send_ptr, send_ptr + n_nbr + 1);
+    H.recv_ptr.assign(recv_ptr, recv_ptr + n_nbr + 1);
+    H.n_send = H.send_ptr[n_nbr] - H.send_ptr[0];
+    H.n_recv = H.recv_ptr[n_nbr] - H.recv_ptr[0];
+    if (H.send_ptr[0] != 0 || H.recv_ptr[0] != 0) JH_THROW("send_ptr/recv_ptr must start at 0");
+    std::vector<int32_t> si(H.n_send), ri(H.n_recv);
+    for (int64_t i = 0; i < H.n_send; ++i) {
+      int64_t c = send_cells[i] - 1;
+      if (c < 0 || c >= n_owned) JH_THROW("send cell is not an owned cell");
+      si[i] = P.iperm.empty() ? (int32_t)c : P.iperm[c];
+    }
+    for (int64_t i = 0; i < H.n_recv; ++i) {
+      int64_t c = recv_cells[i] - 1;
+      if (c < n_owned || c >= d->nc) JH_THROW("recv cell is not a ghost cell");
+      ri[i] = P.iperm.empty() ? (int32_t)c : P.iperm[c];
+    }
+    hipStream_t s = d->ctx->stream;
+    H.d_send_idx.upload(si, s);
+    H.d_recv_idx.upload(ri, s);
+    H.d_send_buf.alloc(std::max<size_t>(1, (size_t)H.n_send * d->N));
+    H.d_recv_buf.alloc(std::max<size_t>(1, (size_t)H.n_recv * d->N));
+    JH_HIP(hipStreamSynchronize(s));
+    H.active = true;
+  });
+}

@@ -1,0 +1,212 @@
+// Internal declarations of libjutul_hip.so (gfx950 only).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/jutul_hip.h"
+
+namespace jh {
+
+// ---- error handling -------------------------------------------------------------------------------------
+void set_error(const std::string &msg);
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+#define JH_THROW(msg) throw ::jh::Error(std::string(msg))
+#define JH_HIP(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      throw ::jh::Error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " + __FILE__ + ":" + \
+                        std::to_string(__LINE__) + " (" #expr ")");                                     \
+  } while (0)
+
+template <class F>
+static inline int32_t guard(F &&f) noexcept {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception &e) {
+    set_error(e.what());
+    return -1;
+  } catch (...) {
+    set_error("unknown error");
+    return -2;
+  }
+}
+
+// ---- tiling constants for the CSR row-segment kernels ------------------------------------------------
+constexpr int TILE_THREADS = 256;  // 4 wavefronts
+constexpr int TILE_NNZ = 1024;     // block-nnz staged in LDS per workgroup
+constexpr int TILE_ROWS = 256;     // rows per tile (one row-reduce thread each; row id fits uint8)
+constexpr int NUM_XCD = 8;
+
+// ---- device buffer helper ----------------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) JH_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+  }
+  void upload(const T *h, size_t count, hipStream_t s) {
+    if (count > n) alloc(count);
+    if (count) JH_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void upload(const std::vector<T> &h, hipStream_t s) {
+    alloc(h.size());
+    if (!h.empty()) JH_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+};
+
+struct Comm;  // RCCL state (jh_comm.cpp)
+
+}  // namespace jh
+
+// ---- handle structs ------------------------------------------------------------------------------------
+struct jh_context_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // reduction scratch: partial sums [NSLOT][max_blocks], device scalars, pinned host mirror
+  jh::DevBuf<double> partials;
+  size_t partial_stride = 0;
+  jh::DevBuf<double> scalars;  // 32 doubles
+  double *h_scalars = nullptr; // pinned, 32 doubles
+  jh::DevBuf<double> stage;    // staging for permuted uploads/downloads
+  jh::Comm *comm = nullptr;
+  void ensure_stage(size_t n) {
+    if (stage.n < n) stage.alloc(n);
+  }
+};
+
+namespace jh {
+
+// Sparsity pattern in DEVICE numbering shared by matrices / vectors / preconditioners.
+struct Pattern {
+  jh_context ctx = nullptr;
+  int64_t n = 0;     // block rows
+  int64_t nnzb = 0;  // block non-zeros
+  int bs = 1;
+  std::vector<int32_t> rowptr, col, diag;  // host copies, 0-based, device numbering
+  // device order <-> host order (empty => identity)
+  std::vector<int32_t> perm;      // perm[i] = host row at device position i
+  std::vector<int32_t> iperm;     // iperm[host] = device position
+  std::vector<int32_t> nz_hslot;  // device block slot -> host block slot (empty => identity)
+  std::vector<int32_t> block_ptr; // contiguous device row blocks (block-Jacobi partition), may be empty
+  // tiles
+  std::vector<int32_t> tile_row;
+  int32_t ntiles = 0;
+  // device copies
+  DevBuf<int32_t> d_rowptr, d_col, d_diag, d_perm, d_nz_hslot, d_tile_row;
+  void build_tiles();
+  void upload();
+};
+
+}  // namespace jh
+
+struct jh_tpfa_s {
+  jh_context ctx = nullptr;
+  int64_t nc = 0, nf = 0, nhf = 0, nnzb = 0;
+  int N = 1;
+  std::vector<int64_t> Nhost;  // 2*nf, 1-based, as given
+  std::shared_ptr<jh::Pattern> pat;
+  // per device nnz: signed face id (+(f+1) if row cell == N[1,f], -(f+1) if == N[2,f], 0 on the diagonal)
+  std::vector<int32_t> nz_face;
+  jh::DevBuf<int32_t> d_nz_face;
+  // lazily built reference-exact host tables (1-based)
+  bool tables_built = false;
+  std::vector<int64_t> face_pos, hf_self, hf_other, hf_face, hf_sign, h_rowptr, h_colidx, pos_acc, pos_flux;
+  void build_tables();
+  // halo plan (device indices), see jh_comm.cpp
+  struct Halo {
+    int64_t n_owned = 0;
+    std::vector<int32_t> nbr;
+    std::vector<int64_t> send_ptr, recv_ptr;     // per neighbour offsets into send/recv index lists
+    jh::DevBuf<int32_t> d_send_idx, d_recv_idx;  // device row indices
+    jh::DevBuf<double> d_send_buf, d_recv_buf;
+    int64_t n_send = 0, n_recv = 0;
+    bool active = false;
+  } halo;
+};
+
+struct jh_vec_s {
+  jh_context ctx = nullptr;
+  std::shared_ptr<jh::Pattern> pat;  // for the permutation (may be null => identity, plain vector)
+  int64_t len = 0;                   // doubles
+  int bs = 1;
+  jh::DevBuf<double> d;
+};
+
+struct jh_csr_s {
+  jh_context ctx = nullptr;
+  std::shared_ptr<jh::Pattern> pat;
+  jh_tpfa disc = nullptr;  // non-owning, may be null
+  jh::DevBuf<double> val;  // nnzb * bs * bs, device slot order, each block column-major
+};
+
+struct jh_law_s {
+  jh_context ctx = nullptr;
+  jh_tpfa disc = nullptr;
+  int kind = 0, N = 1;
+  double par[7] = {1, 1, 0, 0, 1, 1, 0};
+  jh::DevBuf<double> X, X0;  // [N, nc] device order
+  jh::DevBuf<double> Tnz;    // per device nnz: T_f off-diagonal, accumulation coefficient on the diagonal
+  jh::DevBuf<double> gnz;    // per device nnz: signed gdz (self -> other); empty when no gravity
+  bool has_gdz = false;
+  int64_t nsrc = 0;
+  jh::DevBuf<int32_t> src_cell;
+  jh::DevBuf<double> src_val;
+};
+
+namespace jh {
+
+// ---- kernel launch wrappers (jh_kernels.hip) ----------------------------------------------------------------
+void k_fill(hipStream_t s, double *x, int64_t n, double v);
+void k_copy(hipStream_t s, double *dst, const double *src, int64_t n);
+void k_axpby(hipStream_t s, double *y, double a, const double *x, double b, int64_t n);
+void k_negate(hipStream_t s, double *dst, const double *src, int64_t n);
+void k_permute_in(hipStream_t s, double *dst, const double *src_hostorder, const int32_t *perm, int64_t n, int bs);
+void k_permute_out(hipStream_t s, double *dst_hostorder, const double *src, const int32_t *perm, int64_t n, int bs);
+void k_gather_blocks(hipStream_t s, double *dst, const double *src, const int32_t *slot, int64_t nblk, int bb,
+                     bool scatter);
+// dot products: result(s) land in ctx->scalars[slot..]; deterministic two-stage reduction
+void k_dot(jh_context ctx, const double *a, const double *b, int64_t n, int slot);
+void k_dot2(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, int slot);
+void k_absmax_strided(jh_context ctx, const double *r, int64_t ncell, int bs, int slot);
+double read_scalar(jh_context ctx, int slot);                  // sync + D2H
+void read_scalars(jh_context ctx, int slot, int count, double *out);
+void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta);
+void k_unit_diag(hipStream_t s, const Pattern &P, double *val, double *r, int64_t n_owned);
+
+// ---- assembly (jh_assembly.hip) -------------------------------------------------------------------------------
+void k_gather_face_data(hipStream_t s, double *nzdata, const int32_t *nz_face, const double *face_data, int64_t nnzb,
+                        bool signed_data);
+void k_set_diag_data(hipStream_t s, double *nzdata, const int32_t *diag, const int32_t *perm, const double *cell_data,
+                     int64_t n, bool use_const, double cval);
+void k_assemble(jh_law L, double dt, jh_csr A, jh_vec r);
+void k_update_primary(jh_law L, const double *dx, double w, const double *limits);
+
+}  // namespace jh
+
+// ---- ILU (jh_ilu.hip) -------------------------------------------------------------------------------------------------
+struct jh_ilu_s;
+// ---- Krylov (jh_krylov.hip) ---------------------------------------------------------------------------------------------
+struct jh_krylov_s;

@@ -1,0 +1,307 @@
+// Vector kernels, deterministic reductions and the CSR SpMV (a-10) for gfx950.
+//
+// SpMV design (StaticCSR/mat.jl:24-68 semantics): rows of a TPFA Jacobian are short (~5 block entries on a tet
+// mesh), so one wavefront per row would idle 90% of its lanes.  Instead a 256-thread workgroup owns a TILE of
+// consecutive rows holding <= TILE_NNZ entries: every lane streams (val, col) pairs fully coalesced, gathers
+// x[col], stages the products in LDS, and then one lane per row reduces its LDS row segment left->right (the
+// reference's accumulation order).  Tiles are mapped to XCDs in contiguous chunks so that each XCD's private
+// L2 only ever holds one window of x.  Bound: HBM; algorithmic bytes 12*nnz + 20*n.
+#include "jh_internal.hpp"
+
+namespace jh {
+
+__device__ __forceinline__ int xcd_tile(int b, int ntiles) {
+  // workgroup b runs on XCD b % 8 (observed placement, performance only): give each XCD a contiguous chunk
+  int chunk = (ntiles + NUM_XCD - 1) / NUM_XCD;
+  return (b % NUM_XCD) * chunk + b / NUM_XCD;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// elementwise
+// ---------------------------------------------------------------------------------------------------------
+__global__ void fill_kernel(double *x, int64_t n, double v) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = v;
+}
+__global__ void axpby_kernel(double *y, double a, const double *x, double b, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
+}
+__global__ void permute_in_kernel(double *dst, const double *src, const int32_t *perm, int64_t n, int bs) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * bs; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / bs;
+    int e = (int)(i - r * bs);
+    dst[i] = src[(int64_t)perm[r] * bs + e];
+  }
+}
+__global__ void permute_out_kernel(double *dst, const double *src, const int32_t *perm, int64_t n, int bs) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * bs; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / bs;
+    int e = (int)(i - r * bs);
+    dst[(int64_t)perm[r] * bs + e] = src[i];
+  }
+}
+// dst[k] = src[slot[k]] (gather) or dst[slot[k]] = src[k] (scatter), blocks of bb doubles
+__global__ void gather_blocks_kernel(double *dst, const double *src, const int32_t *slot, int64_t nblk, int bb, bool scatter) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nblk * bb; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t k = i / bb;
+    int e = (int)(i - k * bb);
+    int64_t j = (int64_t)slot[k] * bb + e;
+    if (scatter) dst[j] = src[i]; else dst[i] = src[j];
+  }
+}
+
+static inline int grid_for(int64_t n, int threads = 256) {
+  int64_t g = (n + threads - 1) / threads;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;  // grid-stride beyond 8 blocks/CU
+  return (int)g;
+}
+
+void k_fill(hipStream_t s, double *x, int64_t n, double v) {
+  if (n) hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, n, v);
+}
+void k_copy(hipStream_t s, double *dst, const double *src, int64_t n) {
+  if (n) JH_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+}
+void k_axpby(hipStream_t s, double *y, double a, const double *x, double b, int64_t n) {
+  if (n) hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, a, x, b, n);
+}
+void k_negate(hipStream_t s, double *dst, const double *src, int64_t n) { k_axpby(s, dst, -1.0, src, 0.0, n); }
+void k_permute_in(hipStream_t s, double *dst, const double *src, const int32_t *perm, int64_t n, int bs) {
+  if (n) hipLaunchKernelGGL(permute_in_kernel, dim3(grid_for(n * bs)), dim3(256), 0, s, dst, src, perm, n, bs);
+}
+void k_permute_out(hipStream_t s, double *dst, const double *src, const int32_t *perm, int64_t n, int bs) {
+  if (n) hipLaunchKernelGGL(permute_out_kernel, dim3(grid_for(n * bs)), dim3(256), 0, s, dst, src, perm, n, bs);
+}
+void k_gather_blocks(hipStream_t s, double *dst, const double *src, const int32_t *slot, int64_t nblk, int bb, bool scatter) {
+  if (nblk) hipLaunchKernelGGL(gather_blocks_kernel, dim3(grid_for(nblk * bb)), dim3(256), 0, s, dst, src, slot, nblk, bb, scatter);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// reductions: per-block partial (wave shuffle + LDS), then a single-block ordered final sum => deterministic
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+template <bool MAX>
+__device__ __forceinline__ double block_reduce(double v, double *sm) {
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  v = MAX ? wave_max(v) : wave_sum(v);
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  int nw = blockDim.x >> 6;
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    r = sm[0];
+    for (int i = 1; i < nw; ++i) r = MAX ? fmax(r, sm[i]) : r + sm[i];
+  }
+  __syncthreads();
+  return r;  // valid on thread 0
+}
+
+constexpr int RED_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void dot2_partial_kernel(const double *a, const double *b, const double *c, const double *d,
+                                                           int64_t n, double *part, size_t stride) {
+  __shared__ double sm[8];
+  double s0 = 0, s1 = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    s0 += a[i] * b[i];
+    if (c) s1 += c[i] * d[i];
+  }
+  double r0 = block_reduce<false>(s0, sm);
+  double r1 = c ? block_reduce<false>(s1, sm) : 0.0;
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = r0;
+    if (c) part[stride + blockIdx.x] = r1;
+  }
+}
+__global__ __launch_bounds__(256) void absmax_partial_kernel(const double *r, int64_t ncell, int bs, int e, double *part) {
+  __shared__ double sm[8];
+  double m = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < ncell; i += (int64_t)gridDim.x * blockDim.x) {
+    double v = fabs(r[i * bs + e]);
+    m = (v > m || v != v) ? v : m;  // NaN propagates like Julia's maximum(abs, ...)
+  }
+  double r0 = block_reduce<true>(m, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = r0;
+}
+// final: one block sums nparts partials of `count` slots in fixed order
+template <bool MAX>
+__global__ __launch_bounds__(256) void final_reduce_kernel(const double *part, size_t stride, int nparts, int count, double *out) {
+  __shared__ double sm[8];
+  for (int k = 0; k < count; ++k) {
+    double s = 0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+      double v = part[k * stride + i];
+      s = MAX ? ((v > s || v != v) ? v : s) : s + v;
+    }
+    double r = block_reduce<MAX>(s, sm);
+    if (threadIdx.x == 0) out[k] = r;
+  }
+}
+
+static void ensure_partials(jh_context ctx) {
+  if (ctx->partials.n == 0) {
+    ctx->partial_stride = 65536;  // also used by tile-level partials
+    ctx->partials.alloc(ctx->partial_stride * 4);
+  }
+}
+
+void k_dot2(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, int slot) {
+  ensure_partials(ctx);
+  int g = grid_for(n);
+  if (g > RED_BLOCKS) g = RED_BLOCKS;
+  hipLaunchKernelGGL(dot2_partial_kernel, dim3(g), dim3(256), 0, ctx->stream, a, b, c, d, n, ctx->partials.p, ctx->partial_stride);
+  hipLaunchKernelGGL(final_reduce_kernel<false>, dim3(1), dim3(256), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, g,
+                     c ? 2 : 1, ctx->scalars.p + slot);
+}
+void k_dot(jh_context ctx, const double *a, const double *b, int64_t n, int slot) { k_dot2(ctx, a, b, nullptr, nullptr, n, slot); }
+
+void k_absmax_strided(jh_context ctx, const double *r, int64_t ncell, int bs, int slot) {
+  ensure_partials(ctx);
+  int g = grid_for(ncell);
+  if (g > RED_BLOCKS) g = RED_BLOCKS;
+  for (int e = 0; e < bs; ++e) {
+    hipLaunchKernelGGL(absmax_partial_kernel, dim3(g), dim3(256), 0, ctx->stream, r, ncell, bs, e, ctx->partials.p);
+    hipLaunchKernelGGL(final_reduce_kernel<true>, dim3(1), dim3(256), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, g, 1,
+                       ctx->scalars.p + slot + e);
+  }
+}
+
+void read_scalars(jh_context ctx, int slot, int count, double *out) {
+  JH_HIP(hipMemcpyAsync(ctx->h_scalars + slot, ctx->scalars.p + slot, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+  JH_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < count; ++i) out[i] = ctx->h_scalars[slot + i];
+}
+double read_scalar(jh_context ctx, int slot) {
+  double v;
+  read_scalars(ctx, slot, 1, &v);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SpMV: y = alpha*A*x (+ beta*y)
+// ---------------------------------------------------------------------------------------------------------
+template <int BS>
+__global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *__restrict__ tile_row, int ntiles,
+                                                                 const int32_t *__restrict__ rowptr,
+                                                                 const int32_t *__restrict__ col,
+                                                                 const double *__restrict__ val,
+                                                                 const double *__restrict__ x, double *__restrict__ y,
+                                                                 double alpha, double beta) {
+  __shared__ double prod[TILE_NNZ * BS];
+  __shared__ int32_t rp[TILE_ROWS + 1];
+  __shared__ double red[8];
+  const int t = xcd_tile(blockIdx.x, ntiles);
+  if (t >= ntiles) return;
+  const int r0 = tile_row[t], r1 = tile_row[t + 1];
+  const int nrows = r1 - r0;
+  const int base = rowptr[r0];
+  const int cnt = rowptr[r1] - base;
+  const int tid = threadIdx.x;
+  if (nrows == 1 && cnt > TILE_NNZ) {
+    // long row: the whole workgroup strides over one row, then block-reduces
+    double acc[BS];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) acc[e] = 0.0;
+    for (int k = tid; k < cnt; k += TILE_THREADS) {
+      const int c = col[base + k];
+      if (BS == 1) {
+        acc[0] += val[base + k] * x[c];
+      } else {
+        const double *A = val + (size_t)(base + k) * BS * BS;
+#pragma unroll
+        for (int d = 0; d < BS; ++d) {
+          double xd = x[(size_t)c * BS + d];
+#pragma unroll
+          for (int e = 0; e < BS; ++e) acc[e] += A[d * BS + e] * xd;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < BS; ++e) {
+      double s = block_reduce<false>(acc[e], red);
+      if (tid == 0) {
+        size_t o = (size_t)r0 * BS + e;
+        y[o] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[o];
+      }
+    }
+    return;
+  }
+  for (int i = tid; i <= nrows; i += TILE_THREADS) rp[i] = rowptr[r0 + i] - base;
+  for (int k = tid; k < cnt; k += TILE_THREADS) {
+    const int c = col[base + k];
+    if (BS == 1) {
+      prod[k] = val[base + k] * x[c];
+    } else {
+      const double *A = val + (size_t)(base + k) * BS * BS;
+      double xv[BS], p[BS];
+#pragma unroll
+      for (int d = 0; d < BS; ++d) xv[d] = x[(size_t)c * BS + d];
+#pragma unroll
+      for (int e = 0; e < BS; ++e) {
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < BS; ++d) s += A[d * BS + e] * xv[d];
+        p[e] = s;
+      }
+#pragma unroll
+      for (int e = 0; e < BS; ++e) prod[k * BS + e] = p[e];
+    }
+  }
+  __syncthreads();
+  if (tid < nrows) {
+    double s[BS];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) s[e] = 0.0;
+    for (int j = rp[tid]; j < rp[tid + 1]; ++j) {
+#pragma unroll
+      for (int e = 0; e < BS; ++e) s[e] = s[e] + prod[j * BS + e];
+    }
+#pragma unroll
+    for (int e = 0; e < BS; ++e) {
+      size_t o = (size_t)(r0 + tid) * BS + e;
+      y[o] = (beta == 0.0) ? alpha * s[e] : alpha * s[e] + beta * y[o];
+    }
+  }
+}
+
+void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta) {
+  if (P.n == 0) return;
+  int chunk = (P.ntiles + NUM_XCD - 1) / NUM_XCD;
+  dim3 grid(chunk * NUM_XCD), block(TILE_THREADS);
+  switch (P.bs) {
+    case 1: hipLaunchKernelGGL(spmv_tile_kernel<1>, grid, block, 0, ctx->stream, P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta); break;
+    case 2: hipLaunchKernelGGL(spmv_tile_kernel<2>, grid, block, 0, ctx->stream, P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta); break;
+    case 3: hipLaunchKernelGGL(spmv_tile_kernel<3>, grid, block, 0, ctx->stream, P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta); break;
+    default: JH_THROW("unsupported block size");
+  }
+}
+
+// unit_diagonalize!: ghost rows -> -I, r_ghost -> 0 (ext/JutulPartitionedArraysExt/linalg.jl:18-35)
+__global__ void unit_diag_kernel(const int32_t *rowptr, const int32_t *col, double *val, double *r, int64_t n_owned, int64_t n, int bs) {
+  int64_t row = n_owned + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  for (int e = 0; e < bs; ++e) r[row * bs + e] = 0.0;
+  for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) {
+    double *A = val + (size_t)k * bs * bs;
+    for (int i = 0; i < bs * bs; ++i) A[i] = 0.0;
+    if (col[k] == row)
+      for (int e = 0; e < bs; ++e) A[e * bs + e] = -1.0;
+  }
+}
+void k_unit_diag(hipStream_t s, const Pattern &P, double *val, double *r, int64_t n_owned) {
+  int64_t ng = P.n - n_owned;
+  if (ng <= 0) return;
+  hipLaunchKernelGGL(unit_diag_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, P.d_rowptr.p, P.d_col.p, val, r, n_owned, P.n, P.bs);
+}
+
+}  // namespace jh

@@ -1,0 +1,403 @@
+// Host-side setup of the TPFA discretisation: connectivity (a-1), pattern (a-3), positions (a-4), device
+// ordering, CSR tiles.  Runs once per Simulator setup; everything here is integer work.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <queue>
+
+#include "jh_internal.hpp"
+
+namespace jh {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+const std::string &last_error() { return g_err; }
+
+// --------------------------------------------------------------------------------------------------------------
+// Pattern: tiles + upload
+// --------------------------------------------------------------------------------------------------------------
+void Pattern::build_tiles() {
+  tile_row.clear();
+  tile_row.push_back(0);
+  int64_t r = 0;
+  while (r < n) {
+    int64_t r1 = r;
+    int64_t base = rowptr[r];
+    // always take at least one row (a row longer than TILE_NNZ forms its own tile: "long row" path)
+    ++r1;
+    while (r1 < n && (r1 - r) < TILE_ROWS && (rowptr[r1 + 1] - base) <= TILE_NNZ) ++r1;
+    tile_row.push_back((int32_t)r1);
+    r = r1;
+  }
+  ntiles = (int32_t)tile_row.size() - 1;
+}
+
+void Pattern::upload() {
+  hipStream_t s = ctx->stream;
+  d_rowptr.upload(rowptr, s);
+  d_col.upload(col, s);
+  d_diag.upload(diag, s);
+  d_tile_row.upload(tile_row, s);
+  if (!perm.empty()) d_perm.upload(perm, s);
+  if (!nz_hslot.empty()) d_nz_hslot.upload(nz_hslot, s);
+  JH_HIP(hipStreamSynchronize(s));
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// adjacency in host numbering (0-based), without the diagonal
+// --------------------------------------------------------------------------------------------------------------
+struct Adj {
+  std::vector<int64_t> ptr;
+  std::vector<int32_t> nbr;
+  std::vector<int32_t> sface;  // signed face id: +(f+1) if this cell is N[1,f], -(f+1) otherwise
+};
+
+static Adj build_adjacency(int64_t nc, int64_t nf, const int64_t *N) {
+  Adj A;
+  A.ptr.assign(nc + 1, 0);
+  for (int64_t f = 0; f < nf; ++f) {
+    int64_t l = N[2 * f], r = N[2 * f + 1];
+    if (l < 1 || l > nc || r < 1 || r > nc)
+      JH_THROW("neighborship entry out of range (utils.jl:822: max(N) <= nc)");
+    if (l == r) JH_THROW("face connecting a cell to itself is not supported");
+    A.ptr[l]++;
+    A.ptr[r]++;
+  }
+  for (int64_t c = 0; c < nc; ++c) A.ptr[c + 1] += A.ptr[c];
+  A.nbr.resize(A.ptr[nc]);
+  A.sface.resize(A.ptr[nc]);
+  std::vector<int64_t> cur(A.ptr.begin(), A.ptr.end() - 1);
+  for (int64_t f = 0; f < nf; ++f) {
+    int64_t l = N[2 * f] - 1, r = N[2 * f + 1] - 1;
+    A.nbr[cur[l]] = (int32_t)r;
+    A.sface[cur[l]++] = (int32_t)(f + 1);
+    A.nbr[cur[r]] = (int32_t)l;
+    A.sface[cur[r]++] = -(int32_t)(f + 1);
+  }
+  return A;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// device ordering: compact blocks grown by BFS; blocks in creation order, cells in growth order
+// --------------------------------------------------------------------------------------------------------------
+static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block_rows, std::vector<int32_t> &perm,
+                         std::vector<int32_t> &block_ptr) {
+  // cells >= nc (ghosts of a rank-local subdomain) are never absorbed; they form the last block
+  perm.clear();
+  perm.reserve(nc_all);
+  block_ptr.assign(1, 0);
+  std::vector<int32_t> blk(nc_all, -1);
+  for (int64_t c = nc; c < nc_all; ++c) blk[c] = INT32_MAX;
+  std::vector<int32_t> cand;  // frontier candidates for the next seed (FIFO)
+  size_t cand_head = 0;
+  std::vector<int32_t> q;
+  q.reserve(block_rows);
+  int64_t next_unassigned = 0;
+  int32_t b = 0;
+  while ((int64_t)perm.size() < nc) {
+    int32_t seed = -1;
+    while (cand_head < cand.size()) {
+      int32_t c = cand[cand_head++];
+      if (blk[c] < 0) { seed = c; break; }
+    }
+    if (seed < 0) {
+      while (next_unassigned < nc && blk[next_unassigned] >= 0) ++next_unassigned;
+      seed = (int32_t)next_unassigned;
+    }
+    // grow
+    q.clear();
+    q.push_back(seed);
+    blk[seed] = b;
+    size_t head = 0;
+    while (head < q.size() && (int64_t)q.size() < block_rows) {
+      int32_t c = q[head++];
+      for (int64_t k = A.ptr[c]; k < A.ptr[c + 1] && (int64_t)q.size() < block_rows; ++k) {
+        int32_t o = A.nbr[k];
+        if (blk[o] < 0) { blk[o] = b; q.push_back(o); }
+      }
+    }
+    // unassigned neighbours of the block become seed candidates
+    for (int32_t c : q)
+      for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k)
+        if (blk[A.nbr[k]] < 0) cand.push_back(A.nbr[k]);
+    if (cand_head > (1u << 20) && cand_head * 2 > cand.size()) {  // compact the FIFO
+      cand.erase(cand.begin(), cand.begin() + cand_head);
+      cand_head = 0;
+    }
+    perm.insert(perm.end(), q.begin(), q.end());
+    block_ptr.push_back((int32_t)perm.size());
+    ++b;
+  }
+  // merge small fragments into the preceding block when the result stays within 5/4 of the target
+  std::vector<int32_t> merged(1, 0);
+  int64_t cap = block_rows + block_rows / 4;
+  for (size_t i = 1; i < block_ptr.size(); ++i) {
+    int64_t sz = block_ptr[i] - block_ptr[i - 1];
+    int64_t prev = merged.size() > 1 ? merged.back() - merged[merged.size() - 2] : 0;
+    if (merged.size() > 1 && sz < block_rows / 4 && prev + sz <= cap)
+      merged.back() = block_ptr[i];
+    else
+      merged.push_back(block_ptr[i]);
+  }
+  block_ptr.swap(merged);
+  if (nc_all > nc) {
+    for (int64_t c = nc; c < nc_all; ++c) perm.push_back((int32_t)c);
+    block_ptr.push_back((int32_t)nc_all);
+  }
+}
+
+static void order_by_partition(const Adj &A, int64_t nc, const int64_t *partition, std::vector<int32_t> &perm,
+                               std::vector<int32_t> &block_ptr) {
+  (void)A;
+  int64_t np = 0;
+  for (int64_t c = 0; c < nc; ++c) {
+    if (partition[c] < 1) JH_THROW("partition ids must be >= 1 (par_ilu0.jl:49)");
+    np = std::max(np, partition[c]);
+  }
+  std::vector<int64_t> cnt(np + 1, 0);
+  for (int64_t c = 0; c < nc; ++c) cnt[partition[c]]++;
+  block_ptr.assign(np + 1, 0);
+  for (int64_t b = 0; b < np; ++b) block_ptr[b + 1] = block_ptr[b] + (int32_t)cnt[b + 1];
+  perm.resize(nc);
+  std::vector<int32_t> cur(block_ptr.begin(), block_ptr.end() - 1);
+  for (int64_t c = 0; c < nc; ++c) perm[cur[partition[c] - 1]++] = (int32_t)c;  // findall order inside a part
+}
+
+}  // namespace jh
+
+using namespace jh;
+
+// --------------------------------------------------------------------------------------------------------------
+// jh_tpfa_create
+// --------------------------------------------------------------------------------------------------------------
+extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const int64_t *N, int32_t block_n,
+                                  int32_t reorder, const int64_t *partition, int64_t block_rows, int64_t n_owned,
+                                  jh_tpfa *out) {
+  return guard([&] {
+    if (!ctx || !out) JH_THROW("null argument");
+    if (nc < 1 || nf < 0) JH_THROW("bad sizes");
+    if (block_n < 1 || block_n > 3) JH_THROW("block_n must be 1..3");
+    if (nc > 2000000000LL || 2 * nf + nc > 2000000000LL) JH_THROW("problem too large for 32-bit device indices");
+    JH_HIP(hipSetDevice(ctx->device));
+    auto d = std::make_unique<jh_tpfa_s>();
+    d->ctx = ctx;
+    d->nc = nc;
+    d->nf = nf;
+    d->nhf = 2 * nf;
+    d->N = block_n;
+    d->Nhost.assign(N, N + 2 * nf);
+    Adj A = build_adjacency(nc, nf, N);
+    if (n_owned <= 0 || n_owned > nc) n_owned = nc;
+
+    auto pat = std::make_shared<Pattern>();
+    pat->ctx = ctx;
+    pat->n = nc;
+    pat->bs = block_n;
+    if (partition) {
+      order_by_partition(A, nc, partition, pat->perm, pat->block_ptr);
+    } else if (reorder == JH_REORDER_BLOCKS) {
+      if (block_rows <= 0) block_rows = 4096;
+      order_blocks(A, nc, n_owned, block_rows, pat->perm, pat->block_ptr);
+    } else if (reorder != JH_REORDER_NONE) {
+      JH_THROW("unknown reorder mode");
+    }
+    bool ident = pat->perm.empty();
+    if (!ident)
+      for (int64_t i = n_owned; i < nc; ++i)
+        if (pat->perm[i] < n_owned) JH_THROW("partition must keep the ghost cells (>= n_owned) as the last device rows");
+    if (!ident) {
+      pat->iperm.resize(nc);
+      for (int64_t i = 0; i < nc; ++i) pat->iperm[pat->perm[i]] = (int32_t)i;
+    }
+    // device CSR: row i = host cell perm[i]; columns mapped to device numbering, ascending; diagonal present
+    pat->rowptr.resize(nc + 1);
+    pat->rowptr[0] = 0;
+    for (int64_t i = 0; i < nc; ++i) {
+      int64_t h = ident ? i : pat->perm[i];
+      pat->rowptr[i + 1] = pat->rowptr[i] + (int32_t)(A.ptr[h + 1] - A.ptr[h]) + 1;
+    }
+    pat->nnzb = pat->rowptr[nc];
+    d->nnzb = pat->nnzb;
+    pat->col.resize(pat->nnzb);
+    pat->diag.resize(nc);
+    d->nz_face.resize(pat->nnzb);
+    // host CSR (host numbering) rowptr to compute host slots: row h has deg(h)+1 entries, ascending host cols
+    std::vector<int64_t> hrp(nc + 1, 0);
+    for (int64_t h = 0; h < nc; ++h) hrp[h + 1] = hrp[h] + (A.ptr[h + 1] - A.ptr[h]) + 1;
+    if (!ident) pat->nz_hslot.resize(pat->nnzb);
+    std::vector<std::pair<int32_t, int32_t>> tmp, tmph;
+    for (int64_t i = 0; i < nc; ++i) {
+      int64_t h = ident ? i : pat->perm[i];
+      tmp.clear();
+      tmp.emplace_back((int32_t)i, 0);
+      for (int64_t k = A.ptr[h]; k < A.ptr[h + 1]; ++k)
+        tmp.emplace_back(ident ? A.nbr[k] : pat->iperm[A.nbr[k]], A.sface[k]);
+      std::sort(tmp.begin(), tmp.end());
+      int32_t base = pat->rowptr[i];
+      for (size_t j = 0; j < tmp.size(); ++j) {
+        if (j > 0 && tmp[j].first == tmp[j - 1].first)
+          JH_THROW("two faces connect the same pair of cells: multigraph neighborships are not supported");
+        pat->col[base + j] = tmp[j].first;
+        d->nz_face[base + j] = tmp[j].second;
+        if (tmp[j].first == (int32_t)i) pat->diag[i] = base + (int32_t)j;
+      }
+      if (!ident) {
+        // host slot = position of host column in host row h (ascending host columns incl. diagonal)
+        tmph.clear();
+        for (size_t j = 0; j < tmp.size(); ++j) tmph.emplace_back(pat->perm[tmp[j].first], (int32_t)j);
+        std::sort(tmph.begin(), tmph.end());
+        for (size_t j = 0; j < tmph.size(); ++j) pat->nz_hslot[base + tmph[j].second] = (int32_t)(hrp[h] + j);
+      }
+    }
+    for (int64_t i = 0; i < nc; ++i)
+      if (pat->rowptr[i + 1] - pat->rowptr[i] > TILE_NNZ) JH_THROW("cell with more than 1023 faces is not supported");
+    pat->build_tiles();
+    pat->upload();
+    d->d_nz_face.upload(d->nz_face, ctx->stream);
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+    d->pat = pat;
+    *out = d.release();
+  });
+}
+
+extern "C" int32_t jh_tpfa_destroy(jh_tpfa d) {
+  return guard([&] { delete d; });
+}
+
+extern "C" int32_t jh_tpfa_sizes(jh_tpfa d, int64_t *nc, int64_t *nf, int64_t *nhf, int64_t *nnzb, int32_t *block_n) {
+  return guard([&] {
+    if (!d) JH_THROW("null handle");
+    if (nc) *nc = d->nc;
+    if (nf) *nf = d->nf;
+    if (nhf) *nhf = d->nhf;
+    if (nnzb) *nnzb = d->nnzb;
+    if (block_n) *block_n = d->N;
+  });
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// Reference-exact host tables (1-based), built on demand for the getters / the Julia glue.
+//   get_facepos (utils.jl:813-874), get_connection (flux.jl:128-142), pattern (conservation.jl:486-505 +
+//   StaticCSR/mat.jl:73-76), positions (conservation.jl:143-216, equations.jl:95-113,163-174).
+// --------------------------------------------------------------------------------------------------------------
+void jh_tpfa_s::build_tables() {
+  if (tables_built) return;
+  const int64_t *Nn = Nhost.data();
+  face_pos.assign(nc + 1, 0);
+  for (int i = 0; i < 2; ++i)
+    for (int64_t j = 0; j < nf; ++j) face_pos[Nn[2 * j + i]]++;
+  face_pos[0] = 1;
+  for (int64_t c = 0; c < nc; ++c) face_pos[c + 1] += face_pos[c];
+  hf_face.resize(nhf);
+  {
+    std::vector<int64_t> cur(nc);
+    for (int64_t c = 0; c < nc; ++c) cur[c] = face_pos[c] - 1;
+    for (int i = 0; i < 2; ++i)
+      for (int64_t j = 0; j < nf; ++j) hf_face[cur[Nn[2 * j + i] - 1]++] = j + 1;
+    for (int64_t c = 0; c < nc; ++c) std::sort(hf_face.begin() + (face_pos[c] - 1), hf_face.begin() + (face_pos[c + 1] - 1));
+  }
+  hf_self.resize(nhf);
+  hf_other.resize(nhf);
+  hf_sign.resize(nhf);
+  for (int64_t c = 1; c <= nc; ++c)
+    for (int64_t k = face_pos[c - 1]; k <= face_pos[c] - 1; ++k) {
+      int64_t f = hf_face[k - 1];
+      int64_t l = Nn[2 * (f - 1)], r = Nn[2 * (f - 1) + 1];
+      hf_self[k - 1] = c;
+      if (l == c) { hf_sign[k - 1] = 1; hf_other[k - 1] = r; }
+      else { hf_sign[k - 1] = -1; hf_other[k - 1] = l; }
+    }
+  // pattern: per row sorted unique {others} U {row}
+  h_rowptr.assign(nc + 1, 1);
+  h_colidx.clear();
+  h_colidx.reserve(nnzb);
+  std::vector<int64_t> tmp;
+  for (int64_t c = 1; c <= nc; ++c) {
+    tmp.clear();
+    for (int64_t k = face_pos[c - 1]; k <= face_pos[c] - 1; ++k) tmp.push_back(hf_other[k - 1]);
+    tmp.push_back(c);
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+    h_colidx.insert(h_colidx.end(), tmp.begin(), tmp.end());
+    h_rowptr[c] = h_rowptr[c - 1] + (int64_t)tmp.size();
+  }
+  // positions, BlockMajorLayout flat index: (pos-1)*N^2 + N*(d-1) + e
+  auto find_pos = [&](int64_t row, int64_t colv) -> int64_t {
+    for (int64_t p = h_rowptr[row - 1]; p <= h_rowptr[row] - 1; ++p)
+      if (h_colidx[p - 1] == colv) return p;
+    return 0;
+  };
+  int64_t NN = (int64_t)N * N;
+  pos_acc.resize(NN * nc);
+  pos_flux.resize(NN * nhf);
+  for (int64_t c = 1; c <= nc; ++c) {
+    int64_t pos = find_pos(c, c);
+    for (int e = 1; e <= N; ++e)
+      for (int dd = 1; dd <= N; ++dd) pos_acc[NN * (c - 1) + (e - 1) * N + (dd - 1)] = (pos - 1) * NN + N * (dd - 1) + e;
+  }
+  for (int64_t k = 1; k <= nhf; ++k) {
+    int64_t pos = find_pos(hf_other[k - 1], hf_self[k - 1]);
+    for (int e = 1; e <= N; ++e)
+      for (int dd = 1; dd <= N; ++dd) pos_flux[NN * (k - 1) + (e - 1) * N + (dd - 1)] = (pos - 1) * NN + N * (dd - 1) + e;
+  }
+  tables_built = true;
+}
+
+extern "C" int32_t jh_tpfa_get_conn(jh_tpfa d, int64_t *face_pos, int64_t *self, int64_t *other, int64_t *face,
+                                    int64_t *face_sign) {
+  return guard([&] {
+    if (!d) JH_THROW("null handle");
+    d->build_tables();
+    if (face_pos) std::memcpy(face_pos, d->face_pos.data(), sizeof(int64_t) * (d->nc + 1));
+    if (self) std::memcpy(self, d->hf_self.data(), sizeof(int64_t) * d->nhf);
+    if (other) std::memcpy(other, d->hf_other.data(), sizeof(int64_t) * d->nhf);
+    if (face) std::memcpy(face, d->hf_face.data(), sizeof(int64_t) * d->nhf);
+    if (face_sign) std::memcpy(face_sign, d->hf_sign.data(), sizeof(int64_t) * d->nhf);
+  });
+}
+
+extern "C" int32_t jh_tpfa_get_pattern(jh_tpfa d, int64_t *rowptr, int64_t *colidx) {
+  return guard([&] {
+    if (!d) JH_THROW("null handle");
+    d->build_tables();
+    if (rowptr) std::memcpy(rowptr, d->h_rowptr.data(), sizeof(int64_t) * (d->nc + 1));
+    if (colidx) std::memcpy(colidx, d->h_colidx.data(), sizeof(int64_t) * d->h_colidx.size());
+  });
+}
+
+extern "C" int32_t jh_tpfa_get_positions(jh_tpfa d, int64_t *pos_acc, int64_t *pos_flux) {
+  return guard([&] {
+    if (!d) JH_THROW("null handle");
+    d->build_tables();
+    if (pos_acc) std::memcpy(pos_acc, d->pos_acc.data(), sizeof(int64_t) * d->pos_acc.size());
+    if (pos_flux) std::memcpy(pos_flux, d->pos_flux.data(), sizeof(int64_t) * d->pos_flux.size());
+  });
+}
+
+extern "C" int32_t jh_tpfa_get_ordering(jh_tpfa d, int64_t *perm, int64_t *nblocks, int64_t *block_ptr,
+                                        int64_t block_ptr_cap) {
+  return guard([&] {
+    if (!d) JH_THROW("null handle");
+    const Pattern &P = *d->pat;
+    if (perm)
+      for (int64_t i = 0; i < d->nc; ++i) perm[i] = (P.perm.empty() ? i : P.perm[i]) + 1;
+    int64_t nb = P.block_ptr.empty() ? 0 : (int64_t)P.block_ptr.size() - 1;
+    if (nblocks) *nblocks = nb;
+    if (block_ptr) {
+      if (block_ptr_cap < nb + 1) JH_THROW("block_ptr buffer too small");
+      for (int64_t i = 0; i <= nb; ++i) block_ptr[i] = P.block_ptr[i];
+    }
+  });
+}
+
+extern "C" int32_t jh_last_error(char *buf, int64_t cap) {
+  const std::string &e = jh::last_error();
+  if (buf && cap > 0) {
+    int64_t n = std::min<int64_t>(cap - 1, (int64_t)e.size());
+    std::memcpy(buf, e.data(), n);
+    buf[n] = 0;
+  }
+  return (int32_t)e.size();
+}
+
+extern "C" int32_t jh_version(void) { return 100; }
