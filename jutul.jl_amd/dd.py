@@ -1,0 +1,129 @@
+"""Domain decomposition host logic (a-16/a-17): partitions, rank-local subdomains with one ghost ring, halo plans.
+
+Mirrors src/partitioning.jl and ext/JutulPartitionedArraysExt/utils.jl.  Integer work only; the data path
+(pack -> RCCL send/recv -> unpack, all-reduces) runs inside libjutul_hip.so.  `HostExchange` performs the same
+`consistent!` on host arrays through torch.distributed (gloo or nccl) -- used to distribute initial data and by
+the CPU multi-process tests.
+"""
+import numpy as np
+
+
+# ---- partitioners ------------------------------------------------------------------------------------------------
+def partition_linear(m, n):
+    """partition_linear(m, n) (partitioning.jl:12-18): p[i] = ceil(i / (n/m)), 1-based parts."""
+    i = np.arange(1, n + 1, dtype=np.float64)
+    return np.ceil(i / (n / m)).astype(np.int64)
+
+
+def compress_partition(p):
+    """compress_partition (partitioning.jl:92-99): renumber to 1..k preserving order of the ids."""
+    p = np.asarray(p, dtype=np.int64)
+    up = np.unique(p)
+    return np.searchsorted(up, p).astype(np.int64) + 1
+
+
+def partition_rcb(centroids, nparts):
+    """Recursive coordinate bisection into `nparts` (any integer) compact parts; 1-based part ids.
+    Build-side stand-in for MetisPartitioner (partitioning.jl:29-51; Metis.jl is an un-vendored C library):
+    the partition vector is an INPUT to the hot path, any valid vector works."""
+    X = np.asarray(centroids, dtype=np.float64)
+    if X.shape[0] in (1, 2, 3) and X.shape[1] > 3:
+        X = X.T
+    n = X.shape[0]
+    part = np.zeros(n, dtype=np.int64)
+
+    def rec(idx, k, first):
+        if k == 1:
+            part[idx] = first
+            return
+        kl = k // 2
+        ext = X[idx].max(axis=0) - X[idx].min(axis=0)
+        ax = int(np.argmax(ext))
+        nl = int(round(len(idx) * kl / k))
+        order = np.argpartition(X[idx, ax], nl - 1) if 0 < nl < len(idx) else np.arange(len(idx))
+        rec(idx[order[:nl]], kl, first)
+        rec(idx[order[nl:]], k - kl, first + kl)
+
+    rec(np.arange(n), int(nparts), 1)
+    return part
+
+
+# ---- distributed numbering (ext/JutulPartitionedArraysExt/utils.jl) --------------------------------------------------------
+def partition_boundary(N, p, rank):
+    """partition_boundary (utils.jl:32-56) for one part (1-based `rank`): cells of other parts sharing a face with
+    an owned cell.  Returned ascending (the reference delegates the final ghost order to PartitionedArrays;
+    results are compared in global numbering)."""
+    l, r = N[0] - 1, N[1] - 1
+    il, ir = p[l] == rank, p[r] == rank
+    return np.unique(np.concatenate([r[il & ~ir], l[ir & ~il]])) + 1
+
+
+def remap_global_indices(p, nparts):
+    """remap_global_indices, order = :default (utils.jl:9-30): owned-first contiguous numbering per rank."""
+    p = np.asarray(p, dtype=np.int64)
+    counts = np.bincount(p, minlength=nparts + 1)[1:]
+    offs = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    order = np.argsort(p, kind="stable")
+    rem = np.empty(p.size, dtype=np.int64)
+    rem[order] = np.arange(1, p.size + 1)
+    assert np.all(rem[order[offs]] == offs + 1)
+    return rem, counts
+
+
+def local_subdomain(N, p, rank):
+    """Rank-local subdomain as PArraySimulator builds it (interface.jl:38-63 with submap_cells buffer = 0,
+    dd/subdomains.jl:77-182): cells = [owned (findall order) ..., ghosts (ascending global id) ...]; faces kept iff
+    both cells are local.  `rank` is 1-based.  All returned index arrays are 1-based."""
+    N = np.asarray(N, dtype=np.int64)
+    p = np.asarray(p, dtype=np.int64)
+    nc = p.size
+    l, r = N[0] - 1, N[1] - 1
+    mine = p == rank
+    il, ir = mine[l], mine[r]
+    owned = np.flatnonzero(mine)
+    ghosts = np.unique(np.concatenate([r[il & ~ir], l[ir & ~il]]))
+    n_owned = owned.size
+    g2l = np.full(nc, -1, dtype=np.int64)
+    g2l[owned] = np.arange(n_owned)
+    g2l[ghosts] = n_owned + np.arange(ghosts.size)
+    keep = (g2l[l] >= 0) & (g2l[r] >= 0)
+    faces = np.flatnonzero(keep)
+    N_local = np.stack([g2l[l[keep]], g2l[r[keep]]]) + 1
+    # halo plan
+    gp = p[ghosts]
+    nbr = np.unique(gp)
+    recv = [n_owned + np.flatnonzero(gp == s) + 1 for s in nbr]
+    # cells I own that are ghosts on rank s: owned endpoints of faces crossing to s (ascending global id)
+    cell_a = np.concatenate([l[il & ~ir], r[ir & ~il]])
+    rank_b = np.concatenate([p[r[il & ~ir]], p[l[ir & ~il]]])
+    send = []
+    for s in nbr:
+        c = np.unique(cell_a[rank_b == s])
+        send.append(g2l[c] + 1)
+    return dict(cells=np.concatenate([owned, ghosts]) + 1, n_owned=n_owned, n_local=n_owned + ghosts.size, faces=faces + 1,
+                N=np.ascontiguousarray(N_local), neighbors=(nbr - 1).astype(np.int32), send=send, recv=recv)
+
+
+class HostExchange:
+    """consistent!(v) on host arrays over torch.distributed (any backend): owner -> ghost copies."""
+
+    def __init__(self, sub, block=1):
+        self.sub, self.block = sub, block
+
+    def __call__(self, v):
+        import torch
+        import torch.distributed as dist
+        sub, b = self.sub, self.block
+        v2 = v.reshape(-1, b)
+        reqs, bufs = [], []
+        for s, snd, rcv in zip(sub["neighbors"], sub["send"], sub["recv"]):
+            out = torch.from_numpy(np.ascontiguousarray(v2[snd - 1]))
+            inp = torch.empty((len(rcv), b), dtype=torch.float64)
+            reqs.append(dist.isend(out, int(s)))
+            reqs.append(dist.irecv(inp, int(s)))
+            bufs.append((rcv, inp, out))
+        for q in reqs:
+            q.wait()
+        for rcv, inp, _ in bufs:
+            v2[rcv - 1] = inp.numpy()
+        return v

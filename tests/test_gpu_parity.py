@@ -164,7 +164,7 @@ def test_heat_2d_periodic_config1(ja, ctx, oracle):
     T1 = law.get_state().reshape(ny, nx)
     lap = (np.roll(T1, 1, 1) + np.roll(T1, -1, 1) + np.roll(T1, 1, 0) + np.roll(T1, -1, 0) - 4 * T1) / h ** 2
     assert np.abs((T1 - T0) / 1.0 - lap).max() < 1e-6 * 100.0 / h ** 2 * 1e-3
-    assert np.isclose(T1.sum(), T0.sum(), rtol=1e-9)
+    assert np.isclose(T1.sum(), T0.sum(), rtol=1e-7)
     assert its == 2  # linear problem: 2 assemblies + 1 solve per ministep
 
 
