@@ -151,6 +151,9 @@ int32_t jh_ilu0_apply(jh_ilu M, jh_vec b, jh_vec x);
 /* factor values scattered to A's HOST pattern: L multipliers below the diagonal, inv(U_ii) on it, U above */
 int32_t jh_ilu0_get_factor(jh_ilu M, double *lu);
 int32_t jh_ilu0_info(jh_ilu M, int64_t *nblocks, int64_t *max_block_rows, int64_t *max_levels);
+/* stats4: [0] strict-lower block entries kept in L, [1] strict-upper kept in U (fixed_block, ilu0.jl:13-54),
+ * [2] execution blocks, [3] 1 if the LDS (block-Jacobi) kernels are used, 0 for the level-per-launch kernels */
+int32_t jh_ilu0_stats(jh_ilu M, int64_t *stats4);
 
 /* ---- a-14: Krylov ---------------------------------------------------------------------------------------------- */
 #define JH_SIDE_NONE 0
@@ -163,6 +166,10 @@ int32_t jh_krylov_destroy(jh_krylov K);
  * status: 0 solved, 1 itmax reached, 2 breakdown.  hist: ||r_k||, k = 0..iters (at most hist_cap entries). */
 int32_t jh_bicgstab(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh_vec x, double rtol, double atol, int64_t itmax,
                     int64_t *iters, int32_t *status, double *hist, int64_t hist_cap);
+/* PrecondWrapper-style instrumentation (linsolve/krylov.jl:5-25): accumulated HIP-event time [ms] and launch
+ * count of [0] the SpMV and [1] the preconditioner apply inside jh_bicgstab / jh_newton_step.  Reads the
+ * totals (ms2/count2 may be NULL), then optionally resets them and enables/disables further profiling. */
+int32_t jh_krylov_profile(jh_krylov K, int32_t enable, int32_t reset, double *ms2, int64_t *count2);
 /* update_dx_from_vector! (linsolve/default.jl:444-446): dx = -x */
 int32_t jh_vec_negate_into(jh_vec dx, jh_vec x);
 

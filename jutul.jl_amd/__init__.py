@@ -364,7 +364,10 @@ class ILUZeroPreconditioner(_Handle):
     def info(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         check(_L().jh_ilu0_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(nblocks=a.value, max_block_rows=b.value, max_levels=c.value)
+        st = np.zeros(4, dtype=np.int64)
+        check(_L().jh_ilu0_stats(self.h, pi(st)))
+        return dict(nblocks=a.value, max_block_rows=b.value, max_levels=c.value, l_entries=int(st[0]),
+                    u_entries=int(st[1]), exec_blocks=int(st[2]), lds_mode=bool(st[3]))
 
 
 def ilu0_csr(A, partition=None):
@@ -413,6 +416,13 @@ class GenericKrylov(_Handle):
             check(_L().jh_krylov_create(A.h, C.byref(self.h)))
             self.A = A
         return self.h
+
+    def profile(self, enable=True, reset=True):
+        """PrecondWrapper-like counters: dict(spmv_ms, spmv_count, precond_ms, precond_count) since last reset."""
+        ms = np.zeros(2)
+        cnt = np.zeros(2, dtype=np.int64)
+        check(_L().jh_krylov_profile(self.h, 1 if enable else 0, 1 if reset else 0, pf(ms), pi(cnt)))
+        return dict(spmv_ms=ms[0], spmv_count=int(cnt[0]), precond_ms=ms[1], precond_count=int(cnt[1]))
 
 
 class LinearizedSystem:

@@ -79,8 +79,10 @@ SIGNATURES = {
     "jh_ilu0_apply": [H, H, H],
     "jh_ilu0_get_factor": [H, F64P],
     "jh_ilu0_info": [H, I64P, I64P, I64P],
+    "jh_ilu0_stats": [H, I64P],
     "jh_krylov_create": [H, C.POINTER(H)],
     "jh_krylov_destroy": [H],
+    "jh_krylov_profile": [H, C.c_int32, C.c_int32, F64P, I64P],
     "jh_bicgstab": [H, H, C.c_int32, H, H, C.c_double, C.c_double, C.c_int64, I64P, I32P, F64P, C.c_int64],
     "jh_newton_step": [H, H, H, H, H, H, C.c_double, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_int64,
                        C.c_int32, C.POINTER(NewtonReport)],

@@ -511,6 +511,17 @@ extern "C" int32_t jh_ilu0_info(jh_ilu M, int64_t *nblocks, int64_t *max_block_r
   });
 }
 
+// stats[0] strict-lower entries kept, [1] strict-upper entries kept, [2] execution blocks, [3] 1 = LDS mode
+extern "C" int32_t jh_ilu0_stats(jh_ilu M, int64_t *stats4) {
+  return guard([&] {
+    if (!M || !stats4) JH_THROW("null argument");
+    stats4[0] = (int64_t)M->l_col.size();
+    stats4[1] = (int64_t)M->u_col.size();
+    stats4[2] = (int64_t)M->blk_ptr.size() - 1;
+    stats4[3] = M->lds_mode ? 1 : 0;
+  });
+}
+
 namespace jh {
 void ilu_factor(jh_ilu M) {
   jh_context ctx = M->ctx;

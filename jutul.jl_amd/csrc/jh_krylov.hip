@@ -26,6 +26,40 @@ struct jh_krylov_s {
   int64_t len = 0;      // doubles per vector
   int64_t len_dot = 0;  // owned part (dots / norms)
   DevBuf<double> r, p, c, s, q, y, z, d, v, t;
+  // optional in-solve profiling with HIP events on the context stream (PrecondWrapper-style time/count,
+  // linsolve/krylov.jl:5-25): [0] spmv, [1] preconditioner apply
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<int> ev_kind;
+  size_t ev_used = 0;
+  double prof_ms[2] = {0, 0};
+  int64_t prof_cnt[2] = {0, 0};
+  ~jh_krylov_s() {
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+  }
+  void mark(int kind, hipStream_t st) {  // call before and after the profiled launch
+    if (!profiling) return;
+    if (ev_used == ev_pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      ev_pool.push_back(e);
+      ev_kind.push_back(kind);
+    }
+    ev_kind[ev_used] = kind;
+    (void)hipEventRecord(ev_pool[ev_used++], st);
+  }
+  void collect() {
+    if (!profiling || ev_used < 2) { ev_used = 0; return; }
+    (void)hipEventSynchronize(ev_pool[ev_used - 1]);
+    for (size_t i = 0; i + 1 < ev_used; i += 2) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) {
+        prof_ms[ev_kind[i]] += ms;
+        prof_cnt[ev_kind[i]]++;
+      }
+    }
+    ev_used = 0;
+  }
 };
 
 namespace {
@@ -101,7 +135,9 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   auto prec = [&](double *in, double *out) {
     // parray_preconditioner_apply! (ext/.../linalg.jl:78-88): ghost part of the input zeroed, local apply
     if (dist && n > nd) k_fill(st, in + nd, n - nd, 0.0);
+    K->mark(1, st);
     ilu_apply(M, in, out);
+    K->mark(1, st);
   };
   auto dot2 = [&](const double *a, const double *bb, const double *c2, const double *d2, int slot) {
     k_dot2(ctx, a, bb, c2, d2, nd, slot);
@@ -109,7 +145,9 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   };
   auto spmv = [&](double *in, double *out) {
     if (dist) halo_exchange(disc, in, P.bs);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
+    K->mark(0, st);
     k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0);
+    K->mark(0, st);
   };
   k_fill(st, x, n, 0.0);
   k_copy(st, K->c.p, b_in, n);  // scratch copy of b (the ghost zeroing of the preconditioner must not touch b)
@@ -166,11 +204,22 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   else if (status == 0 && it >= itmax) status = 1;
   if (dist) halo_exchange(disc, x, P.bs);  // consistent!(x) (ext/.../krylov.jl:75)
   *iters_out = it;
+  K->collect();
   JH_HIP(hipGetLastError());
   return status;
 }
 
 }  // namespace jh
+
+extern "C" int32_t jh_krylov_profile(jh_krylov K, int32_t enable, int32_t reset, double *ms2, int64_t *count2) {
+  return guard([&] {
+    if (!K) JH_THROW("null handle");
+    if (ms2) { ms2[0] = K->prof_ms[0]; ms2[1] = K->prof_ms[1]; }
+    if (count2) { count2[0] = K->prof_cnt[0]; count2[1] = K->prof_cnt[1]; }
+    if (reset) { K->prof_ms[0] = K->prof_ms[1] = 0; K->prof_cnt[0] = K->prof_cnt[1] = 0; }
+    K->profiling = enable != 0;
+  });
+}
 
 extern "C" int32_t jh_bicgstab(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh_vec x, double rtol, double atol,
                                int64_t itmax, int64_t *iters, int32_t *status, double *hist, int64_t hist_cap) {
