@@ -18,6 +18,7 @@
 // In both modes each row performs the reference's IKJ update sequence (ascending k, `L_ik = A_ik*inv(D_k)`,
 // inverted pivots stored at the end), so factors agree with the oracle to rounding.
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 #include "jh_internal.hpp"
@@ -33,6 +34,7 @@ struct jh_ilu_s {
   bool lds_mode = false;
   int64_t nparts = 1, max_block_rows = 0, max_levels = 0;
   int threads = 256;
+  int lanes_per_block = 64;  // < 64: several blocks share one wavefront (grouped apply kernel)
   size_t lds_bytes = 0;
   // symbolic data (host)
   std::vector<int32_t> rowmap;            // ilu row -> device row of A
@@ -40,6 +42,8 @@ struct jh_ilu_s {
   std::vector<int32_t> flev_off, flev_ptr; // per block: offsets into flev_ptr; flev_ptr: ilu row starts
   std::vector<int32_t> blev_off, blev_ptr; // backward levels over U-order positions
   std::vector<int32_t> l_ptr, l_col, l_map, u_ptr, u_col, u_map, d_map, u_row, upos_of;
+  std::vector<int32_t> l_lev, u_lev;  // in-block level of every ilu row (fwd order) / U-order position (bwd order)
+  DevBuf<int32_t> d_l_lev, d_u_lev;
   DevBuf<int32_t> d_rowmap, d_blk_ptr, d_flev_off, d_flev_ptr, d_blev_off, d_blev_ptr, d_l_ptr, d_l_col, d_l_map, d_u_ptr,
       d_u_col, d_u_map, d_d_map, d_u_row, d_upos_of;
   DevBuf<double> l_val, u_val, dinv, xg;
@@ -116,7 +120,7 @@ template <> __device__ __forceinline__ Blk<3> blk_inv<3>(const Blk<3> &A) {
 
 struct IluDev {
   const int32_t *rowmap, *blk_ptr, *flev_off, *flev_ptr, *blev_off, *blev_ptr;
-  const int32_t *l_ptr, *l_col, *l_map, *u_ptr, *u_col, *u_map, *d_map, *u_row, *upos_of;
+  const int32_t *l_ptr, *l_col, *l_map, *u_ptr, *u_col, *u_map, *d_map, *u_row, *upos_of, *l_lev, *u_lev;
   double *l_val, *u_val, *dinv;
 };
 
@@ -295,6 +299,294 @@ __global__ void ilu_apply_blocks_kernel(IluDev F, const double *__restrict__ bve
   }
 }
 
+// ---- software-pipelined LDS apply -------------------------------------------------------------------------------
+// The level loop above is latency-bound: every level issues two dependent global loads (row pointers, then
+// entries) before it can touch LDS.  Nothing but the LDS vector depends on earlier levels, so the factor data of
+// level l+1 (entries) and l+2 (row pointers) is fetched into registers while level l computes: the per-level
+// critical path shrinks to LDS latency + one barrier.  Rows longer than PFW entries take a slow tail loop.
+constexpr int PFW = 4;
+
+template <int BS>
+struct RowPF {
+  int lt;   // local row id (index into xs), -1 = lane idle
+  int s, e; // entry range
+  int col[PFW];
+  double val[PFW * BS * BS];
+  double dinv[BS * BS];
+};
+
+template <int BS, bool BWD>
+__device__ __forceinline__ void pf_ptrs(const IluDev &F, RowPF<BS> &R, int idx, int end, int b0) {
+  // idx: ilu row (fwd) or U-order position (bwd)
+  if (idx < end) {
+    if (BWD) {
+      R.lt = F.u_row[idx];
+      R.s = F.u_ptr[idx];
+      R.e = F.u_ptr[idx + 1];
+#pragma unroll
+      for (int i = 0; i < BS * BS; ++i) R.dinv[i] = F.dinv[(size_t)idx * BS * BS + i];
+    } else {
+      R.lt = idx - b0;
+      R.s = F.l_ptr[idx];
+      R.e = F.l_ptr[idx + 1];
+    }
+  } else {
+    R.lt = -1;
+    R.s = R.e = 0;
+  }
+}
+template <int BS, bool BWD>
+__device__ __forceinline__ void pf_entries(const IluDev &F, RowPF<BS> &R) {
+  const int32_t *cols = BWD ? F.u_col : F.l_col;
+  const double *vals = BWD ? F.u_val : F.l_val;
+#pragma unroll
+  for (int j = 0; j < PFW; ++j) {
+    if (R.s + j < R.e) {
+      R.col[j] = cols[R.s + j];
+#pragma unroll
+      for (int i = 0; i < BS * BS; ++i) R.val[j * BS * BS + i] = vals[(size_t)(R.s + j) * BS * BS + i];
+    }
+  }
+}
+template <int BS, bool BWD>
+__device__ __forceinline__ void pf_compute(const IluDev &F, const RowPF<BS> &R, double *xs) {
+  if (R.lt < 0) return;
+  const int32_t *cols = BWD ? F.u_col : F.l_col;
+  const double *vals = BWD ? F.u_val : F.l_val;
+  double v[BS];
+#pragma unroll
+  for (int e = 0; e < BS; ++e) v[e] = xs[R.lt * BS + e];
+#pragma unroll
+  for (int j = 0; j < PFW; ++j) {
+    if (R.s + j < R.e) {
+      const int k = R.col[j];
+      if (BS == 1) {
+        v[0] -= R.val[j] * xs[k];
+      } else {
+#pragma unroll
+        for (int e = 0; e < BS; ++e) {
+          double sum = 0.0;
+#pragma unroll
+          for (int d = 0; d < BS; ++d) sum += R.val[j * BS * BS + d * BS + e] * xs[k * BS + d];
+          v[e] -= sum;
+        }
+      }
+    }
+  }
+  for (int j = R.s + PFW; j < R.e; ++j) {  // slow tail for long rows
+    const int k = cols[j];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) {
+      double sum = 0.0;
+#pragma unroll
+      for (int d = 0; d < BS; ++d) sum += vals[(size_t)j * BS * BS + d * BS + e] * xs[k * BS + d];
+      v[e] -= sum;
+    }
+  }
+  if (BWD) {
+    if (BS == 1) {
+      xs[R.lt] = R.dinv[0] * v[0];
+    } else {
+      double o[BS];
+#pragma unroll
+      for (int e = 0; e < BS; ++e) {
+        double sum = 0.0;
+#pragma unroll
+        for (int d = 0; d < BS; ++d) sum += R.dinv[d * BS + e] * v[d];
+        o[e] = sum;
+      }
+#pragma unroll
+      for (int e = 0; e < BS; ++e) xs[R.lt * BS + e] = o[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < BS; ++e) xs[R.lt * BS + e] = v[e];
+  }
+}
+
+template <int BS, bool BWD>
+__device__ __forceinline__ void pf_sweep(const IluDev &F, double *xs, int b0, int lev_begin, int lev_end) {
+  const int32_t *lptr = BWD ? F.blev_ptr : F.flev_ptr;
+  const int T = blockDim.x, tid = threadIdx.x;
+  if (lev_begin >= lev_end) return;
+  RowPF<BS> cur, nxt;
+  // prologue: pointers+entries of the first level, pointers of the second
+  int s0 = lptr[lev_begin], e0 = lptr[lev_begin + 1];
+  pf_ptrs<BS, BWD>(F, cur, s0 + tid, e0, b0);
+  pf_entries<BS, BWD>(F, cur);
+  int s1 = e0, e1 = e0;
+  if (lev_begin + 1 < lev_end) { e1 = lptr[lev_begin + 2]; }
+  pf_ptrs<BS, BWD>(F, nxt, s1 + tid, e1, b0);
+  for (int lev = lev_begin; lev < lev_end; ++lev) {
+    // issue the loads of the next level's entries and the level-after-next's pointers before computing
+    RowPF<BS> nn;
+    pf_entries<BS, BWD>(F, nxt);
+    int s2 = e1, e2 = e1;
+    if (lev + 2 < lev_end) e2 = lptr[lev + 3];
+    pf_ptrs<BS, BWD>(F, nn, s2 + tid, e2, b0);
+    pf_compute<BS, BWD>(F, cur, xs);
+    for (int idx = s0 + tid + T; idx < e0; idx += T) {  // levels wider than the workgroup: not prefetched
+      RowPF<BS> r;
+      pf_ptrs<BS, BWD>(F, r, idx, e0, b0);
+      pf_entries<BS, BWD>(F, r);
+      pf_compute<BS, BWD>(F, r, xs);
+    }
+    __syncthreads();
+    cur = nxt;
+    nxt = nn;
+    s0 = s1; e0 = e1;
+    s1 = s2; e1 = e2;
+  }
+}
+
+template <int BS>
+__global__ void ilu_apply_blocks_pf_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];
+  const int b = blockIdx.x;
+  const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
+  const int nr = b1 - b0;
+  for (int t = threadIdx.x; t < nr; t += blockDim.x) {
+    const int dev = F.rowmap[b0 + t];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) xs[t * BS + e] = bvec[(size_t)dev * BS + e];
+  }
+  __syncthreads();
+  pf_sweep<BS, false>(F, xs, b0, F.flev_off[b] + 1, F.flev_off[b + 1] - 1);  // level 0 rows have no L entries
+  pf_sweep<BS, true>(F, xs, b0, F.blev_off[b], F.blev_off[b + 1] - 1);
+  for (int t = threadIdx.x; t < nr; t += blockDim.x) {
+    const int dev = F.rowmap[b0 + t];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[t * BS + e];
+  }
+}
+
+// ---- grouped variant: several blocks per wavefront ----------------------------------------------------------------
+// In-block levels of a ~512-row block hold only ~8 rows, so a wavefront that owns ONE block issues every
+// instruction for ~8 useful lanes and the kernel becomes instruction-issue bound (measured: 44M VALU wave-
+// instructions per apply vs 17M for the SpMV).  Here a 64-lane workgroup owns 64/LPG blocks: lane group g runs the
+// level loop of block blockIdx.x*(64/LPG)+g in lockstep with the other groups (trip count = longest level chain
+// among them), each with its own LDS slice.  Same data layout and arithmetic as above.
+template <int BS, bool BWD>
+__device__ __forceinline__ void pfg_sweep(const IluDev &F, double *xs, int b0, int lev_begin, int lev_end, int tid, int T) {
+  const int32_t *lptr = BWD ? F.blev_ptr : F.flev_ptr;
+  int nlev = lev_end > lev_begin ? lev_end - lev_begin : 0;
+  int nmax = nlev;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+  if (nmax == 0) return;
+  RowPF<BS> cur, nxt;
+  int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
+  if (nlev > 0) { s0 = lptr[lev_begin]; e0 = lptr[lev_begin + 1]; }
+  pf_ptrs<BS, BWD>(F, cur, s0 + tid, e0, b0);
+  pf_entries<BS, BWD>(F, cur);
+  s1 = e0; e1 = e0;
+  if (nlev > 1) e1 = lptr[lev_begin + 2];
+  pf_ptrs<BS, BWD>(F, nxt, s1 + tid, e1, b0);
+  for (int i = 0; i < nmax; ++i) {
+    RowPF<BS> nn;
+    pf_entries<BS, BWD>(F, nxt);
+    int s2 = e1, e2 = e1;
+    if (i + 2 < nlev) e2 = lptr[lev_begin + i + 3];
+    pf_ptrs<BS, BWD>(F, nn, s2 + tid, e2, b0);
+    pf_compute<BS, BWD>(F, cur, xs);
+    for (int idx = s0 + tid + T; idx < e0; idx += T) {
+      RowPF<BS> r;
+      pf_ptrs<BS, BWD>(F, r, idx, e0, b0);
+      pf_entries<BS, BWD>(F, r);
+      pf_compute<BS, BWD>(F, r, xs);
+    }
+    __syncthreads();
+    cur = nxt;
+    nxt = nn;
+    s0 = s1; e0 = e1;
+    s1 = s2; e1 = e2;
+  }
+}
+
+template <int BS, int LPG>
+__global__ __launch_bounds__(64) void ilu_apply_grouped_kernel(IluDev F, int nblocks, int maxrows, const double *__restrict__ bvec,
+                                                               double *__restrict__ xvec) {
+  extern __shared__ __attribute__((aligned(16))) double xs_all[];
+  constexpr int G = 64 / LPG;
+  const int grp = threadIdx.x / LPG, tid = threadIdx.x % LPG;
+  const int b = blockIdx.x * G + grp;
+  const bool live = b < nblocks;
+  double *xs = xs_all + (size_t)grp * maxrows * BS;
+  int b0 = 0, nr = 0;
+  if (live) { b0 = F.blk_ptr[b]; nr = F.blk_ptr[b + 1] - b0; }
+  for (int t = tid; t < nr; t += LPG) {
+    const int dev = F.rowmap[b0 + t];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) xs[t * BS + e] = bvec[(size_t)dev * BS + e];
+  }
+  __syncthreads();
+  int fb = 0, fe = 0, bb = 0, be = 0;
+  if (live) { fb = F.flev_off[b] + 1; fe = F.flev_off[b + 1] - 1; bb = F.blev_off[b]; be = F.blev_off[b + 1] - 1; }
+  pfg_sweep<BS, false>(F, xs, b0, fb, fe, tid, LPG);
+  pfg_sweep<BS, true>(F, xs, b0, bb, be, tid, LPG);
+  for (int t = tid; t < nr; t += LPG) {
+    const int dev = F.rowmap[b0 + t];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[t * BS + e];
+  }
+}
+
+// ---- chunked variant: one wavefront per block, 64 rows in flight regardless of level width --------------------------
+// The tail of a block's level structure is narrow (a few rows per level), so prefetching "the next level" keeps
+// only a few rows in flight and every level pays a full memory latency.  Here the wavefront walks the block's rows
+// (already sorted by level) in chunks of 64: each lane owns one row of the chunk, the factor data of chunk c+1 and
+// the row pointers of chunk c+2 are in flight while chunk c is processed level by level out of registers and LDS.
+template <int BS, bool BWD>
+__device__ __forceinline__ void chunk_sweep(const IluDev &F, double *xs, int b0, int b1, int skip_level0) {
+  const int lane = threadIdx.x;
+  const int32_t *levs = BWD ? F.u_lev : F.l_lev;
+  RowPF<BS> cur, nxt, nn;
+  int lv_cur = -1, lv_nxt = -1, lv_nn = -1;
+  int base = b0;
+  // prologue
+  pf_ptrs<BS, BWD>(F, cur, base + lane, b1, b0);
+  if (base + lane < b1) lv_cur = levs[base + lane];
+  pf_entries<BS, BWD>(F, cur);
+  pf_ptrs<BS, BWD>(F, nxt, base + 64 + lane, b1, b0);
+  if (base + 64 + lane < b1) lv_nxt = levs[base + 64 + lane];
+  for (; base < b1; base += 64) {
+    pf_entries<BS, BWD>(F, nxt);
+    pf_ptrs<BS, BWD>(F, nn, base + 128 + lane, b1, b0);
+    lv_nn = (base + 128 + lane < b1) ? levs[base + 128 + lane] : -1;
+    // levels present in this chunk: rows are sorted by level, so [level of lane 0, level of the last valid lane]
+    const int nvalid = min(64, b1 - base);
+    const int lv_lo = __shfl(lv_cur, 0, 64);
+    const int lv_hi = __shfl(lv_cur, nvalid - 1, 64);
+    for (int lv = max(lv_lo, skip_level0); lv <= lv_hi; ++lv) {
+      if (lv_cur == lv) pf_compute<BS, BWD>(F, cur, xs);
+      __syncthreads();
+    }
+    cur = nxt; lv_cur = lv_nxt;
+    nxt = nn; lv_nxt = lv_nn;
+  }
+}
+
+template <int BS>
+__global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];
+  const int b = blockIdx.x;
+  const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
+  const int nr = b1 - b0;
+  for (int t = threadIdx.x; t < nr; t += 64) {
+    const int dev = F.rowmap[b0 + t];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) xs[t * BS + e] = bvec[(size_t)dev * BS + e];
+  }
+  __syncthreads();
+  chunk_sweep<BS, false>(F, xs, b0, b1, 1);  // forward: level-0 rows have no L entries
+  chunk_sweep<BS, true>(F, xs, b0, b1, 0);   // backward: every row is scaled by its inverted pivot
+  for (int t = threadIdx.x; t < nr; t += 64) {
+    const int dev = F.rowmap[b0 + t];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[t * BS + e];
+  }
+}
+
 // GLOBAL mode kernels: x lives in HBM in ilu order
 template <int BS>
 __global__ void ilu_gather_kernel(double *xg, const double *bvec, const int32_t *rowmap, int64_t n, bool scatter) {
@@ -326,6 +618,7 @@ IluDev dev_view(jh_ilu M) {
   F.l_ptr = M->d_l_ptr.p; F.l_col = M->d_l_col.p; F.l_map = M->d_l_map.p;
   F.u_ptr = M->d_u_ptr.p; F.u_col = M->d_u_col.p; F.u_map = M->d_u_map.p;
   F.d_map = M->d_d_map.p; F.u_row = M->d_u_row.p; F.upos_of = M->d_upos_of.p;
+  F.l_lev = M->d_l_lev.p; F.u_lev = M->d_u_lev.p;
   F.l_val = M->l_val.p; F.u_val = M->u_val.p; F.dinv = M->dinv.p;
   return F;
 }
@@ -478,8 +771,13 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         if (part[P.col[k]] == part[i]) { M->u_col.push_back(ilu_of[P.col[k]] - b0); M->u_map.push_back(k); }
       M->u_ptr[pos + 1] = (int32_t)M->u_col.size();
     }
+    M->l_lev.resize(n);
+    M->u_lev.resize(n);
+    for (int64_t t = 0; t < n; ++t) M->l_lev[t] = flev[order[t]];
+    for (int64_t pos = 0; pos < n; ++pos) M->u_lev[pos] = blev[order[uord[pos]]];
     // upload
     hipStream_t s = M->ctx->stream;
+    M->d_l_lev.upload(M->l_lev, s); M->d_u_lev.upload(M->u_lev, s);
     M->d_rowmap.upload(M->rowmap, s); M->d_blk_ptr.upload(M->blk_ptr, s);
     M->d_flev_off.upload(M->flev_off, s); M->d_flev_ptr.upload(M->flev_ptr, s);
     M->d_blev_off.upload(M->blev_off, s); M->d_blev_ptr.upload(M->blev_ptr, s);
@@ -492,7 +790,18 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     M->dinv.alloc((size_t)n * bb);
     if (!lds) M->xg.alloc((size_t)n * P.bs);
     M->lds_bytes = lds ? (size_t)maxrows * P.bs * sizeof(double) : 0;
-    M->threads = 256;
+    // one wavefront per small block keeps many blocks resident per CU (the level loop is latency-bound)
+    M->threads = maxrows <= 1024 ? 64 : (maxrows <= 2048 ? 128 : 256);
+    // narrow in-block levels: let several blocks share a wavefront (only if their LDS slices fit)
+    {
+      const double rows_per_level = (double)n / std::max<double>(1.0, (double)M->flev_ptr.size());
+      int lpg = 64;
+      (void)rows_per_level;  // grouping measured slower than one block per wavefront (profiles/ notes); opt-in only
+      if (const char *e = getenv("JH_ILU_LPG")) { int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) lpg = v; }
+      while (lpg < 64 && (size_t)(64 / lpg) * maxrows * P.bs * sizeof(double) > LDS_CAP_BYTES) lpg *= 2;
+      M->lanes_per_block = lpg;
+    }
+    if (const char *e = getenv("JH_ILU_THREADS")) { int t = atoi(e); if (t == 64 || t == 128 || t == 256 || t == 512) M->threads = t; }
     JH_HIP(hipStreamSynchronize(s));
     *out = M.release();
   });
@@ -569,10 +878,50 @@ void ilu_apply(jh_ilu M, const double *b, double *x) {
   IluDev F = dev_view(M);
   const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
   if (M->lds_mode) {
+    static const bool no_pf = getenv("JH_ILU_NO_PREFETCH") != nullptr;
+    if (no_pf) {
+      switch (M->bs) {
+        case 1: hipLaunchKernelGGL(ilu_apply_blocks_kernel<1>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
+        case 2: hipLaunchKernelGGL(ilu_apply_blocks_kernel<2>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
+        case 3: hipLaunchKernelGGL(ilu_apply_blocks_kernel<3>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
+      }
+      return;
+    }
+    static const bool no_chunk = getenv("JH_ILU_NO_CHUNK") != nullptr;
+    if (M->threads == 64 && M->lanes_per_block == 64 && !no_chunk) {
+      switch (M->bs) {
+        case 1: hipLaunchKernelGGL(ilu_apply_chunked_kernel<1>, dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x); break;
+        case 2: hipLaunchKernelGGL(ilu_apply_chunked_kernel<2>, dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x); break;
+        case 3: hipLaunchKernelGGL(ilu_apply_chunked_kernel<3>, dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x); break;
+      }
+      return;
+    }
+    if (M->lanes_per_block < 64) {
+      const int G = 64 / M->lanes_per_block;
+      dim3 grid((unsigned)((nb + G - 1) / G));
+      const size_t lds = (size_t)G * M->max_block_rows * M->bs * sizeof(double);
+      const int mr = (int)M->max_block_rows, nbi = (int)nb;
+#define JH_GROUPED(BSV, LPGV) hipLaunchKernelGGL((ilu_apply_grouped_kernel<BSV, LPGV>), grid, dim3(64), lds, s, F, nbi, mr, b, x)
+      const int key = M->bs * 100 + M->lanes_per_block;
+      switch (key) {
+        case 108: JH_GROUPED(1, 8); break;
+        case 116: JH_GROUPED(1, 16); break;
+        case 132: JH_GROUPED(1, 32); break;
+        case 208: JH_GROUPED(2, 8); break;
+        case 216: JH_GROUPED(2, 16); break;
+        case 232: JH_GROUPED(2, 32); break;
+        case 308: JH_GROUPED(3, 8); break;
+        case 316: JH_GROUPED(3, 16); break;
+        case 332: JH_GROUPED(3, 32); break;
+        default: JH_THROW("bad lanes_per_block");
+      }
+#undef JH_GROUPED
+      return;
+    }
     switch (M->bs) {
-      case 1: hipLaunchKernelGGL(ilu_apply_blocks_kernel<1>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
-      case 2: hipLaunchKernelGGL(ilu_apply_blocks_kernel<2>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
-      case 3: hipLaunchKernelGGL(ilu_apply_blocks_kernel<3>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
+      case 1: hipLaunchKernelGGL(ilu_apply_blocks_pf_kernel<1>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
+      case 2: hipLaunchKernelGGL(ilu_apply_blocks_pf_kernel<2>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
+      case 3: hipLaunchKernelGGL(ilu_apply_blocks_pf_kernel<3>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
     }
     return;
   }
