@@ -198,6 +198,12 @@ int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_vec r, jh_v
 int32_t jh_comm_unique_id(char *id128);
 int32_t jh_comm_init(jh_context ctx, int32_t nranks, int32_t rank, const char *id128);
 int32_t jh_comm_finalize(jh_context ctx);
+/* In-process multi-rank backend (the analogue of DebugPArrayBackend / JuliaPArrayBackend,
+ * src/ext/partitionedarrays_ext.jl:37-39): ranks are host threads of one process exchanging through host memory;
+ * same pack/unpack kernels, halo plans and reduction placement as the RCCL path.  For tests on one GPU. */
+int32_t jh_comm_local_group_create(int32_t nranks, void **group);
+int32_t jh_comm_local_group_destroy(void *group);
+int32_t jh_comm_init_local(jh_context ctx, void *group, int32_t rank);
 /* Halo plan of a rank-local discretisation whose cells are [owned..., ghosts...] in HOST numbering
  * (ext/JutulPartitionedArraysExt/utils.jl:9-56,178-184).  For each neighbour rank: the local (1-based) owned
  * cells to send and the local ghost cells to receive, in matching order on both sides. */

@@ -24,7 +24,7 @@ from . import _lib
 from ._lib import JutulHIPError, NewtonReport, check, f64, i64, pf, pi, pi32
 from .meshgen import cartesian_neighbors, tet_lattice_mesh  # noqa: F401
 
-__all__ = ["HIPContext", "TwoPointPotentialFlowHardCoded", "DeviceVector", "StaticSparsityMatrixCSR", "ConservationLaw",
+__all__ = ["HIPContext", "LocalCommGroup", "TwoPointPotentialFlowHardCoded", "DeviceVector", "StaticSparsityMatrixCSR", "ConservationLaw",
            "ILUZeroPreconditioner", "IterativeSolverConfig", "GenericKrylov", "LinearizedSystem", "linear_solve",
            "Simulator", "JutulHIPError", "mul_", "ilu0_csr", "ldiv_", "tet_lattice_mesh", "cartesian_neighbors"]
 
@@ -88,6 +88,11 @@ class HIPContext(_Handle):
         check(_L().jh_comm_init(self.h, int(nranks), int(rank), uid))
         self.comm_size, self.comm_rank = nranks, rank
 
+    def comm_init_local(self, group, rank):
+        """Join an in-process rank group (LocalCommGroup): the DebugPArrayBackend analogue."""
+        check(_L().jh_comm_init_local(self.h, group.h, int(rank)))
+        self.comm_size, self.comm_rank = group.nranks, rank
+
     def comm_finalize(self):
         check(_L().jh_comm_finalize(self.h))
 
@@ -95,6 +100,17 @@ class HIPContext(_Handle):
         v = f64(np.atleast_1d(values)).copy()
         check(_L().jh_allreduce(self.h, pf(v), v.size, 1 if op == "max" else 0))
         return v
+
+
+class LocalCommGroup(_Handle):
+    """In-process multi-rank rendezvous (one host thread per rank), cf. DebugPArrayBackend
+    (src/ext/partitionedarrays_ext.jl:37-39)."""
+    _destroy = "jh_comm_local_group_destroy"
+
+    def __init__(self, nranks):
+        super().__init__()
+        self.nranks = int(nranks)
+        check(_L().jh_comm_local_group_create(self.nranks, C.byref(self.h)))
 
 
 class TwoPointPotentialFlowHardCoded(_Handle):

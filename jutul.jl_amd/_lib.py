@@ -89,6 +89,9 @@ SIGNATURES = {
     "jh_comm_unique_id": [C.c_char_p],
     "jh_comm_init": [H, C.c_int32, C.c_int32, C.c_char_p],
     "jh_comm_finalize": [H],
+    "jh_comm_local_group_create": [C.c_int32, C.POINTER(H)],
+    "jh_comm_local_group_destroy": [H],
+    "jh_comm_init_local": [H, H, C.c_int32],
     "jh_halo_create": [H, C.c_int64, C.c_int32, I32P, I64P, I64P, I64P, I64P],
     "jh_halo_exchange": [H, H],
     "jh_halo_exchange_state": [H],

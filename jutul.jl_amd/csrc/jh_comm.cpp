@@ -9,7 +9,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 
 #include "jh_internal.hpp"
 
@@ -59,8 +61,29 @@ static Rccl &rccl() {
     if (_r != ncclSuccess) JH_THROW(std::string("RCCL error: ") + rccl().GetErrorString(_r) + " in " #expr); \
   } while (0)
 
+// In-process rendezvous group: the analogue of the reference's DebugPArrayBackend / JuliaPArrayBackend
+// (src/ext/partitionedarrays_ext.jl:37-39) -- several ranks live in ONE process (one host thread each, any
+// device) and exchange through host memory.  Exercises the same pack/unpack kernels, halo plans, ghost handling
+// and reduction placement as the RCCL path; used by tests on a single GPU.
+struct LocalGroup {
+  int n = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t gen = 0;
+  std::vector<std::vector<double>> slot;            // per rank contribution (allreduce)
+  std::vector<std::vector<std::vector<double>>> box;  // box[src][dst] halo payload
+  void barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    uint64_t g = gen;
+    if (++arrived == n) { arrived = 0; ++gen; cv.notify_all(); }
+    else cv.wait(lk, [&] { return gen != g; });
+  }
+};
+
 struct Comm {
   ncclComm_t comm = nullptr;
+  LocalGroup *local = nullptr;
   int nranks = 1, rank = 0;
 };
 
@@ -70,6 +93,25 @@ int comm_rank(jh_context ctx) { return ctx->comm ? ctx->comm->rank : 0; }
 // in-stream all-reduce of n doubles living in device memory; no-op without a communicator
 void comm_allreduce_dev(jh_context ctx, double *p, int n, int op) {
   if (!ctx->comm || ctx->comm->nranks == 1) return;
+  if (ctx->comm->local) {
+    LocalGroup &G = *ctx->comm->local;
+    const int r = ctx->comm->rank;
+    std::vector<double> mine(n);
+    JH_HIP(hipMemcpyAsync(mine.data(), p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+    G.slot[r] = mine;
+    G.barrier();
+    std::vector<double> out(n, 0.0);
+    for (int i = 0; i < n; ++i) {
+      double acc = G.slot[0][i];
+      for (int q = 1; q < G.n; ++q) acc = (op == 1) ? std::max(acc, G.slot[q][i]) : acc + G.slot[q][i];  // fixed order
+      out[i] = acc;
+    }
+    G.barrier();  // everyone has read the slots
+    JH_HIP(hipMemcpyAsync(p, out.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+    return;
+  }
   JH_NCCL(rccl().AllReduce(p, p, (size_t)n, ncclFloat64, op == 1 ? ncclMax : ncclSum, ctx->comm->comm, ctx->stream));
 }
 
@@ -84,6 +126,28 @@ void halo_exchange(jh_tpfa d, double *v, int bs) {
   if (!ctx->comm) JH_THROW("halo exchange without a communicator (jh_comm_init)");
   hipStream_t s = ctx->stream;
   if (H.n_send) halo_pack_launch(s, H.d_send_buf.p, v, H.d_send_idx.p, H.n_send, bs);
+  if (ctx->comm->local) {
+    LocalGroup &G = *ctx->comm->local;
+    const int me = ctx->comm->rank;
+    std::vector<double> hs((size_t)H.n_send * bs), hr((size_t)H.n_recv * bs);
+    if (H.n_send) JH_HIP(hipMemcpyAsync(hs.data(), H.d_send_buf.p, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    JH_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < H.nbr.size(); ++i)
+      G.box[me][H.nbr[i]].assign(hs.begin() + H.send_ptr[i] * bs, hs.begin() + H.send_ptr[i + 1] * bs);
+    G.barrier();
+    for (size_t i = 0; i < H.nbr.size(); ++i) {
+      const std::vector<double> &in = G.box[H.nbr[i]][me];
+      if ((int64_t)in.size() != (H.recv_ptr[i + 1] - H.recv_ptr[i]) * bs) JH_THROW("halo plan mismatch between ranks");
+      std::copy(in.begin(), in.end(), hr.begin() + H.recv_ptr[i] * bs);
+    }
+    G.barrier();
+    if (H.n_recv) {
+      JH_HIP(hipMemcpyAsync(H.d_recv_buf.p, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice, s));
+      halo_unpack_launch(s, v, H.d_recv_buf.p, H.d_recv_idx.p, H.n_recv, bs);
+      JH_HIP(hipStreamSynchronize(s));
+    }
+    return;
+  }
   Rccl &R = rccl();
   JH_NCCL(R.GroupStart());
   for (size_t i = 0; i < H.nbr.size(); ++i) {
@@ -119,6 +183,33 @@ extern "C" int32_t jh_comm_init(jh_context ctx, int32_t nranks, int32_t rank, co
     ncclUniqueId id;
     std::memcpy(&id, id128, 128);
     JH_NCCL(rccl().CommInitRank(&c->comm, nranks, id, rank));
+    ctx->comm = c.release();
+  });
+}
+
+extern "C" int32_t jh_comm_local_group_create(int32_t nranks, void **group) {
+  return guard([&] {
+    if (nranks < 1 || !group) JH_THROW("bad arguments");
+    auto *G = new LocalGroup();
+    G->n = nranks;
+    G->slot.resize(nranks);
+    G->box.assign(nranks, std::vector<std::vector<double>>(nranks));
+    *group = G;
+  });
+}
+extern "C" int32_t jh_comm_local_group_destroy(void *group) {
+  return guard([&] { delete (LocalGroup *)group; });
+}
+extern "C" int32_t jh_comm_init_local(jh_context ctx, void *group, int32_t rank) {
+  return guard([&] {
+    if (!ctx || !group) JH_THROW("null argument");
+    if (ctx->comm) JH_THROW("communicator already initialised");
+    auto *G = (LocalGroup *)group;
+    if (rank < 0 || rank >= G->n) JH_THROW("rank out of range");
+    auto c = std::make_unique<Comm>();
+    c->local = G;
+    c->nranks = G->n;
+    c->rank = rank;
     ctx->comm = c.release();
   });
 }

@@ -127,3 +127,32 @@ class HostExchange:
         for rcv, inp, _ in bufs:
             v2[rcv - 1] = inp.numpy()
         return v
+
+
+def setup_rank_problem(ctx, N, part, rank, T, vol, X0, kind="poisson", block_n=1, sources=None, reorder="blocks",
+                       block_rows=512, law_params=None, gdz=None):
+    """Builds this rank's discretisation + law the way PArraySimulator does per rank (interface.jl:38-63):
+    submodel on [owned..., ghosts...], substate, halo plan.  `rank` is 0-based; `sources` = (cells 1-based global,
+    values [n, block_n]).  Returns (disc, law, sub)."""
+    from . import ConservationLaw, TwoPointPotentialFlowHardCoded
+    sub = local_subdomain(N, part, rank + 1)
+    cells = sub["cells"] - 1
+    disc = TwoPointPotentialFlowHardCoded(ctx, sub["N"], sub["n_local"], block_n=block_n, reorder=reorder,
+                                          block_rows=block_rows, n_owned=sub["n_owned"])
+    disc.set_halo(sub["n_owned"], sub["neighbors"], sub["send"], sub["recv"])
+    law = ConservationLaw(disc, kind, **(law_params or {}))
+    law.set_face_trans(np.asarray(T)[sub["faces"] - 1])
+    law.set_volumes(np.asarray(vol)[cells])
+    if gdz is not None:
+        law.set_face_gdz(np.asarray(gdz)[sub["faces"] - 1])
+    X0 = np.asarray(X0).reshape(-1, block_n)
+    law.set_state(X0[cells].reshape(-1))
+    law.set_state0(X0[cells].reshape(-1))
+    if sources is not None:
+        sc, sv = np.asarray(sources[0], dtype=np.int64), np.asarray(sources[1], dtype=np.float64).reshape(-1, block_n)
+        g2l = np.full(np.asarray(part).size, 0, dtype=np.int64)
+        g2l[cells[: sub["n_owned"]]] = np.arange(1, sub["n_owned"] + 1)
+        keep = g2l[sc - 1] > 0  # forces only on the owning rank
+        if keep.any():
+            law.set_sources(g2l[sc[keep] - 1], sv[keep].reshape(-1))
+    return disc, law, sub

@@ -1,0 +1,156 @@
+"""GPU tests of the domain-decomposed path on ONE GPU: ranks are host threads joined by the in-process
+LocalCommGroup (the DebugPArrayBackend analogue); same kernels / halo plans / reductions as the RCCL path.
+Property pinned (the reference has no test here): N-rank result == 1-rank result to solver tolerance."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ja():
+    import jutul_amd
+    return jutul_amd
+
+
+def run_ranks(nranks, fn):
+    out, err = [None] * nranks, [None] * nranks
+
+    def wrap(r):
+        try:
+            out[r] = fn(r)
+        except Exception as e:  # noqa: BLE001
+            err[r] = e
+    th = [threading.Thread(target=wrap, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+def problem(ja, dims=(10, 9, 8), kind="poisson", seed=0):
+    g = ja.tet_lattice_mesh(*dims)
+    rng = np.random.default_rng(seed)
+    nblk = 2 if kind == "twophase" else 1
+    nc = g["nc"]
+    if nblk == 1:
+        X0 = 1.0 + 0.1 * rng.random(nc)
+    else:
+        X0 = np.stack([1.0 + 0.1 * rng.random(nc), rng.uniform(0.3, 0.7, nc)]).T.reshape(-1)
+    return g, g["T"] / g["T"].mean(), X0, nblk
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("kind", ["poisson", "twophase"])
+def test_distributed_newton_matches_single_rank(ja, kind, nranks):
+    from jutul_amd import dd
+    g, T, X0, nblk = problem(ja, kind=kind)
+    nc = g["nc"]
+    par = dict(rho0=(1.0, 0.8), compressibility=(1e-2, 2e-2), viscosity=(1.0, 2.0), p_ref=1.0)
+    dt = 0.5
+    q = 1.0 if nblk == 1 else 0.02  # keep the two-phase saturations inside (0, 1) without update limits
+    src = ([1, nc], np.array([[q] * nblk, [-q] * nblk]))
+
+    def make_sim(law):
+        ks = ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"),
+                              relative_tolerance=1e-11, max_iterations=300, precond_side="left")
+        return ja.Simulator(law, ks, tolerance=1e-9)
+
+    # single rank reference (same left preconditioning as the distributed path, ext/.../krylov.jl:60)
+    ctx0 = ja.HIPContext(0)
+    disc0 = ja.TwoPointPotentialFlowHardCoded(ctx0, g["N"], nc, block_n=nblk, reorder="blocks", block_rows=256)
+    law0 = ja.ConservationLaw(disc0, kind, **par)
+    law0.set_face_trans(T)
+    law0.set_volumes(g["volumes"])
+    law0.set_state(X0)
+    law0.set_state0(X0)
+    law0.set_sources(src[0], src[1].reshape(-1))
+    sim0 = make_sim(law0)
+    ok0, its0, _ = sim0.solve_ministep(dt)
+    assert ok0
+    X_ref = law0.get_state().reshape(nc, nblk)
+
+    part = dd.partition_rcb(g["cell_centroids"], nranks)
+    group = ja.LocalCommGroup(nranks)
+
+    def rank_fn(r):
+        ctx = ja.HIPContext(0)
+        ctx.comm_init_local(group, r)
+        disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, r, T, g["volumes"], X0, kind=kind, block_n=nblk,
+                                               sources=src, block_rows=256, law_params=par)
+        sim = make_sim(law)
+        ok, its, rep = sim.solve_ministep(dt)
+        X = law.get_state().reshape(-1, nblk)
+        ctx.comm_finalize()
+        return ok, its, sub, X
+
+    res = run_ranks(nranks, rank_fn)
+    X = np.zeros_like(X_ref)
+    for ok, its, sub, Xl in res:
+        assert ok
+        own = sub["cells"][: sub["n_owned"]] - 1
+        X[own] = Xl[: sub["n_owned"]]
+        # ghosts carry the owner's values after the final consistent!(x) + update
+        gh = sub["cells"][sub["n_owned"]:] - 1
+        assert np.allclose(Xl[sub["n_owned"]:], X_ref[gh], rtol=1e-7, atol=1e-9)
+    assert np.abs(X - X_ref).max() <= 1e-7 * np.abs(X_ref).max()
+    assert all(r[1] == res[0][1] for r in res)  # every rank takes the same number of Newton iterations
+
+
+def test_halo_exchange_and_unit_diagonalize(ja):
+    """consistent!(v) fills every ghost with its owner's value; unit_diagonalize! turns ghost rows into -I."""
+    from jutul_amd import dd
+    g, T, X0, _ = problem(ja, dims=(6, 5, 4))
+    nc = g["nc"]
+    nranks = 3
+    part = dd.partition_rcb(g["cell_centroids"], nranks)
+    group = ja.LocalCommGroup(nranks)
+    glob = np.arange(1, nc + 1, dtype=np.float64) * 1.5
+
+    def rank_fn(r):
+        ctx = ja.HIPContext(0)
+        ctx.comm_init_local(group, r)
+        disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, r, T, g["volumes"], X0, block_rows=64)
+        loc = glob[sub["cells"] - 1].copy()
+        loc[sub["n_owned"]:] = -777.0  # stale ghosts
+        v = ja.DeviceVector(disc, loc)
+        ja._lib.check(ja._lib.load().jh_halo_exchange(disc.h, v.h))
+        out = v.download()
+        lsys = ja.LinearizedSystem(disc)
+        law.update_equation_and_linearized_system(0.5, lsys.jac, lsys.r)
+        ja._lib.check(ja._lib.load().jh_unit_diagonalize(lsys.jac.h, lsys.r.h, sub["n_owned"]))
+        rowptr, colidx = disc.pattern()
+        nz, rr = lsys.jac.nzval, lsys.r.download()
+        ctx.comm_finalize()
+        return sub, out, rowptr, colidx, nz, rr
+
+    for sub, out, rowptr, colidx, nz, rr in run_ranks(nranks, rank_fn):
+        assert np.array_equal(out, glob[sub["cells"] - 1])
+        no = sub["n_owned"]
+        assert np.all(rr[no:] == 0.0)
+        for row in range(no, sub["n_local"]):
+            cols = colidx[rowptr[row] - 1: rowptr[row + 1] - 1]
+            vals = nz[rowptr[row] - 1: rowptr[row + 1] - 1]
+            assert np.array_equal(vals, np.where(cols == row + 1, -1.0, 0.0))
+
+
+def test_rccl_single_rank_communicator(ja):
+    """The RCCL code path with a 1-rank communicator (dlopen librccl, ncclCommInitRank, in-stream all-reduce)."""
+    from jutul_amd import dd
+    g, T, X0, _ = problem(ja, dims=(6, 5, 4))
+    nc = g["nc"]
+    ctx = ja.HIPContext(0)
+    ctx.comm_init(1, 0, ja.HIPContext.comm_unique_id())
+    assert np.allclose(ctx.allreduce([1.5, -2.0], "sum"), [1.5, -2.0])
+    part = np.ones(nc, dtype=np.int64)
+    disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, 0, T, g["volumes"], X0, sources=([1, nc], [1.0, -1.0]))
+    assert sub["n_owned"] == nc and len(sub["neighbors"]) == 0
+    sim = ja.Simulator(law, ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"),
+                                             relative_tolerance=1e-10, precond_side="left"), tolerance=1e-8)
+    ok, its, rep = sim.solve_ministep(0.5)
+    assert ok and its == 2
+    ctx.comm_finalize()
