@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cells", type=int, default=10_000_000)
     ap.add_argument("--law", default="poisson", choices=["poisson", "compressible"])
-    ap.add_argument("--block-rows", type=int, default=4096)
+    ap.add_argument("--block-rows", type=int, default=512)
     ap.add_argument("--rtol", type=float, default=1e-3)
     ap.add_argument("--dt", type=float, default=5.0)
     ap.add_argument("--cpu-cells", type=int, default=1_000_000)

@@ -196,7 +196,7 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
     if (partition) {
       order_by_partition(A, nc, partition, pat->perm, pat->block_ptr);
     } else if (reorder == JH_REORDER_BLOCKS) {
-      if (block_rows <= 0) block_rows = 4096;
+      if (block_rows <= 0) block_rows = 512;
       order_blocks(A, nc, n_owned, block_rows, pat->perm, pat->block_ptr);
     } else if (reorder != JH_REORDER_NONE) {
       JH_THROW("unknown reorder mode");

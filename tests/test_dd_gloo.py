@@ -1,0 +1,176 @@
+"""CPU multi-process test (gloo, world_size 2) of the domain-decomposition host logic: partitions, rank-local
+subdomains with one ghost ring, halo plans and `consistent!` (HostExchange).  Compute is done with the CPU oracle
+(tests may use it as the checker); the property pinned is the reference's distributed semantics:
+N-rank distributed BiCGStab == serial solve."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import jutul_amd as ja
+        from jutul_amd import dd
+        from oracle import oracle as o
+        o.set_num_threads(1)
+        g = ja.tet_lattice_mesh(7, 6, 5)
+        nc = g["nc"]
+        T = g["T"] / g["T"].mean()
+        rng = np.random.default_rng(0)
+        U0 = 1.0 + 0.1 * rng.random(nc)
+        dt = 0.5
+        part = dd.partition_rcb(g["cell_centroids"], world)
+        sub = dd.local_subdomain(g["N"], part, rank + 1)
+        cells = sub["cells"] - 1
+        no, nl = sub["n_owned"], sub["n_local"]
+        # every owned cell of mine that is a ghost elsewhere is in a send list, and vice versa (plan symmetry)
+        counts = torch.zeros(world, dtype=torch.int64)
+        for s, snd in zip(sub["neighbors"], sub["send"]):
+            counts[int(s)] = len(snd)
+        allc = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allc, counts)
+        for s, rcv in zip(sub["neighbors"], sub["recv"]):
+            assert int(allc[int(s)][rank]) == len(rcv)
+        # consistent!: ghosts receive the owner's value
+        ex = dd.HostExchange(sub)
+        v = (cells + 1).astype(np.float64)
+        v[no:] = -1.0
+        ex(v)
+        assert np.array_equal(v, (cells + 1).astype(np.float64))
+        # local system = assemble on owned+ghost, ghost rows -> -I (linalg.jl:18-35)
+        osys = o.TPFASystem(sub["N"], nl)
+        law = o.Law("poisson", dt)
+        src_c = [i + 1 for i, c in enumerate(cells[:no]) if c in (0, nc - 1)]
+        src_v = [1.0 if cells[i - 1] == 0 else -1.0 for i in src_c]
+        nz, r = osys.assemble(law, U0[cells], U0[cells], g["volumes"][cells], T[sub["faces"] - 1], src_cells=src_c or None,
+                              src_values=src_v or None)
+        nz, r = o.unit_diagonalize(nl, no, 1, osys.rowptr, osys.colidx, nz, r)
+        F = o.ILU0(nl, 1, osys.rowptr, osys.colidx, nz)
+
+        def gdot(a, b):
+            t = torch.tensor([float(a[:no] @ b[:no])], dtype=torch.float64)
+            dist.all_reduce(t)
+            return float(t[0])
+
+        def prec(x):  # parray_preconditioner_apply!: ghost input zeroed (linalg.jl:78-88)
+            x = x.copy()
+            x[no:] = 0.0
+            return F.apply(x)
+
+        def mul(x):  # distributed_mul!: consistent!(x) then local mul! (linalg.jl:37-55)
+            ex(x)
+            return o.spmv(nl, 1, osys.rowptr, osys.colidx, nz, x)
+
+        # left-preconditioned BiCGStab on distributed vectors (ext/.../krylov.jl:51-105)
+        b = r.copy()
+        ex(b)
+        x = np.zeros(nl)
+        rr = prec(b)
+        p, c = rr.copy(), rr.copy()
+        rho = gdot(c, rr)
+        r0 = np.sqrt(gdot(rr, rr))
+        its = 0
+        while np.sqrt(gdot(rr, rr)) > 1e-12 * r0 and its < 200:
+            its += 1
+            vv = prec(mul(p))
+            alpha = rho / gdot(c, vv)
+            s = rr - alpha * vv
+            t = prec(mul(s))
+            omega = gdot(t, s) / gdot(t, t)
+            x = x + alpha * p + omega * s
+            rr = s - omega * t
+            rho_n = gdot(c, rr)
+            p = rr + (rho_n / rho) * (alpha / omega) * (p - omega * vv)
+            rho = rho_n
+        ex(x)
+        q.put((rank, cells[:no], x[:no], cells[no:], x[no:], its))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put(("error", rank, traceback.format_exc()))
+
+
+def test_two_rank_gloo_distributed_solve_matches_serial():
+    import torch.multiprocessing as mp
+    from oracle import oracle as o
+    import jutul_amd as ja
+    world = 2
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=240) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    for r in res:
+        assert r[0] != "error", r
+    # serial reference
+    g = ja.tet_lattice_mesh(7, 6, 5)
+    nc = g["nc"]
+    T = g["T"] / g["T"].mean()
+    U0 = 1.0 + 0.1 * np.random.default_rng(0).random(nc)
+    osys = o.TPFASystem(g["N"], nc)
+    nz, r = osys.assemble(o.Law("poisson", 0.5), U0, U0, g["volumes"], T, src_cells=[1, nc], src_values=[1.0, -1.0])
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    A = sp.csr_matrix((nz, osys.colidx - 1, osys.rowptr - 1), shape=(nc, nc))
+    x_ref = spl.spsolve(A.tocsc(), r)
+    x = np.zeros(nc)
+    for rank, own, xo, gh, xg, its in res:
+        x[own] = xo
+        assert np.allclose(xg, x_ref[gh], rtol=1e-8, atol=1e-10)  # ghosts consistent after the final exchange
+        assert its < 100
+    assert np.abs(x - x_ref).max() <= 1e-8 * np.abs(x_ref).max()
+
+
+def test_partition_and_subdomain_properties(oracle):
+    import jutul_amd as ja
+    from jutul_amd import dd
+    g = ja.tet_lattice_mesh(6, 5, 4)
+    nc, N = g["nc"], g["N"]
+    assert np.array_equal(dd.partition_linear(3, 7), oracle.partition_linear(3, 7))  # partitioning.jl:12-18
+    assert np.array_equal(dd.compress_partition([1, 3, 6, 5]), [1, 2, 4, 3])         # test/partitioning.jl:8
+    for npart in (1, 2, 3, 5, 8):
+        p = dd.partition_rcb(g["cell_centroids"], npart)
+        assert p.min() == 1 and p.max() == npart and np.all(np.bincount(p)[1:] > 0)  # test/partitioning.jl:13-19
+        assert np.bincount(p)[1:].max() - np.bincount(p)[1:].min() <= npart
+        rem, counts = dd.remap_global_indices(p, npart)
+        orem, ocounts = oracle.remap_global_indices(p, npart)
+        assert np.array_equal(rem, orem) and np.array_equal(counts, ocounts)
+        owned_total = 0
+        for r in range(1, npart + 1):
+            sub = dd.local_subdomain(N, p, r)
+            owned_total += sub["n_owned"]
+            ghosts = sub["cells"][sub["n_owned"]:]
+            assert np.array_equal(ghosts, np.sort(oracle.partition_boundary(N, p, r)))  # utils.jl:32-56
+            assert np.array_equal(ghosts, dd.partition_boundary(N, p, r))
+            # faces kept iff both cells local (subdomains.jl:108-119), local numbering consistent
+            gl = sub["cells"]
+            assert np.array_equal(gl[sub["N"][0] - 1], N[0][sub["faces"] - 1])
+            assert np.array_equal(gl[sub["N"][1] - 1], N[1][sub["faces"] - 1])
+            loc = np.zeros(nc + 1, dtype=bool)
+            loc[gl] = True
+            assert np.array_equal(np.flatnonzero(loc[N[0]] & loc[N[1]]) + 1, sub["faces"])
+            for s, snd, rcv in zip(sub["neighbors"], sub["send"], sub["recv"]):
+                assert np.all(p[gl[rcv - 1] - 1] == s + 1) and np.all(snd <= sub["n_owned"]) and np.all(rcv > sub["n_owned"])
+        assert owned_total == nc
