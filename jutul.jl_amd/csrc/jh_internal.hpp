@@ -193,7 +193,18 @@ void k_dot2(jh_context ctx, const double *a, const double *b, const double *c, c
 void k_absmax_strided(jh_context ctx, const double *r, int64_t ncell, int bs, int slot);
 double read_scalar(jh_context ctx, int slot);                  // sync + D2H
 void read_scalars(jh_context ctx, int slot, int count, double *out);
-void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta);
+// Optional dot-product epilogue of the SpMV: mode 1 -> sum(w .* y) ; mode 2 -> sum(y .* w), sum(y .* y); rows >= n_rows
+// (ghost rows) do not contribute.  Results land in ctx->scalars[slot (, slot+1)] after an ordered final reduction.
+struct SpmvDot {
+  int mode = 0;
+  const double *w = nullptr;
+  int slot = 0;
+  int64_t n_rows = 0;
+};
+void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta,
+            const SpmvDot *dot = nullptr);
+void ensure_partials(jh_context ctx, size_t min_stride);
+void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max);
 void k_unit_diag(hipStream_t s, const Pattern &P, double *val, double *r, int64_t n_owned);
 
 // ---- assembly (jh_assembly.hip) -------------------------------------------------------------------------------

@@ -133,45 +133,75 @@ __global__ __launch_bounds__(256) void absmax_partial_kernel(const double *r, in
   double r0 = block_reduce<true>(m, sm);
   if (threadIdx.x == 0) part[blockIdx.x] = r0;
 }
-// final: one block sums nparts partials of `count` slots in fixed order
+// final: one 1024-thread block sums nparts partials of `count` slots in a fixed order.  The loads of a thread are
+// independent (8 accumulators), so ~50k tile partials cost a few microseconds instead of a serial latency chain.
+constexpr int FIN_THREADS = 1024;
 template <bool MAX>
-__global__ __launch_bounds__(256) void final_reduce_kernel(const double *part, size_t stride, int nparts, int count, double *out) {
-  __shared__ double sm[8];
+__global__ __launch_bounds__(FIN_THREADS) void final_reduce_kernel(const double *part, size_t stride, int nparts, int count, double *out) {
+  __shared__ double sm[FIN_THREADS / 64];
   for (int k = 0; k < count; ++k) {
-    double s = 0;
-    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-      double v = part[k * stride + i];
-      s = MAX ? ((v > s || v != v) ? v : s) : s + v;
+    const double *p = part + k * stride;
+    double a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.0;
+    int i = threadIdx.x;
+    for (; i + 7 * FIN_THREADS < nparts; i += 8 * FIN_THREADS) {
+      double v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[i + j * FIN_THREADS];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = MAX ? ((v[j] > a[j] || v[j] != v[j]) ? v[j] : a[j]) : a[j] + v[j];
     }
-    double r = block_reduce<MAX>(s, sm);
-    if (threadIdx.x == 0) out[k] = r;
+    for (int j = 0; i < nparts; i += FIN_THREADS, ++j) {
+      const double v = p[i];
+      a[j & 7] = MAX ? ((v > a[j & 7] || v != v) ? v : a[j & 7]) : a[j & 7] + v;
+    }
+    double s = a[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) s = MAX ? ((a[j] > s || a[j] != a[j]) ? a[j] : s) : s + a[j];
+    s = MAX ? wave_max(s) : wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double r = sm[0];
+      for (int w = 1; w < FIN_THREADS / 64; ++w) r = MAX ? ((sm[w] > r || sm[w] != sm[w]) ? sm[w] : r) : r + sm[w];
+      out[k] = r;
+    }
+    __syncthreads();
   }
 }
 
-static void ensure_partials(jh_context ctx) {
-  if (ctx->partials.n == 0) {
-    ctx->partial_stride = 65536;  // also used by tile-level partials
+void ensure_partials(jh_context ctx, size_t min_stride) {
+  if (ctx->partials.n == 0 || ctx->partial_stride < min_stride) {
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->partial_stride = std::max<size_t>(65536, min_stride);  // also used by tile-level partials
     ctx->partials.alloc(ctx->partial_stride * 4);
   }
 }
+void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max) {
+  if (is_max)
+    hipLaunchKernelGGL(final_reduce_kernel<true>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, nparts, count, ctx->scalars.p + slot);
+  else
+    hipLaunchKernelGGL(final_reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, nparts, count, ctx->scalars.p + slot);
+}
 
 void k_dot2(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, int slot) {
-  ensure_partials(ctx);
+  ensure_partials(ctx, 0);
   int g = grid_for(n);
   if (g > RED_BLOCKS) g = RED_BLOCKS;
   hipLaunchKernelGGL(dot2_partial_kernel, dim3(g), dim3(256), 0, ctx->stream, a, b, c, d, n, ctx->partials.p, ctx->partial_stride);
-  hipLaunchKernelGGL(final_reduce_kernel<false>, dim3(1), dim3(256), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, g,
+  hipLaunchKernelGGL(final_reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, g,
                      c ? 2 : 1, ctx->scalars.p + slot);
 }
 void k_dot(jh_context ctx, const double *a, const double *b, int64_t n, int slot) { k_dot2(ctx, a, b, nullptr, nullptr, n, slot); }
 
 void k_absmax_strided(jh_context ctx, const double *r, int64_t ncell, int bs, int slot) {
-  ensure_partials(ctx);
+  ensure_partials(ctx, 0);
   int g = grid_for(ncell);
   if (g > RED_BLOCKS) g = RED_BLOCKS;
   for (int e = 0; e < bs; ++e) {
     hipLaunchKernelGGL(absmax_partial_kernel, dim3(g), dim3(256), 0, ctx->stream, r, ncell, bs, e, ctx->partials.p);
-    hipLaunchKernelGGL(final_reduce_kernel<true>, dim3(1), dim3(256), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, g, 1,
+    hipLaunchKernelGGL(final_reduce_kernel<true>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, g, 1,
                        ctx->scalars.p + slot + e);
   }
 }
@@ -190,13 +220,14 @@ double read_scalar(jh_context ctx, int slot) {
 // ---------------------------------------------------------------------------------------------------------
 // SpMV: y = alpha*A*x (+ beta*y)
 // ---------------------------------------------------------------------------------------------------------
-template <int BS>
+template <int BS, int DOT>
 __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *__restrict__ tile_row, int ntiles,
                                                                  const int32_t *__restrict__ rowptr,
                                                                  const int32_t *__restrict__ col,
                                                                  const double *__restrict__ val,
                                                                  const double *__restrict__ x, double *__restrict__ y,
-                                                                 double alpha, double beta) {
+                                                                 double alpha, double beta, const double *__restrict__ dw,
+                                                                 int dot_rows, double *__restrict__ part, size_t pstride) {
   __shared__ double prod[TILE_NNZ * BS];
   __shared__ int32_t rp[TILE_ROWS + 1];
   __shared__ double red[8];
@@ -207,6 +238,7 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
   const int base = rowptr[r0];
   const int cnt = rowptr[r1] - base;
   const int tid = threadIdx.x;
+  double d0 = 0.0, d1 = 0.0;  // fused dot partials of this lane
   if (nrows == 1 && cnt > TILE_NNZ) {
     // long row: the whole workgroup strides over one row, then block-reduces
     double acc[BS];
@@ -231,9 +263,12 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
       double s = block_reduce<false>(acc[e], red);
       if (tid == 0) {
         size_t o = (size_t)r0 * BS + e;
-        y[o] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[o];
+        const double yv = (beta == 0.0) ? alpha * s : alpha * s + beta * y[o];
+        y[o] = yv;
+        if (DOT && r0 < dot_rows) { d0 += yv * dw[o]; if (DOT == 2) d1 += yv * yv; }
       }
     }
+    if (DOT && tid == 0) { part[t] = d0; if (DOT == 2) part[pstride + t] = d1; }
     return;
   }
   for (int i = tid; i <= nrows; i += TILE_THREADS) rp[i] = rowptr[r0 + i] - base;
@@ -269,21 +304,47 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
 #pragma unroll
     for (int e = 0; e < BS; ++e) {
       size_t o = (size_t)(r0 + tid) * BS + e;
-      y[o] = (beta == 0.0) ? alpha * s[e] : alpha * s[e] + beta * y[o];
+      const double yv = (beta == 0.0) ? alpha * s[e] : alpha * s[e] + beta * y[o];
+      y[o] = yv;
+      if (DOT && r0 + tid < dot_rows) { d0 += yv * dw[o]; if (DOT == 2) d1 += yv * yv; }
+    }
+  }
+  if (DOT) {  // one partial per tile (per-wavefront partials were measured slower: 4x longer final reduction)
+    const double p0 = block_reduce<false>(d0, red);
+    if (tid == 0) part[t] = p0;
+    if (DOT == 2) {
+      const double p1 = block_reduce<false>(d1, red);
+      if (tid == 0) part[pstride + t] = p1;
     }
   }
 }
 
-void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta) {
+void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta,
+            const SpmvDot *dot) {
   if (P.n == 0) return;
   int chunk = (P.ntiles + NUM_XCD - 1) / NUM_XCD;
   dim3 grid(chunk * NUM_XCD), block(TILE_THREADS);
-  switch (P.bs) {
-    case 1: hipLaunchKernelGGL(spmv_tile_kernel<1>, grid, block, 0, ctx->stream, P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta); break;
-    case 2: hipLaunchKernelGGL(spmv_tile_kernel<2>, grid, block, 0, ctx->stream, P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta); break;
-    case 3: hipLaunchKernelGGL(spmv_tile_kernel<3>, grid, block, 0, ctx->stream, P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta); break;
+  const int mode = dot ? dot->mode : 0;
+  if (mode) ensure_partials(ctx, (size_t)P.ntiles);
+  const double *dw = dot ? dot->w : nullptr;
+  const int drows = dot ? (int)dot->n_rows : 0;
+  double *part = ctx->partials.p;
+  const size_t ps = ctx->partial_stride;
+#define JH_SPMV(BSV, DV) hipLaunchKernelGGL((spmv_tile_kernel<BSV, DV>), grid, block, 0, ctx->stream, P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta, dw, drows, part, ps)
+  switch (P.bs * 10 + mode) {
+    case 10: JH_SPMV(1, 0); break;
+    case 11: JH_SPMV(1, 1); break;
+    case 12: JH_SPMV(1, 2); break;
+    case 20: JH_SPMV(2, 0); break;
+    case 21: JH_SPMV(2, 1); break;
+    case 22: JH_SPMV(2, 2); break;
+    case 30: JH_SPMV(3, 0); break;
+    case 31: JH_SPMV(3, 1); break;
+    case 32: JH_SPMV(3, 2); break;
     default: JH_THROW("unsupported block size");
   }
+#undef JH_SPMV
+  if (mode) k_final_reduce(ctx, P.ntiles, mode == 2 ? 2 : 1, dot->slot, false);
 }
 
 // unit_diagonalize!: ghost rows -> -I, r_ghost -> 0 (ext/JutulPartitionedArraysExt/linalg.jl:18-35)

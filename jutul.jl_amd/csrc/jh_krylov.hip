@@ -64,7 +64,8 @@ struct jh_krylov_s {
 
 namespace {
 // scalar slots in ctx->scalars
-enum { S_RHO0 = 0, S_RHO1 = 1, S_RR = 2, S_CV = 3, S_TS = 4, S_TT = 5, S_ERR = 8 /* ..9 */ };
+// (rho, ||r||^2) live in two ping-pong pairs so that one fused reduction can write (rho_next, ||r_next||^2) contiguously
+enum { S_PAIR0 = 0 /* rho, rr */, S_CV = 3, S_TS = 4, S_TT = 5, S_PAIR1 = 6 /* rho, rr */, S_ERR = 8 /* ..10 */ };
 
 // s = r - alpha*v, alpha = rho/cv
 __global__ void bicg_s_kernel(double *s, const double *r, const double *v, const double *sc, int rho_slot, int64_t n) {
@@ -85,9 +86,38 @@ __global__ void bicg_xr_kernel(double *x, double *r, const double *y, const doub
     r[i] = s[i] - omega * t[i];
   }
 }
+// fused: x += alpha*y + omega*z ; r = s - omega*t ; partial sums of <c,r> and <r,r> over the first nd entries
+__global__ __launch_bounds__(256) void bicg_xr_dots_kernel(double *x, double *r, const double *y, const double *z, const double *s,
+                                                           const double *t, const double *c, const double *sc, int rho_slot, int64_t n,
+                                                           int64_t nd, double *part, size_t stride) {
+  __shared__ double sm[4];
+  const double alpha = sc[rho_slot] / sc[S_CV];
+  const double omega = sc[S_TS] / sc[S_TT];
+  double d0 = 0.0, d1 = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double xi = x[i];
+    xi += alpha * y[i];
+    xi += omega * z[i];
+    x[i] = xi;
+    const double ri = s[i] - omega * t[i];
+    r[i] = ri;
+    if (i < nd) { d0 += c[i] * ri; d1 += ri * ri; }
+  }
+  // block reduction (4 wavefronts)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); d1 += __shfl_down(d1, off, 64); }
+  if (lane == 0) sm[w] = d0;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  __syncthreads();
+  if (lane == 0) sm[w] = d1;
+  __syncthreads();
+  if (threadIdx.x == 0) part[stride + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
 // p = r + beta*(p - omega*v), beta = (rho'/rho)*(alpha/omega)
-__global__ void bicg_p_kernel(double *p, const double *r, const double *v, const double *sc, int rho_slot, int64_t n) {
-  const double rho = sc[rho_slot], rho_next = sc[rho_slot ^ 1];
+__global__ void bicg_p_kernel(double *p, const double *r, const double *v, const double *sc, int rho_slot, int rho_next_slot, int64_t n) {
+  const double rho = sc[rho_slot], rho_next = sc[rho_next_slot];
   const double alpha = rho / sc[S_CV];
   const double omega = sc[S_TS] / sc[S_TT];
   const double beta = (rho_next / rho) * (alpha / omega);
@@ -143,11 +173,13 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     k_dot2(ctx, a, bb, c2, d2, nd, slot);
     comm_allreduce_dev(ctx, sc + slot, c2 ? 2 : 1, 0);
   };
-  auto spmv = [&](double *in, double *out) {
+  const int64_t rows_dot = nd / P.bs;
+  auto spmv = [&](double *in, double *out, const SpmvDot *dot) {
     if (dist) halo_exchange(disc, in, P.bs);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
     K->mark(0, st);
-    k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0);
+    k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot);
     K->mark(0, st);
+    if (dot) comm_allreduce_dev(ctx, sc + dot->slot, dot->mode == 2 ? 2 : 1, 0);
   };
   k_fill(st, x, n, 0.0);
   k_copy(st, K->c.p, b_in, n);  // scratch copy of b (the ghost zeroing of the preconditioner must not touch b)
@@ -155,11 +187,11 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   if (left) prec(K->c.p, K->r.p); else k_copy(st, K->r.p, K->c.p, n);  // r0 = M^-1 b
   k_copy(st, K->p.p, K->r.p, n);
   k_copy(st, K->c.p, K->r.p, n);  // c = r0
-  // rho = <c,r>, ||r||^2
-  k_dot2(ctx, K->c.p, K->r.p, K->r.p, K->r.p, nd, S_RHO0);  // writes S_RHO0 and S_RHO0+1
-  comm_allreduce_dev(ctx, sc + S_RHO0, 2, 0);
+  // rho = <c,r>, ||r||^2 -> pair 0
+  k_dot2(ctx, K->c.p, K->r.p, K->r.p, K->r.p, nd, S_PAIR0);
+  comm_allreduce_dev(ctx, sc + S_PAIR0, 2, 0);
   double h2[2];
-  read_scalars(ctx, S_RHO0, 2, h2);
+  read_scalars(ctx, S_PAIR0, 2, h2);
   double rho = h2[0];
   double rnorm = std::sqrt(h2[1]);
   const double eps = atol + rtol * rnorm;
@@ -168,37 +200,53 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   int status = 0;
   bool solved = rnorm <= eps;
   if (rho == 0.0 && !solved) status = 2;  // "Breakdown b'c = 0"
-  int rs = S_RHO0;                        // slot of the current rho; rho_next goes to rs^1
+  int rs = S_PAIR0;                       // pair holding the current (rho, rr); the next one goes to the other pair
+  ensure_partials(ctx, 4096);
   while (!solved && it < itmax && status == 0) {
     ++it;
+    const int rn = (rs == S_PAIR0) ? S_PAIR1 : S_PAIR0;
     double *yy = K->p.p;
     if (right) { prec(K->p.p, K->y.p); yy = K->y.p; }
-    spmv(yy, K->q.p);
     double *vv = K->q.p;
-    if (left) { prec(K->q.p, K->v.p); vv = K->v.p; }
-    dot2(K->c.p, vv, nullptr, nullptr, S_CV);
+    if (left) {
+      spmv(yy, K->q.p, nullptr);
+      prec(K->q.p, K->v.p);
+      vv = K->v.p;
+      dot2(K->c.p, vv, nullptr, nullptr, S_CV);
+    } else {
+      SpmvDot d1{1, K->c.p, S_CV, rows_dot};  // <c, A y> fused into the SpMV epilogue
+      spmv(yy, K->q.p, &d1);
+    }
     hipLaunchKernelGGL(bicg_s_kernel, vgrid(n), dim3(256), 0, st, K->s.p, K->r.p, vv, sc, rs, n);
     double *zz = K->s.p;
     if (right) { prec(K->s.p, K->z.p); zz = K->z.p; }
-    spmv(zz, K->d.p);
     double *tt = K->d.p;
-    if (left) { prec(K->d.p, K->t.p); tt = K->t.p; }
-    dot2(tt, K->s.p, tt, tt, S_TS);
-    hipLaunchKernelGGL(bicg_xr_kernel, vgrid(n), dim3(256), 0, st, x, K->r.p, yy, zz, K->s.p, tt, sc, rs, n);
-    // rho_next = <c,r> into the other rho slot, ||r||^2 into S_RR
-    k_dot(ctx, K->c.p, K->r.p, nd, rs ^ 1);
-    k_dot(ctx, K->r.p, K->r.p, nd, S_RR);
-    if (ctx->comm) { comm_allreduce_dev(ctx, sc + (rs ^ 1), 1, 0); comm_allreduce_dev(ctx, sc + S_RR, 1, 0); }
-    hipLaunchKernelGGL(bicg_p_kernel, vgrid(n), dim3(256), 0, st, K->p.p, K->r.p, vv, sc, rs, n);
-    double h[6];
-    read_scalars(ctx, 0, 6, h);
+    if (left) {
+      spmv(zz, K->d.p, nullptr);
+      prec(K->d.p, K->t.p);
+      tt = K->t.p;
+      dot2(tt, K->s.p, tt, tt, S_TS);
+    } else {
+      SpmvDot d2{2, K->s.p, S_TS, rows_dot};  // <t,s>, <t,t> fused
+      spmv(zz, K->d.p, &d2);
+    }
+    {
+      dim3 g = vgrid(n);
+      hipLaunchKernelGGL(bicg_xr_dots_kernel, g, dim3(256), 0, st, x, K->r.p, yy, zz, K->s.p, tt, K->c.p, sc, rs, n, nd,
+                         ctx->partials.p, ctx->partial_stride);
+      k_final_reduce(ctx, (int)g.x, 2, rn, false);  // (rho_next, ||r||^2) -> the other pair
+      comm_allreduce_dev(ctx, sc + rn, 2, 0);
+    }
+    hipLaunchKernelGGL(bicg_p_kernel, vgrid(n), dim3(256), 0, st, K->p.p, K->r.p, vv, sc, rs, rn, n);
+    double h[8];
+    read_scalars(ctx, 0, 8, h);
     const double rho_cur = h[rs], cv = h[S_CV];
     const double alpha = rho_cur / cv;
-    rnorm = std::sqrt(h[S_RR]);
+    rnorm = std::sqrt(h[rn + 1]);
     if (hist && it < hist_cap) hist[it] = rnorm;
     solved = rnorm <= eps;
     if (alpha == 0.0 || alpha != alpha) status = 2;
-    rs ^= 1;
+    rs = rn;
   }
   if (solved) status = 0;
   else if (status == 0 && it >= itmax) status = 1;
