@@ -35,6 +35,8 @@ struct jh_ilu_s {
   int64_t nparts = 1, max_block_rows = 0, max_levels = 0;
   int threads = 256;
   int lanes_per_block = 64;  // < 64: several blocks share one wavefront (grouped apply kernel)
+  int max_blk_l = 0, max_blk_u = 0;  // largest per-block strict-L / strict-U entry counts (LDS factor kernel)
+  size_t factor_lds_bytes = 0;       // 0: block does not fit -> global-memory factor kernels
   size_t lds_bytes = 0;
   // symbolic data (host)
   std::vector<int32_t> rowmap;            // ilu row -> device row of A
@@ -182,6 +184,105 @@ __global__ void ilu_invert_kernel(double *dinv, int64_t n) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   blk_store<BS>(dinv + (size_t)i * BS * BS, blk_inv<BS>(blk_load<BS>(dinv + (size_t)i * BS * BS)));
+}
+
+// LDS-resident numeric factorisation: the whole block (values gathered straight from A through the maps, plus
+// 16-bit block-local metadata) is staged in LDS, factorised level by level there (every hop of the dependent
+// lookup chain l_col -> upos -> u_ptr -> u_col -> u_val costs an LDS access instead of an L2/HBM access), and
+// written back once, coalesced.  Same IKJ arithmetic as factor_row above.
+template <int BS>
+__device__ __forceinline__ void factor_row_lds(int lt, double *lv, double *uv, double *dv, const uint16_t *lc, const uint16_t *uc,
+                                               const uint16_t *lp, const uint16_t *up, const uint16_t *upos) {
+  constexpr int BB = BS * BS;
+  const int ipos = upos[lt];
+  const int ls = lp[lt], le = lp[lt + 1];
+  if (ls == le) return;
+  const int us = up[ipos], ue = up[ipos + 1];
+  Blk<BS> dii = blk_load<BS>(dv + (size_t)ipos * BB);
+  for (int p = ls; p < le; ++p) {
+    const int k = lc[p];
+    const int kpos = upos[k];
+    const Blk<BS> lik = blk_mul<BS>(blk_load<BS>(lv + (size_t)p * BB), blk_inv<BS>(blk_load<BS>(dv + (size_t)kpos * BB)));
+    blk_store<BS>(lv + (size_t)p * BB, lik);
+    if (!blk_nonzero<BS>(lik)) continue;
+    const int ks = up[kpos], ke = up[kpos + 1];
+    for (int p2 = p + 1; p2 < le; ++p2) {
+      const int j = lc[p2];
+      for (int q = ks; q < ke; ++q)
+        if (uc[q] == j) {
+          Blk<BS> v = blk_load<BS>(lv + (size_t)p2 * BB);
+          blk_sub<BS>(v, blk_mul<BS>(lik, blk_load<BS>(uv + (size_t)q * BB)));
+          blk_store<BS>(lv + (size_t)p2 * BB, v);
+          break;
+        }
+    }
+    for (int q = ks; q < ke; ++q)
+      if (uc[q] == lt) { blk_sub<BS>(dii, blk_mul<BS>(lik, blk_load<BS>(uv + (size_t)q * BB))); break; }
+    for (int qi = us; qi < ue; ++qi) {
+      const int j = uc[qi];
+      for (int q = ks; q < ke; ++q)
+        if (uc[q] == j) {
+          Blk<BS> v = blk_load<BS>(uv + (size_t)qi * BB);
+          blk_sub<BS>(v, blk_mul<BS>(lik, blk_load<BS>(uv + (size_t)q * BB)));
+          blk_store<BS>(uv + (size_t)qi * BB, v);
+          break;
+        }
+    }
+  }
+  blk_store<BS>(dv + (size_t)ipos * BB, dii);
+}
+
+template <int BS>
+__global__ void ilu_factor_lds_kernel(IluDev F, const double *__restrict__ aval, int maxnl, int maxnu, int maxnr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BB = BS * BS;
+  double *lv = reinterpret_cast<double *>(smem);
+  double *uv = lv + (size_t)maxnl * BB;
+  double *dv = uv + (size_t)maxnu * BB;
+  uint16_t *lc = reinterpret_cast<uint16_t *>(dv + (size_t)maxnr * BB);
+  uint16_t *uc = lc + maxnl;
+  uint16_t *lp = uc + maxnu;
+  uint16_t *up = lp + (maxnr + 1);
+  uint16_t *upos = up + (maxnr + 1);
+  const int b = blockIdx.x;
+  const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
+  const int nr = b1 - b0;
+  const int l0 = F.l_ptr[b0], nl = F.l_ptr[b1] - l0;
+  const int u0 = F.u_ptr[b0], nu = F.u_ptr[b1] - u0;
+  const int T = blockDim.x, tid = threadIdx.x;
+  for (int j = tid; j < nl; j += T) {
+    lc[j] = (uint16_t)F.l_col[l0 + j];
+    const double *src = aval + (size_t)F.l_map[l0 + j] * BB;
+#pragma unroll
+    for (int e = 0; e < BB; ++e) lv[(size_t)j * BB + e] = src[e];
+  }
+  for (int j = tid; j < nu; j += T) {
+    uc[j] = (uint16_t)F.u_col[u0 + j];
+    const double *src = aval + (size_t)F.u_map[u0 + j] * BB;
+#pragma unroll
+    for (int e = 0; e < BB; ++e) uv[(size_t)j * BB + e] = src[e];
+  }
+  for (int t = tid; t <= nr; t += T) {
+    lp[t] = (uint16_t)(F.l_ptr[b0 + t] - l0);
+    up[t] = (uint16_t)(F.u_ptr[b0 + t] - u0);
+    if (t < nr) {
+      upos[t] = (uint16_t)(F.upos_of[b0 + t] - b0);
+      const double *src = aval + (size_t)F.d_map[b0 + t] * BB;
+#pragma unroll
+      for (int e = 0; e < BB; ++e) dv[(size_t)t * BB + e] = src[e];
+    }
+  }
+  __syncthreads();
+  const int lev0 = F.flev_off[b], lev1 = F.flev_off[b + 1] - 1;
+  for (int lev = lev0 + 1; lev < lev1; ++lev) {
+    const int s = F.flev_ptr[lev], e = F.flev_ptr[lev + 1];
+    for (int t = s + tid; t < e; t += T) factor_row_lds<BS>(t - b0, lv, uv, dv, lc, uc, lp, up, upos);
+    __syncthreads();
+  }
+  for (int j = tid; j < nl * BB; j += T) F.l_val[(size_t)l0 * BB + j] = lv[j];
+  for (int j = tid; j < nu * BB; j += T) F.u_val[(size_t)u0 * BB + j] = uv[j];
+  for (int t = tid; t < nr; t += T)
+    blk_store<BS>(F.dinv + (size_t)(b0 + t) * BB, blk_inv<BS>(blk_load<BS>(dv + (size_t)t * BB)));
 }
 
 // LDS mode: one workgroup per block, levels separated by __syncthreads()
@@ -771,6 +872,21 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         if (part[P.col[k]] == part[i]) { M->u_col.push_back(ilu_of[P.col[k]] - b0); M->u_map.push_back(k); }
       M->u_ptr[pos + 1] = (int32_t)M->u_col.size();
     }
+    if (lds) {
+      int64_t mxl = 0, mxu = 0;
+      for (int64_t b = 0; b < nb; ++b) {
+        mxl = std::max<int64_t>(mxl, M->l_ptr[M->blk_ptr[b + 1]] - M->l_ptr[M->blk_ptr[b]]);
+        mxu = std::max<int64_t>(mxu, M->u_ptr[M->blk_ptr[b + 1]] - M->u_ptr[M->blk_ptr[b]]);
+      }
+      const size_t bbv = (size_t)P.bs * P.bs;
+      size_t bytes = sizeof(double) * bbv * (size_t)(mxl + mxu + maxrows) + sizeof(uint16_t) * (size_t)(mxl + mxu + 3 * maxrows + 2);
+      bytes = (bytes + 15) & ~(size_t)15;
+      if (mxl < 65536 && mxu < 65536 && maxrows < 65536 && bytes <= LDS_CAP_BYTES && !getenv("JH_ILU_FACTOR_GLOBAL")) {
+        M->max_blk_l = (int)mxl;
+        M->max_blk_u = (int)mxu;
+        M->factor_lds_bytes = bytes;
+      }
+    }
     M->l_lev.resize(n);
     M->u_lev.resize(n);
     for (int64_t t = 0; t < n; ++t) M->l_lev[t] = flev[order[t]];
@@ -837,6 +953,20 @@ void ilu_factor(jh_ilu M) {
   hipStream_t s = ctx->stream;
   const int bb = M->bs * M->bs;
   const double *aval = M->A->val.p;
+  if (M->lds_mode && M->factor_lds_bytes) {
+    IluDev F = dev_view(M);
+    const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
+    const int mr = (int)M->max_block_rows;
+    // the bulk load/store phases want many lanes (memory-level parallelism); the level loop only needs a few
+    static const int fthreads = getenv("JH_ILU_FACTOR_THREADS") ? atoi(getenv("JH_ILU_FACTOR_THREADS")) : 256;
+    switch (M->bs) {
+      case 1: hipLaunchKernelGGL(ilu_factor_lds_kernel<1>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr); break;
+      case 2: hipLaunchKernelGGL(ilu_factor_lds_kernel<2>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr); break;
+      case 3: hipLaunchKernelGGL(ilu_factor_lds_kernel<3>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr); break;
+    }
+    M->factored = true;
+    return;
+  }
   auto grid_for = [](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096))); };
   if (!M->l_col.empty())
     hipLaunchKernelGGL(ilu_load_kernel, grid_for((int64_t)M->l_col.size() * bb), dim3(256), 0, s, M->l_val.p, aval, M->d_l_map.p, (int64_t)M->l_col.size(), bb);

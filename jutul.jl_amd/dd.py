@@ -22,6 +22,76 @@ def compress_partition(p):
     return np.searchsorted(up, p).astype(np.int64) + 1
 
 
+def load_balanced_endpoint(block_index, nvals, nblocks):
+    """load_balanced_endpoint (partitioning.jl:315-323)."""
+    width, remainder = divmod(nvals, nblocks)
+    return min(min(block_index, remainder) + width * block_index, nvals)
+
+
+def load_balanced_interval(b, n, m):
+    """load_balanced_interval (partitioning.jl:330-334): 1-based inclusive (start, stop) of block b in 1..m."""
+    return load_balanced_endpoint(b - 1, n, m) + 1, load_balanced_endpoint(b, n, m)
+
+
+def cartesian_partition(pts, dims):
+    """cartesian_partition(pts, dim) (partitioning.jl:184-236): bin points into a coarse Cartesian lattice over their
+    bounding box; pts is [ndim, npts]; dims one int or one per dimension.  Degenerate dimensions are skipped exactly
+    like the reference (their row of the index matrix stays 0), the result is compressed to 1..k."""
+    pts = np.asarray(pts, dtype=np.float64)
+    ndim, npts = pts.shape
+    dims = [int(dims)] * ndim if np.isscalar(dims) else [int(d) for d in dims]
+    if len(dims) != ndim:
+        raise ValueError("Second argument must be one value or one per dimension (=number of rows in pts)")
+    prow = np.zeros((ndim, npts), dtype=np.int64)
+    for d in range(ndim):
+        x = pts[d]
+        x0, x1 = x.min(), x.max()
+        if np.isclose(x0, x1):
+            continue
+        dx = (x1 - x0) / dims[d]
+        prow[d] = np.clip(np.ceil((x - x0) / dx), 1, dims[d]).astype(np.int64)
+    p = np.zeros(npts, dtype=np.int64)
+    for d in range(ndim):
+        p += prow[d] * int(np.prod(dims[:d]))
+    return compress_partition(p)
+
+
+def process_partition(N, partition, weights=None):
+    """process_partition (partitioning.jl:128-160): split every coarse block into its connected components; the first
+    component (the one containing the block's lowest cell) keeps the id, the others get max+1, max+2, ...
+    Faces whose weight is ~0 do not connect."""
+    N = np.asarray(N, dtype=np.int64)
+    part = np.asarray(partition, dtype=np.int64)
+    new_p = part.copy()
+    max_p = int(part.max())
+    l, r = N[0] - 1, N[1] - 1
+    ok = np.ones(l.size, dtype=bool) if weights is None else ~np.isclose(np.asarray(weights, dtype=np.float64), 0.0)
+    same = ok & (part[l] == part[r])
+    # union-find over the kept faces
+    parent = np.arange(part.size)
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    for a, b in zip(l[same], r[same]):
+        ra, rb = find(a), find(b)
+        if ra != rb:
+            parent[max(ra, rb)] = min(ra, rb)  # root = lowest cell: components ordered by their first vertex
+    roots = np.array([find(i) for i in range(part.size)])
+    for coarse in range(1, int(part.max()) + 1):
+        cells = np.flatnonzero(part == coarse)
+        if cells.size == 0:
+            continue
+        comp_roots = np.unique(roots[cells])  # ascending = order of each component's first cell
+        for cr in comp_roots[1:]:
+            max_p += 1
+            new_p[cells[roots[cells] == cr]] = max_p
+    return new_p
+
+
 def partition_rcb(centroids, nparts):
     """Recursive coordinate bisection into `nparts` (any integer) compact parts; 1-based part ids.
     Build-side stand-in for MetisPartitioner (partitioning.jl:29-51; Metis.jl is an un-vendored C library):

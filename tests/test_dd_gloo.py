@@ -174,3 +174,33 @@ def test_partition_and_subdomain_properties(oracle):
             for s, snd, rcv in zip(sub["neighbors"], sub["send"], sub["recv"]):
                 assert np.all(p[gl[rcv - 1] - 1] == s + 1) and np.all(snd <= sub["n_owned"]) and np.all(rcv > sub["n_owned"])
         assert owned_total == nc
+
+
+def test_partition_helper_kats():
+    """Known answers of the reference's partition helpers (test/partitioning.jl:55-70, test/utils.jl:10-30)."""
+    import jutul_amd as ja
+    from jutul_amd import dd
+    N5 = ja.cartesian_neighbors((5,))
+    assert list(dd.process_partition(N5, [1, 1, 2, 1, 1])) == [1, 1, 2, 3, 3]          # test/partitioning.jl:60-61
+    p = np.array([1, 1, 2, 3, 3])
+    out = dd.process_partition(N5, p)
+    assert list(out) == [1, 1, 2, 3, 3] and out is not p                                # :62-64 (copy)
+    assert list(dd.process_partition(N5, p, weights=[1.0, 1.0, 1.0, 0.0])) == [1, 1, 2, 3, 4]  # :66-67
+    for n in range(1, 60):                                                              # test/utils.jl:10-30
+        for m in range(1, n + 1):
+            assert dd.load_balanced_endpoint(0, n, m) == 0 and dd.load_balanced_endpoint(m, n, m) == n
+            count = 0
+            for i in range(1, m + 1):
+                a, b = dd.load_balanced_interval(i, n, m)
+                delta = b - a + 1
+                assert delta in (n // m, -(-n // m)) and delta > 0
+                count += delta
+            assert count == n
+    # cartesian_partition (partitioning.jl:184-236): 4x4 cell centroids into 2x2 coarse blocks
+    x, y = np.meshgrid(np.arange(4) + 0.5, np.arange(4) + 0.5, indexing="xy")
+    pts = np.stack([x.reshape(-1), y.reshape(-1)])
+    pc = dd.cartesian_partition(pts, (2, 2))
+    assert list(pc) == [1, 1, 2, 2, 1, 1, 2, 2, 3, 3, 4, 4, 3, 3, 4, 4]
+    assert list(dd.cartesian_partition(pts, 4)) == list(range(1, 17))
+    flat = np.stack([x.reshape(-1), np.zeros(16)])                                       # degenerate dimension skipped
+    assert dd.cartesian_partition(flat, (2, 3)).max() == 2
