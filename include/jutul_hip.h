@@ -72,6 +72,16 @@ int32_t jh_tpfa_get_pattern(jh_tpfa d, int64_t *rowptr, int64_t *colidx);
 /* jacobian_positions (conservation.jl:143-216, equations.jl:95-113): pos_acc [N*N, nc], pos_flux [N*N, nhf],
  * partial index fastest ((e-1)*np + d), BlockMajorLayout flat index into jac_buffer (1-based). */
 int32_t jh_tpfa_get_positions(jh_tpfa d, int64_t *pos_acc, int64_t *pos_flux);
+/* JutulMatrixLayout (core_types.jl:101-165).  The device always stores N x N blocks (BlockMajorLayout); the scalar
+ * layouts are provided at the boundary: EquationMajor row(cell,e) = (e-1)*nc + cell, EntityMajor row = N*(cell-1) + e
+ * (alignment_linear_index, equations.jl:132-138), scalar CSR with ascending columns (models.jl:585-611). */
+#define JH_LAYOUT_EQUATION_MAJOR 0
+#define JH_LAYOUT_ENTITY_MAJOR 1
+#define JH_LAYOUT_BLOCK_MAJOR 2
+/* scalar pattern of a layout: rowptr[nc*N + 1], colidx[nnzb*N*N] (block layout: the block pattern) */
+int32_t jh_tpfa_get_pattern_layout(jh_tpfa d, int32_t layout, int64_t *rowptr, int64_t *colidx);
+/* jacobian_positions for a layout (find_jac_position, equations.jl:4-117): same shapes as jh_tpfa_get_positions */
+int32_t jh_tpfa_get_positions_layout(jh_tpfa d, int32_t layout, int64_t *pos_acc, int64_t *pos_flux);
 /* device cell order: perm[i] = host cell (1-based) stored at device position i; block_ptr (nblocks+1,
  * 0-based device rows) of the contiguous blocks.  Pass NULL to skip an output. */
 int32_t jh_tpfa_get_ordering(jh_tpfa d, int64_t *perm, int64_t *nblocks, int64_t *block_ptr, int64_t block_ptr_cap);
@@ -102,6 +112,13 @@ int32_t jh_csr_sizes(jh_csr A, int64_t *n, int64_t *nnzb, int32_t *bs);
 /* nonzeros(A) in the HOST pattern order (flat jac_buffer: block k, entry (e,d) at (k-1)N^2 + N(d-1) + e) */
 int32_t jh_csr_set_values(jh_csr A, const double *nz);
 int32_t jh_csr_get_values(jh_csr A, double *nz);
+/* nonzeros(A) of the scalar CSR a layout would build (same values, that layout's slot order) */
+int32_t jh_csr_get_values_layout(jh_csr A, int32_t layout, double *nz);
+int32_t jh_csr_set_values_layout(jh_csr A, int32_t layout, const double *nz);
+/* vectors in a layout's order: equation-major x[(e-1)*nc + cell], entity/block-major x[N*(cell-1) + e]
+ * (views at models.jl:1105-1172, utils.jl:65-85) */
+int32_t jh_vec_upload_layout(jh_vec v, int32_t layout, const double *host);
+int32_t jh_vec_download_layout(jh_vec v, int32_t layout, double *host);
 /* mul!(y, A, x, alpha, beta) (StaticCSR/mat.jl:24-39; block: linsolve/block_cpu.jl:1-17) */
 int32_t jh_spmv(jh_csr A, jh_vec x, jh_vec y, double alpha, double beta);
 /* unit_diagonalize!(r, J, n_self) (ext/JutulPartitionedArraysExt/linalg.jl:18-35): rows of ghost cells -> -I,

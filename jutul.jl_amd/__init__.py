@@ -22,6 +22,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import JutulHIPError, NewtonReport, check, f64, i64, pf, pi, pi32
+from .discretization import compute_face_gdz, compute_face_trans, compute_half_face_trans, half_face_map  # noqa: F401
 from .meshgen import cartesian_neighbors, tet_lattice_mesh  # noqa: F401
 
 __all__ = ["HIPContext", "LocalCommGroup", "TwoPointPotentialFlowHardCoded", "DeviceVector", "StaticSparsityMatrixCSR", "ConservationLaw",
@@ -29,6 +30,7 @@ __all__ = ["HIPContext", "LocalCommGroup", "TwoPointPotentialFlowHardCoded", "De
            "Simulator", "JutulHIPError", "mul_", "ilu0_csr", "ldiv_", "tet_lattice_mesh", "cartesian_neighbors"]
 
 REORDER = {"none": 0, "blocks": 1}
+LAYOUT = {"equation_major": 0, "entity_major": 1, "block_major": 2}  # JutulMatrixLayout (core_types.jl:101-165)
 LAW = {"poisson": 0, "compressible": 1, "twophase": 2}
 SIDE = {"none": 0, "left": 1, "right": 2}
 
@@ -157,6 +159,21 @@ class TwoPointPotentialFlowHardCoded(_Handle):
         check(_L().jh_tpfa_get_positions(self.h, pi(pa), pi(pfl)))
         return pa.reshape(self.nc, nn).T.copy(), pfl.reshape(self.nhf, nn).T.copy()
 
+    def pattern_layout(self, layout):
+        """Scalar CSR pattern a JutulMatrixLayout would build (models.jl:585-611, equations.jl:349-392)."""
+        nn = 1 if layout == "block_major" else self.block_n
+        rowptr = np.zeros(self.nc * nn + 1, dtype=np.int64)
+        colidx = np.zeros(self.nnzb * nn * nn, dtype=np.int64)
+        check(_L().jh_tpfa_get_pattern_layout(self.h, LAYOUT[layout], pi(rowptr), pi(colidx)))
+        return rowptr, colidx
+
+    def jacobian_positions_layout(self, layout):
+        nn = self.block_n ** 2
+        pa = np.zeros(nn * self.nc, dtype=np.int64)
+        pfl = np.zeros(nn * self.nhf, dtype=np.int64)
+        check(_L().jh_tpfa_get_positions_layout(self.h, LAYOUT[layout], pi(pa), pi(pfl)))
+        return pa.reshape(self.nc, nn).T.copy(), pfl.reshape(self.nhf, nn).T.copy()
+
     def ordering(self):
         perm = np.zeros(self.nc, dtype=np.int64)
         nb = C.c_int64()
@@ -209,6 +226,17 @@ class DeviceVector(_Handle):
         check(_L().jh_vec_download(self.h, pf(out)))
         return out
 
+    def upload_layout(self, values, layout):
+        v = f64(np.asarray(values).reshape(-1))
+        assert v.size == self.n
+        check(_L().jh_vec_upload_layout(self.h, LAYOUT[layout], pf(v)))
+        return self
+
+    def download_layout(self, layout):
+        out = np.zeros(self.n)
+        check(_L().jh_vec_download_layout(self.h, LAYOUT[layout], pf(out)))
+        return out
+
     def fill(self, v):
         check(_L().jh_vec_fill(self.h, float(v)))
         return self
@@ -259,6 +287,16 @@ class StaticSparsityMatrixCSR(_Handle):
         v = f64(np.asarray(values).reshape(-1))
         assert v.size == self.nnzb * self.bs * self.bs
         check(_L().jh_csr_set_values(self.h, pf(v)))
+
+    def nzval_layout(self, layout):
+        out = np.zeros(self.nnzb * self.bs * self.bs)
+        check(_L().jh_csr_get_values_layout(self.h, LAYOUT[layout], pf(out)))
+        return out
+
+    def set_nzval_layout(self, values, layout):
+        v = f64(np.asarray(values).reshape(-1))
+        assert v.size == self.nnzb * self.bs * self.bs
+        check(_L().jh_csr_set_values_layout(self.h, LAYOUT[layout], pf(v)))
 
     def new_vector(self, values=None):
         return DeviceVector(self.disc if self.disc is not None else self, values)

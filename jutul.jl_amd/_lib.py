@@ -41,6 +41,8 @@ SIGNATURES = {
     "jh_tpfa_get_conn": [H, I64P, I64P, I64P, I64P, I64P],
     "jh_tpfa_get_pattern": [H, I64P, I64P],
     "jh_tpfa_get_positions": [H, I64P, I64P],
+    "jh_tpfa_get_pattern_layout": [H, C.c_int32, I64P, I64P],
+    "jh_tpfa_get_positions_layout": [H, C.c_int32, I64P, I64P],
     "jh_tpfa_get_ordering": [H, I64P, I64P, I64P, C.c_int64],
     "jh_vec_create": [H, C.POINTER(H)],
     "jh_vec_create_for": [H, C.POINTER(H)],
@@ -59,6 +61,10 @@ SIGNATURES = {
     "jh_csr_sizes": [H, I64P, I64P, I32P],
     "jh_csr_set_values": [H, F64P],
     "jh_csr_get_values": [H, F64P],
+    "jh_csr_get_values_layout": [H, C.c_int32, F64P],
+    "jh_csr_set_values_layout": [H, C.c_int32, F64P],
+    "jh_vec_upload_layout": [H, C.c_int32, F64P],
+    "jh_vec_download_layout": [H, C.c_int32, F64P],
     "jh_spmv": [H, H, H, C.c_double, C.c_double],
     "jh_unit_diagonalize": [H, H, C.c_int64],
     "jh_law_create": [H, C.c_int32, F64P, C.POINTER(H)],

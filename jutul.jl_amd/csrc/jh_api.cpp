@@ -9,6 +9,16 @@ void halo_exchange(jh_tpfa d, double *v, int bs);
 }
 using namespace jh;
 
+namespace {
+inline void check(int32_t rc) {  // nested C-ABI call failed: the message is already in the thread-local slot
+  if (rc != 0) {
+    char buf[2048];
+    jh_last_error(buf, sizeof(buf));
+    JH_THROW(std::string(buf));
+  }
+}
+}  // namespace
+
 // ---- context --------------------------------------------------------------------------------------------------
 extern "C" int32_t jh_context_create(int32_t device_id, jh_context *out) {
   return guard([&] {
@@ -431,5 +441,138 @@ extern "C" int32_t jh_halo_exchange_state(jh_law L) {
     if (!L) JH_THROW("null argument");
     JH_HIP(hipSetDevice(L->ctx->device));
     halo_exchange(L->disc, L->X.p, L->N);
+  });
+}
+
+// ---- scalar matrix layouts at the boundary (a-3/a-4) -------------------------------------------------------------------
+namespace {
+// 0-based scalar slot of entry (e, d) of the k-th block (of `len`) in block row i; rp = 0-based block rowptr of row i
+inline int64_t scalar_slot(int layout, int64_t nnzb, int N, int64_t rp, int64_t len, int64_t k, int e, int d) {
+  if (layout == JH_LAYOUT_EQUATION_MAJOR) return (int64_t)e * (nnzb * N) + (int64_t)N * rp + (int64_t)d * len + k;
+  return (int64_t)N * N * rp + (int64_t)e * (len * N) + k * N + d;  // entity major
+}
+void check_layout(int layout) {
+  if (layout < 0 || layout > 2) JH_THROW("unknown matrix layout");
+}
+// host rowptr (0-based) of a matrix: from the discretisation's reference tables or, for raw patterns, the pattern itself
+std::vector<int64_t> host_block_rowptr(jh_csr A) {
+  const Pattern &P = *A->pat;
+  std::vector<int64_t> rp(P.n + 1);
+  if (A->disc) {
+    A->disc->build_tables();
+    for (int64_t i = 0; i <= P.n; ++i) rp[i] = A->disc->h_rowptr[i] - 1;
+  } else {
+    for (int64_t i = 0; i <= P.n; ++i) rp[i] = P.rowptr[i];
+  }
+  return rp;
+}
+}  // namespace
+
+extern "C" int32_t jh_tpfa_get_pattern_layout(jh_tpfa d, int32_t layout, int64_t *rowptr, int64_t *colidx) {
+  return guard([&] {
+    if (!d) JH_THROW("null handle");
+    check_layout(layout);
+    if (layout == JH_LAYOUT_BLOCK_MAJOR || d->N == 1) { check(jh_tpfa_get_pattern(d, rowptr, colidx)); return; }
+    d->build_tables();
+    const int N = d->N;
+    const int64_t nc = d->nc, nnzb = d->nnzb;
+    for (int64_t i = 0; i < nc; ++i) {
+      const int64_t rp = d->h_rowptr[i] - 1, len = d->h_rowptr[i + 1] - d->h_rowptr[i];
+      for (int e = 0; e < N; ++e) {
+        const int64_t row = (layout == JH_LAYOUT_EQUATION_MAJOR) ? (int64_t)e * nc + i : (int64_t)N * i + e;
+        const int64_t start = scalar_slot(layout, nnzb, N, rp, len, 0, e, 0);
+        if (rowptr) { rowptr[row] = start + 1; rowptr[row + 1] = start + len * N + 1; }
+        if (colidx)
+          for (int64_t k = 0; k < len; ++k)
+            for (int dd = 0; dd < N; ++dd) {
+              const int64_t j = d->h_colidx[rp + k] - 1;
+              const int64_t col = (layout == JH_LAYOUT_EQUATION_MAJOR) ? (int64_t)dd * nc + j : (int64_t)N * j + dd;
+              colidx[scalar_slot(layout, nnzb, N, rp, len, k, e, dd)] = col + 1;
+            }
+      }
+    }
+  });
+}
+
+extern "C" int32_t jh_tpfa_get_positions_layout(jh_tpfa d, int32_t layout, int64_t *pos_acc, int64_t *pos_flux) {
+  return guard([&] {
+    if (!d) JH_THROW("null handle");
+    check_layout(layout);
+    if (layout == JH_LAYOUT_BLOCK_MAJOR || d->N == 1) { check(jh_tpfa_get_positions(d, pos_acc, pos_flux)); return; }
+    d->build_tables();
+    const int N = d->N;
+    const int64_t NN = (int64_t)N * N, nnzb = d->nnzb;
+    auto conv = [&](const std::vector<int64_t> &blk, int64_t count, int64_t *out, auto row_of) {
+      if (!out) return;
+      for (int64_t idx = 0; idx < count; ++idx) {
+        const int64_t i = row_of(idx);  // 0-based block row holding the entry
+        const int64_t rp = d->h_rowptr[i] - 1, len = d->h_rowptr[i + 1] - d->h_rowptr[i];
+        const int64_t p = (blk[NN * idx] - 1) / NN;  // host block slot (block-major position of (1,1))
+        for (int e = 0; e < N; ++e)
+          for (int dd = 0; dd < N; ++dd) out[NN * idx + (int64_t)e * N + dd] = scalar_slot(layout, nnzb, N, rp, len, p - rp, e, dd) + 1;
+      }
+    };
+    conv(d->pos_acc, d->nc, pos_acc, [&](int64_t c) { return c; });
+    conv(d->pos_flux, d->nhf, pos_flux, [&](int64_t k) { return d->hf_other[k] - 1; });  // entry (row = other, col = self)
+  });
+}
+
+static void values_layout(jh_csr A, int layout, double *nz, bool to_host) {
+  const Pattern &P = *A->pat;
+  const int N = P.bs;
+  const int64_t NN = (int64_t)N * N, nnzb = P.nnzb;
+  std::vector<double> blk((size_t)nnzb * NN);
+  std::vector<int64_t> rp = host_block_rowptr(A);
+  if (to_host) check(jh_csr_get_values(A, blk.data()));
+  for (int64_t i = 0; i < P.n; ++i) {
+    const int64_t len = rp[i + 1] - rp[i];
+    for (int64_t k = 0; k < len; ++k)
+      for (int e = 0; e < N; ++e)
+        for (int dd = 0; dd < N; ++dd) {
+          const int64_t s = scalar_slot(layout, nnzb, N, rp[i], len, k, e, dd);
+          const int64_t b = (rp[i] + k) * NN + (int64_t)dd * N + e;
+          if (to_host) nz[s] = blk[b]; else blk[b] = nz[s];
+        }
+  }
+  if (!to_host) check(jh_csr_set_values(A, blk.data()));
+}
+extern "C" int32_t jh_csr_get_values_layout(jh_csr A, int32_t layout, double *nz) {
+  return guard([&] {
+    if (!A || !nz) JH_THROW("null argument");
+    check_layout(layout);
+    if (layout == JH_LAYOUT_BLOCK_MAJOR || A->pat->bs == 1) { check(jh_csr_get_values(A, nz)); return; }
+    values_layout(A, layout, nz, true);
+  });
+}
+extern "C" int32_t jh_csr_set_values_layout(jh_csr A, int32_t layout, const double *nz) {
+  return guard([&] {
+    if (!A || !nz) JH_THROW("null argument");
+    check_layout(layout);
+    if (layout == JH_LAYOUT_BLOCK_MAJOR || A->pat->bs == 1) { check(jh_csr_set_values(A, nz)); return; }
+    values_layout(A, layout, const_cast<double *>(nz), false);
+  });
+}
+extern "C" int32_t jh_vec_upload_layout(jh_vec v, int32_t layout, const double *host) {
+  return guard([&] {
+    if (!v || !host) JH_THROW("null argument");
+    check_layout(layout);
+    if (layout != JH_LAYOUT_EQUATION_MAJOR || v->bs == 1) { check(jh_vec_upload(v, host)); return; }
+    const int64_t n = v->pat->n;
+    std::vector<double> tmp((size_t)v->len);
+    for (int64_t c = 0; c < n; ++c)
+      for (int e = 0; e < v->bs; ++e) tmp[c * v->bs + e] = host[(int64_t)e * n + c];
+    check(jh_vec_upload(v, tmp.data()));
+  });
+}
+extern "C" int32_t jh_vec_download_layout(jh_vec v, int32_t layout, double *host) {
+  return guard([&] {
+    if (!v || !host) JH_THROW("null argument");
+    check_layout(layout);
+    if (layout != JH_LAYOUT_EQUATION_MAJOR || v->bs == 1) { check(jh_vec_download(v, host)); return; }
+    const int64_t n = v->pat->n;
+    std::vector<double> tmp((size_t)v->len);
+    check(jh_vec_download(v, tmp.data()));
+    for (int64_t c = 0; c < n; ++c)
+      for (int e = 0; e < v->bs; ++e) host[(int64_t)e * n + c] = tmp[c * v->bs + e];
   });
 }

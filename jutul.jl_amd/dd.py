@@ -140,6 +140,33 @@ def remap_global_indices(p, nparts):
     return rem, counts
 
 
+def submap_cells(N, indices, nc=None, buffer=0, excluded=()):
+    """submap_cells(gmap, N, indices; buffer) (dd/subdomains.jl:77-182) without a parent map: the local cell list,
+    the kept faces and the boundary flags of a subdomain.  buffer = 0: cells = `indices` in the given order, faces
+    kept iff both cells are listed, nothing flagged (the mode the distributed path uses).  buffer = 1: every face of a
+    listed cell is kept, the neighbours are appended as boundary cells (cells come back ascending: `findall`)."""
+    assert buffer in (0, 1)
+    N = np.asarray(N, dtype=np.int64)
+    idx = np.asarray(indices, dtype=np.int64)
+    nc = int(N.max()) if nc is None else nc
+    inside = np.zeros(nc + 1, dtype=bool)
+    inside[idx] = True
+    l, r = N[0], N[1]
+    both = inside[l] & inside[r]
+    if buffer == 0:
+        return dict(cells=idx.copy(), faces=np.flatnonzero(both) + 1, is_boundary=np.zeros(idx.size, dtype=bool))
+    excl = np.zeros(nc + 1, dtype=bool)
+    excl[np.asarray(list(excluded), dtype=np.int64)] = True
+    touch_l = inside[l] & ~excl[r]   # face seen from listed cell l: other = r
+    touch_r = inside[r] & ~excl[l]
+    face_active = both | touch_l | touch_r
+    cell_active = inside.copy()
+    cell_active[r[touch_l]] = True
+    cell_active[l[touch_r]] = True
+    cells = np.flatnonzero(cell_active)
+    return dict(cells=cells, faces=np.flatnonzero(face_active) + 1, is_boundary=~inside[cells])
+
+
 def local_subdomain(N, p, rank):
     """Rank-local subdomain as PArraySimulator builds it (interface.jl:38-63 with submap_cells buffer = 0,
     dd/subdomains.jl:77-182): cells = [owned (findall order) ..., ghosts (ascending global id) ...]; faces kept iff

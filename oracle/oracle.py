@@ -438,3 +438,44 @@ class TPFASystem:
             apply_sources(acc, src_cells, src_values)
         return fill_conservation_eq(self.nc, self.nblk, self.hfm, acc, hf, self.pos_acc, self.pos_flux,
                                     self.nnzb * self.nblk * self.nblk)
+
+
+def submap_cells(N, indices, nc, buffer=0, excluded=()):
+    """Literal (loop) restatement of submap_cells (dd/subdomains.jl:77-182) without gmap / active_global."""
+    N = np.asarray(N, dtype=np.int64)
+    faces, facepos = get_facepos(N, nc)
+    nf = N.shape[1]
+    cell_active = np.zeros(nc + 1, dtype=bool)
+    cell_is_bnd = np.zeros(nc + 1, dtype=bool)
+    face_active = np.zeros(nf + 1, dtype=bool)
+    interior = np.zeros(nc + 1, dtype=bool)
+    interior[np.asarray(indices)] = True
+    for gc in indices:
+        pb = False
+        for fi in range(facepos[gc - 1], facepos[gc]):
+            face = faces[fi - 1]
+            l, r = N[0, face - 1], N[1, face - 1]
+            if interior[l] and interior[r]:
+                face_active[face] = True
+            else:
+                pb = True
+        cell_active[gc] = True
+        cell_is_bnd[gc] = pb and buffer == 0
+    if buffer > 0:
+        for gc in indices:
+            for fi in range(facepos[gc - 1], facepos[gc]):
+                face = faces[fi - 1]
+                l, r = N[0, face - 1], N[1, face - 1]
+                other = r if l == gc else l
+                if other in excluded:
+                    continue
+                face_active[face] = True
+                if not cell_active[other] and not interior[other]:
+                    cell_active[other] = True
+                    cell_is_bnd[other] = True
+        cells = np.flatnonzero(cell_active)
+        is_b = cell_is_bnd[cells]
+    else:
+        cells = np.asarray(indices, dtype=np.int64).copy()
+        is_b = np.zeros(cells.size, dtype=bool)
+    return dict(cells=cells, faces=np.flatnonzero(face_active), is_boundary=is_b)

@@ -204,3 +204,40 @@ def test_partition_helper_kats():
     assert list(dd.cartesian_partition(pts, 4)) == list(range(1, 17))
     flat = np.stack([x.reshape(-1), np.zeros(16)])                                       # degenerate dimension skipped
     assert dd.cartesian_partition(flat, (2, 3)).max() == 2
+
+
+def test_submap_cells_and_discretization_mirror(oracle):
+    """submap_cells (dd/subdomains.jl:77-182) buffer 0/1 vs the literal oracle restatement, the reference's
+    extract_submesh KAT (test/mesh.jl:181-185: cells 1:3 of a 2x2x2 mesh -> 3 cells / 2 faces), and the host-side
+    transmissibility helpers (finite-volume.jl:130-233,304-313) vs the C oracle."""
+    import jutul_amd as ja
+    from jutul_amd import dd
+    N = ja.cartesian_neighbors((2, 2, 2))
+    s0 = dd.submap_cells(N, [1, 2, 3], 8, buffer=0)
+    assert list(s0["cells"]) == [1, 2, 3] and len(s0["faces"]) == 2 and not s0["is_boundary"].any()
+    g = ja.tet_lattice_mesh(4, 3, 3)
+    nc = g["nc"]
+    rng = np.random.default_rng(0)
+    idx = np.sort(rng.choice(np.arange(1, nc + 1), 40, replace=False))
+    for buf in (0, 1):
+        a = dd.submap_cells(g["N"], idx, nc, buffer=buf)
+        b = oracle.submap_cells(g["N"], idx, nc, buffer=buf)
+        assert np.array_equal(a["cells"], b["cells"]) and np.array_equal(a["faces"], b["faces"])
+        assert np.array_equal(a["is_boundary"], b["is_boundary"])
+    a = dd.submap_cells(g["N"], idx, nc, buffer=1, excluded=[int(idx[0]) % nc + 1])
+    b = oracle.submap_cells(g["N"], idx, nc, buffer=1, excluded=[int(idx[0]) % nc + 1])
+    assert np.array_equal(a["cells"], b["cells"]) and np.array_equal(a["faces"], b["faces"])
+    # transmissibilities
+    perm = np.stack([g["perm_k"], 2 * g["perm_k"], 3 * g["perm_k"]])
+    Thf, hf = ja.compute_half_face_trans(g["cell_centroids"], g["face_centroids"], g["normals"], g["areas"], perm, g["N"])
+    oh = oracle.half_face_map(g["N"], nc)
+    for k in ("faces", "face_pos", "face_sign"):
+        assert np.array_equal(hf[k], oh[k])
+    assert np.array_equal(hf["cells"], oh["other"])
+    geo = dict(nc=nc, dim=3, cell_centroids=g["cell_centroids"], face_centroids=g["face_centroids"], normals=g["normals"],
+               areas=g["areas"])
+    Thf_o = oracle.half_face_trans(geo, perm, oh)
+    assert np.allclose(Thf, Thf_o, rtol=1e-13)
+    assert np.allclose(ja.compute_face_trans(Thf, hf["faces"], g["nf"]), oracle.face_trans(Thf_o, oh["faces"], g["nf"]), rtol=1e-13)
+    z = g["cell_centroids"][2]
+    assert np.array_equal(ja.compute_face_gdz(g["N"], z, 9.81), oracle.face_gdz(g["N"], z, 9.81))

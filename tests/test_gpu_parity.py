@@ -471,3 +471,37 @@ def test_medium_tet_mesh_end_to_end_properties(ja, ctx, oracle):
     xo, st = oracle.bicgstab(nc, 1, osys.rowptr, osys.colidx, nz_o, r_o, prec=Fo, rtol=1e-10, atol=1e-30, itmax=300)
     assert st["solved"]
     assert relerr(law.get_state() - U0, -xo) < 1e-5
+
+
+# ---- scalar matrix layouts at the boundary (a-3/a-4) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", ["equation_major", "entity_major"])
+def test_scalar_layouts_pattern_positions_values(ja, ctx, oracle, layout):
+    """EquationMajor / EntityMajor (equations.jl:132-138, models.jl:585-611): pattern + jacobian positions bit-exact
+    vs the oracle, Jacobian values and residual delivered in that layout == the oracle's fill through ITS positions."""
+    g, rng = tet_case(ja, (5, 4, 3), seed=21)
+    nc, N = g["nc"], 2
+    lay = oracle.LAYOUT[layout]
+    lsys, law, disc, osys, nz_blk, r_blk = assemble_both(ja, ctx, oracle, g, rng, "twophase", "blocks")
+    srp, sci = oracle.csr_pattern_scalar(nc, N, lay, osys.rowptr, osys.colidx)
+    rp, ci = disc.pattern_layout(layout)
+    assert np.array_equal(rp, srp) and np.array_equal(ci, sci)
+    opa, opf = oracle.align(nc, N, lay, osys.rowptr, osys.colidx, osys.hfm, srp, sci)
+    pa, pf = disc.jacobian_positions_layout(layout)
+    assert np.array_equal(pa, opa) and np.array_equal(pf, opf)
+    # values: scatter the block-major oracle Jacobian through both position tables and compare slot by slot
+    nz_scalar = np.zeros(nz_blk.size)
+    bpa, bpf = osys.pos_acc, osys.pos_flux
+    nz_scalar[opa.reshape(-1) - 1] = nz_blk[bpa.reshape(-1) - 1]
+    nz_scalar[opf.reshape(-1) - 1] = nz_blk[bpf.reshape(-1) - 1]
+    assert relerr(lsys.jac.nzval_layout(layout), nz_scalar) < RTOL
+    r_dev = lsys.r.download_layout(layout)
+    r_ref = r_blk.reshape(nc, N).T.reshape(-1) if layout == "equation_major" else r_blk
+    assert relerr(r_dev, r_ref) < RTOL
+    # round trip: set values / vectors in the layout, read back block-major
+    A2 = ja.StaticSparsityMatrixCSR(disc)
+    A2.set_nzval_layout(nz_scalar, layout)
+    assert relerr(A2.nzval, nz_blk) < 1e-15
+    v = ja.DeviceVector(disc).upload_layout(r_ref, layout)
+    assert np.array_equal(v.download(), r_blk)
+    # block layout passes through
+    assert np.array_equal(disc.pattern_layout("block_major")[1], osys.colidx)
