@@ -158,7 +158,7 @@ def main():
         k["frac_of_peak"] = k["gbs"] / HBM_PEAK_GBS
     dom = max(kern, key=lambda n: kern[n]["total_ms"])
     roofline = dict(bound="hbm", kernel=dom, achieved=round(kern[dom]["gbs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(kern[dom]["gbs"] / HBM_PEAK_GBS, 4), traffic=None,
+                    frac=round(kern[dom]["gbs"] / HBM_PEAK_GBS, 4), traffic=measured_traffic(dom, nc_g, world),
                     kernels={n: dict(avg_ms=round(k["ms"], 4), launches=k["launches"], algorithmic_bytes=int(k["bytes"]),
                                      gbs=round(k["gbs"], 1), frac=round(k["frac_of_peak"], 4),
                                      share_of_step=round(k["total_ms"] / (elapsed * 1e3), 4)) for n, k in kern.items()})
@@ -193,6 +193,23 @@ def main():
         ctx.comm_finalize()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(kernel, cells, world):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected separately on
+    this same command, FETCH doubled per the gfx950 correction; tools/pmc_summary.py -> profiles/r01_traffic_*.json).
+    PMC counters cannot be read from inside the benchmark, so the number is the committed measurement for the default
+    1-GPU 10M-cell workload and None for anything else."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_10M_1gpu.json")
+    if world != 1 or not os.path.exists(path) or abs(cells - 10_025_988) > 0:
+        return None
+    names = {"ilu0_apply": "ilu_apply_chunked_kernel<1>", "spmv": "spmv_tile_kernel<1, 1>", "assembly": "assemble_tile_kernel<0>"}
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return int(d[names[kernel]]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(args, nc_gpu):
