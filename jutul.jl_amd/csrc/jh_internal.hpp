@@ -217,6 +217,17 @@ void k_update_primary(jh_law L, const double *dx, double w, const double *limits
 
 }  // namespace jh
 
+namespace jh {
+// BiCGStab vector update fused into the gather phase of the ILU(0) apply (see ilu_apply_chunked_kernel)
+struct IluGather {
+  int mode = 0;             // 1: s = r - alpha*q ; 2: p = r + beta*(p - omega*q)
+  const double *r = nullptr, *q = nullptr;
+  double *out = nullptr;    // s (mode 1) or p (mode 2, read-modify-write)
+  const double *sc = nullptr;
+  int rho_slot = 0, rho_next_slot = 0, cv_slot = 0, ts_slot = 0;
+};
+}  // namespace jh
+
 // ---- ILU (jh_ilu.hip) -------------------------------------------------------------------------------------------------
 struct jh_ilu_s;
 // ---- Krylov (jh_krylov.hip) ---------------------------------------------------------------------------------------------

@@ -14,6 +14,8 @@
 
 namespace jh {
 void ilu_apply(jh_ilu M, const double *b, double *x);
+bool ilu_can_fuse_gather(jh_ilu M);
+void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x);
 void ilu_factor(jh_ilu M);
 void comm_allreduce_dev(jh_context ctx, double *p, int n, int op);
 void halo_exchange(jh_tpfa d, double *v, int bs);
@@ -202,11 +204,22 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   if (rho == 0.0 && !solved) status = 2;  // "Breakdown b'c = 0"
   int rs = S_PAIR0;                       // pair holding the current (rho, rr); the next one goes to the other pair
   ensure_partials(ctx, 4096);
+  // right preconditioning on one rank: the s- and p-updates are fused into the gather phase of the ILU(0) apply
+  const bool fuse = right && !dist && ilu_can_fuse_gather(M);
+  int prev_rs = -1, prev_rn = -1;         // scalar pairs of the previous iteration (deferred p-update)
   while (!solved && it < itmax && status == 0) {
     ++it;
     const int rn = (rs == S_PAIR0) ? S_PAIR1 : S_PAIR0;
     double *yy = K->p.p;
-    if (right) { prec(K->p.p, K->y.p); yy = K->y.p; }
+    if (fuse && prev_rs >= 0) {  // p = r + beta*(p - omega*q) of the previous iteration, then y = N^-1 p
+      IluGather G;
+      G.mode = 2; G.r = K->r.p; G.q = K->q.p; G.out = K->p.p; G.sc = sc;
+      G.rho_slot = prev_rs; G.rho_next_slot = prev_rn; G.cv_slot = S_CV; G.ts_slot = S_TS;
+      K->mark(1, st);
+      ilu_apply_fused(M, G, K->y.p);
+      K->mark(1, st);
+      yy = K->y.p;
+    } else if (right) { prec(K->p.p, K->y.p); yy = K->y.p; }
     double *vv = K->q.p;
     if (left) {
       spmv(yy, K->q.p, nullptr);
@@ -217,9 +230,19 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       SpmvDot d1{1, K->c.p, S_CV, rows_dot};  // <c, A y> fused into the SpMV epilogue
       spmv(yy, K->q.p, &d1);
     }
-    hipLaunchKernelGGL(bicg_s_kernel, vgrid(n), dim3(256), 0, st, K->s.p, K->r.p, vv, sc, rs, n);
     double *zz = K->s.p;
-    if (right) { prec(K->s.p, K->z.p); zz = K->z.p; }
+    if (fuse) {  // s = r - alpha*q fused into z = N^-1 s
+      IluGather G;
+      G.mode = 1; G.r = K->r.p; G.q = vv; G.out = K->s.p; G.sc = sc;
+      G.rho_slot = rs; G.cv_slot = S_CV;
+      K->mark(1, st);
+      ilu_apply_fused(M, G, K->z.p);
+      K->mark(1, st);
+      zz = K->z.p;
+    } else {
+      hipLaunchKernelGGL(bicg_s_kernel, vgrid(n), dim3(256), 0, st, K->s.p, K->r.p, vv, sc, rs, n);
+      if (right) { prec(K->s.p, K->z.p); zz = K->z.p; }
+    }
     double *tt = K->d.p;
     if (left) {
       spmv(zz, K->d.p, nullptr);
@@ -237,7 +260,8 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       k_final_reduce(ctx, (int)g.x, 2, rn, false);  // (rho_next, ||r||^2) -> the other pair
       comm_allreduce_dev(ctx, sc + rn, 2, 0);
     }
-    hipLaunchKernelGGL(bicg_p_kernel, vgrid(n), dim3(256), 0, st, K->p.p, K->r.p, vv, sc, rs, rn, n);
+    if (fuse) { prev_rs = rs; prev_rn = rn; }  // p-update deferred into the next iteration's first ILU apply
+    else hipLaunchKernelGGL(bicg_p_kernel, vgrid(n), dim3(256), 0, st, K->p.p, K->r.p, vv, sc, rs, rn, n);
     double h[8];
     read_scalars(ctx, 0, 8, h);
     const double rho_cur = h[rs], cv = h[S_CV];
