@@ -145,8 +145,12 @@ def main():
     asm_ms = float(np.mean([r.assembly_ms for r in reps]))
     kern = {}
     B_asm = 44.0 * n_loc + 20.0 * nhf_loc                      # SURVEY 8(d), N = 1
-    B_spmv = 12.0 * nnz_loc + 20.0 * n_loc
-    B_ilu = 12.0 * (info["l_entries"] + info["u_entries"]) + 32.0 * n_loc  # factor entries (val+col) + D + rowptrs + b,x
+    # SpMV 12*nnz + 20*n + 8*n for the vector of the fused dot epilogue (<c,q> or <t,s>,<t,t>) on one rank
+    fused = world == 1 and not force_dist
+    B_spmv = 12.0 * nnz_loc + 20.0 * n_loc + (8.0 * n_loc if fused else 0.0)
+    # ILU(0) apply: kept factor entries (val 8 + col 4) + D 8 + row pointers 8 + b 8 + x 8 per row; on one rank the
+    # BiCGStab s-/p-updates are fused into the gather: the input is rebuilt from r, q (and p) and stored: +20*n on average
+    B_ilu = 12.0 * (info["l_entries"] + info["u_entries"]) + 32.0 * n_loc + (20.0 * n_loc if fused else 0.0)
     kern["assembly"] = dict(ms=asm_ms, launches=len(reps), bytes=B_asm)
     if prof["spmv_count"]:
         kern["spmv"] = dict(ms=prof["spmv_ms"] / prof["spmv_count"], launches=prof["spmv_count"], bytes=B_spmv)

@@ -112,15 +112,26 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
     for (int j = rp[tid]; j < rp[tid + 1]; ++j) rowof[j] = (uint8_t)tid;
   __syncthreads();
   // ---- phase 1: one lane per CSR entry -------------------------------------------------------------------
-  for (int k = tid; k < cnt; k += TILE_THREADS) {
+  // The off-diagonal blocks stay in registers until phase 3 so that every nzval line of the tile is written once,
+  // full and coalesced (8-byte diagonal stores from the row lanes cost a 32-byte HBM write each: +0.32 GB at 10M
+  // cells, measured with WRITE_SIZE).
+  constexpr int KPT = TILE_NNZ / TILE_THREADS;  // entries per lane
+  double off[KPT][NN];
+  bool isdiag[KPT];
+#pragma unroll
+  for (int kk = 0; kk < KPT; ++kk) {
+    const int k = tid + kk * TILE_THREADS;
+    isdiag[kk] = false;
+    if (k >= cnt) continue;
     const int lr = rowof[k];
     const int c = col[base + k];
     const double T = Tnz[base + k];
-    if (c == r0 + lr) {  // diagonal slot: no flux; written by the row lane in phase 2
+    if (c == r0 + lr) {  // diagonal slot: no flux; its block is produced by the row lane in phase 2
 #pragma unroll
       for (int e = 0; e < N; ++e) qv[k * N + e] = 0.0;
 #pragma unroll
       for (int i = 0; i < NN; ++i) dsv[k * NN + i] = 0.0;
+      isdiag[kk] = true;
       continue;
     }
     if (KIND == JH_LAW_POISSON) {
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
       const double Uo = (c >= r0 && c < r1) ? xs[c - r0] : X[c];
       qv[k] = -(T * (Uo - Us));
       dsv[k] = T;
-      nz[base + k] = -T;
+      off[kk][0] = -T;
     } else if (KIND == JH_LAW_COMPRESSIBLE) {
       const double gz = gnz ? gnz[base + k] : 0.0;
       Dual<2> ps = dvar<2>(xs[lr], 0);
@@ -140,14 +151,13 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
       Dual<2> q = (T / par.mu[0]) * (ravg * dphi);
       qv[k] = q.v;
       dsv[k] = q.d[0];
-      nz[base + k] = q.d[1];
+      off[kk][0] = q.d[1];
     } else {
       const double gz = gnz ? gnz[base + k] : 0.0;
       const bool inl = (c >= r0 && c < r1);
       Dual<4> ps = dvar<4>(xs[lr * 2], 0), ss_w = dvar<4>(xs[lr * 2 + 1], 1);
       Dual<4> po = dvar<4>(inl ? xs[(c - r0) * 2] : X[(size_t)c * 2], 2);
       Dual<4> so_w = dvar<4>(inl ? xs[(c - r0) * 2 + 1] : X[(size_t)c * 2 + 1], 3);
-      double *blk = nz + (size_t)(base + k) * 4;
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph) {
         Dual<4> rs = density(par, ph, ps), ro = density(par, ph, po);
@@ -162,8 +172,8 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
         qv[k * 2 + ph] = q.v;
         dsv[k * 4 + 0 * 2 + ph] = q.d[0];  // (e=ph, d=0) column-major
         dsv[k * 4 + 1 * 2 + ph] = q.d[1];
-        blk[0 * 2 + ph] = q.d[2];
-        blk[1 * 2 + ph] = q.d[3];
+        off[kk][(0 * 2 + ph) % NN] = q.d[2];
+        off[kk][(1 * 2 + ph) % NN] = q.d[3];
       }
     }
   }
@@ -215,11 +225,20 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
     }
 #pragma unroll
     for (int e = 0; e < N; ++e) r[(size_t)row * N + e] = ar[e];
-    if (dk >= 0) {
-      double *blk = nz + (size_t)(base + dk) * NN;
+    if (dk >= 0) {  // park the diagonal block in its (otherwise unused) LDS slot for the coalesced store of phase 3
 #pragma unroll
-      for (int i = 0; i < NN; ++i) blk[i] = ap[i];
+      for (int i = 0; i < NN; ++i) dsv[dk * NN + i] = ap[i];
     }
+  }
+  __syncthreads();
+  // ---- phase 3: every lane stores its entries; nzval lines leave the CU complete ---------------------------------------
+#pragma unroll
+  for (int kk = 0; kk < KPT; ++kk) {
+    const int k = tid + kk * TILE_THREADS;
+    if (k >= cnt) continue;
+    double *blk = nz + (size_t)(base + k) * NN;
+#pragma unroll
+    for (int i = 0; i < NN; ++i) blk[i] = isdiag[kk] ? dsv[k * NN + i] : off[kk][i];
   }
 }
 

@@ -6,6 +6,8 @@
 // x[col], stages the products in LDS, and then one lane per row reduces its LDS row segment left->right (the
 // reference's accumulation order).  Tiles are mapped to XCDs in contiguous chunks so that each XCD's private
 // L2 only ever holds one window of x.  Bound: HBM; algorithmic bytes 12*nnz + 20*n.
+#include <cstdlib>
+
 #include "jh_internal.hpp"
 
 namespace jh {
@@ -231,14 +233,20 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
   __shared__ double prod[TILE_NNZ * BS];
   __shared__ int32_t rp[TILE_ROWS + 1];
   __shared__ double red[8];
-  const int t = xcd_tile(blockIdx.x, ntiles);
-  if (t >= ntiles) return;
+  const int tid = threadIdx.x;
+  double d0 = 0.0, d1 = 0.0;  // fused dot partials of this lane
+  // Persistent over tiles: workgroup b belongs to XCD b % 8 and walks that XCD's contiguous chunk of tiles with stride
+  // gridDim/8, so a fused dot product needs ONE block reduction and ONE partial per workgroup (<= 2048 partials).
+  const int chunk = (ntiles + NUM_XCD - 1) / NUM_XCD;
+  const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, wgs = gridDim.x / NUM_XCD;
+  for (int tl = wg; tl < chunk; tl += wgs) {
+  const int t = xcd * chunk + tl;
+  if (t >= ntiles) break;
+  if (tl != wg) __syncthreads();  // the previous tile's LDS contents are dead only once every lane is done with them
   const int r0 = tile_row[t], r1 = tile_row[t + 1];
   const int nrows = r1 - r0;
   const int base = rowptr[r0];
   const int cnt = rowptr[r1] - base;
-  const int tid = threadIdx.x;
-  double d0 = 0.0, d1 = 0.0;  // fused dot partials of this lane
   if (nrows == 1 && cnt > TILE_NNZ) {
     // long row: the whole workgroup strides over one row, then block-reduces
     double acc[BS];
@@ -268,8 +276,7 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
         if (DOT && r0 < dot_rows) { d0 += yv * dw[o]; if (DOT == 2) d1 += yv * yv; }
       }
     }
-    if (DOT && tid == 0) { part[t] = d0; if (DOT == 2) part[pstride + t] = d1; }
-    return;
+    continue;
   }
   for (int i = tid; i <= nrows; i += TILE_THREADS) rp[i] = rowptr[r0 + i] - base;
   for (int k = tid; k < cnt; k += TILE_THREADS) {
@@ -309,12 +316,14 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
       if (DOT && r0 + tid < dot_rows) { d0 += yv * dw[o]; if (DOT == 2) d1 += yv * yv; }
     }
   }
-  if (DOT) {  // one partial per tile (per-wavefront partials were measured slower: 4x longer final reduction)
+  }  // tile loop
+  if (DOT) {  // one partial per workgroup
+    __syncthreads();
     const double p0 = block_reduce<false>(d0, red);
-    if (tid == 0) part[t] = p0;
+    if (tid == 0) part[blockIdx.x] = p0;
     if (DOT == 2) {
       const double p1 = block_reduce<false>(d1, red);
-      if (tid == 0) part[pstride + t] = p1;
+      if (tid == 0) part[pstride + blockIdx.x] = p1;
     }
   }
 }
@@ -323,9 +332,11 @@ void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x
             const SpmvDot *dot) {
   if (P.n == 0) return;
   int chunk = (P.ntiles + NUM_XCD - 1) / NUM_XCD;
-  dim3 grid(chunk * NUM_XCD), block(TILE_THREADS);
+  static const int wg_per_xcd = getenv("JH_SPMV_WGS") ? atoi(getenv("JH_SPMV_WGS")) : 256;  // 32 CUs x 8 workgroups
   const int mode = dot ? dot->mode : 0;
-  if (mode) ensure_partials(ctx, (size_t)P.ntiles);
+  const int per_xcd = mode ? std::min(chunk, wg_per_xcd) : chunk;  // plain SpMV: one tile per workgroup
+  dim3 grid(per_xcd * NUM_XCD), block(TILE_THREADS);
+  if (mode) ensure_partials(ctx, (size_t)grid.x);
   const double *dw = dot ? dot->w : nullptr;
   const int drows = dot ? (int)dot->n_rows : 0;
   double *part = ctx->partials.p;
@@ -344,7 +355,7 @@ void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x
     default: JH_THROW("unsupported block size");
   }
 #undef JH_SPMV
-  if (mode) k_final_reduce(ctx, P.ntiles, mode == 2 ? 2 : 1, dot->slot, false);
+  if (mode) k_final_reduce(ctx, (int)grid.x, mode == 2 ? 2 : 1, dot->slot, false);
 }
 
 // unit_diagonalize!: ghost rows -> -I, r_ghost -> 0 (ext/JutulPartitionedArraysExt/linalg.jl:18-35)
