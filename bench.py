@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
+    # the contract is ONE JSON line on stdout: NCCL_DEBUG=VERSION (set in this image) makes RCCL print a banner there
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -140,9 +140,10 @@ static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block
       merged.push_back(block_ptr[i]);
   }
   block_ptr.swap(merged);
-  if (nc_all > nc) {
-    for (int64_t c = nc; c < nc_all; ++c) perm.push_back((int32_t)c);
-    block_ptr.push_back((int32_t)nc_all);
+  // ghost cells: their rows become -I (unit_diagonalize!), so any grouping works; keep the blocks LDS-sized
+  for (int64_t c = nc; c < nc_all; ++c) {
+    perm.push_back((int32_t)c);
+    if ((c - nc + 1) % block_rows == 0 || c + 1 == nc_all) block_ptr.push_back((int32_t)(c + 1));
   }
 }
 

@@ -154,3 +154,20 @@ def test_rccl_single_rank_communicator(ja):
     ok, its, rep = sim.solve_ministep(0.5)
     assert ok and its == 2
     ctx.comm_finalize()
+
+
+def test_ghost_cells_do_not_break_lds_blocks(ja):
+    """A rank-local subdomain with many ghosts must still get LDS-sized ILU blocks (ghost rows are -I rows)."""
+    from jutul_amd import dd
+    g, T, X0, _ = problem(ja, dims=(24, 20, 16))
+    part = dd.partition_rcb(g["cell_centroids"], 2)
+    ctx = ja.HIPContext(0)
+    disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, 0, T, g["volumes"], X0, block_rows=128)
+    assert sub["n_local"] - sub["n_owned"] > 500
+    perm, bp = disc.ordering()
+    assert np.diff(bp).max() <= 160
+    assert np.all(perm[sub["n_owned"]:] > sub["n_owned"])  # ghosts stay the last device rows
+    lsys = ja.LinearizedSystem(disc)
+    law.update_equation_and_linearized_system(0.5, lsys.jac, lsys.r)
+    prec = ja.ILUZeroPreconditioner(partition="blocks").update_preconditioner(lsys.jac)
+    assert prec.info()["lds_mode"]
