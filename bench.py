@@ -50,8 +50,10 @@ def main():
     args = ap.parse_args()
 
     # the contract is ONE JSON line on stdout: NCCL_DEBUG=VERSION (set in this image) makes RCCL print a banner there
+    # to stdout at exit, and any other level interleaves log lines with it -> banner off, logs to a file
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-        os.environ["NCCL_DEBUG"] = "WARN"
+        del os.environ["NCCL_DEBUG"]
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/jutul_hip_rccl_%h_%p.log")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
