@@ -34,19 +34,9 @@ struct jh_ilu_s {
   bool lds_mode = false;
   int64_t nparts = 1, max_block_rows = 0, max_levels = 0;
   int threads = 256;
-  int lanes_per_block = 64;  // < 64: several blocks share one wavefront (grouped apply kernel)
-  int max_blk_l = 0, max_blk_u = 0;  // largest per-block strict-L / strict-U entry counts (LDS factor kernel)
-  // packed metadata of the chunked apply kernel (LDS mode): per row one u32 (level << 16 | entry count), 16-bit block-local
-  // column ids, one entry offset per 64-row chunk -- 10 B instead of 20 B of row metadata, 10 B instead of 12 B per entry
-  bool packed = false;
-  std::vector<uint32_t> a_lmeta, a_umeta;
-  std::vector<uint16_t> a_lcol, a_ucol, a_urow;
-  std::vector<int32_t> a_chunk_ptr, a_lchunk, a_uchunk;
-  DevBuf<uint32_t> d_a_lmeta, d_a_umeta;
-  DevBuf<uint16_t> d_a_lcol, d_a_ucol, d_a_urow;
-  DevBuf<int32_t> d_a_chunk_ptr, d_a_lchunk, d_a_uchunk;
-  size_t factor_lds_bytes = 0;       // 0: block does not fit -> global-memory factor kernels
   size_t lds_bytes = 0;
+  int max_blk_l = 0, max_blk_u = 0;  // largest per-block strict-L / strict-U entry counts (LDS factor kernel)
+  size_t factor_lds_bytes = 0;       // 0: block does not fit -> global-memory factor kernels
   // symbolic data (host)
   std::vector<int32_t> rowmap;            // ilu row -> device row of A
   std::vector<int32_t> blk_ptr;           // execution blocks (LDS mode: partition blocks; GLOBAL: {0, n})
@@ -133,9 +123,6 @@ struct IluDev {
   const int32_t *rowmap, *blk_ptr, *flev_off, *flev_ptr, *blev_off, *blev_ptr;
   const int32_t *l_ptr, *l_col, *l_map, *u_ptr, *u_col, *u_map, *d_map, *u_row, *upos_of, *l_lev, *u_lev;
   double *l_val, *u_val, *dinv;
-  const uint32_t *a_lmeta, *a_umeta;
-  const uint16_t *a_lcol, *a_ucol, *a_urow;
-  const int32_t *a_chunk_ptr, *a_lchunk, *a_uchunk;
 };
 
 // ---- numeric factorisation of one row (ilu0_factor!, ilu0.jl:108-144) -----------------------------------------------
@@ -573,77 +560,6 @@ __global__ void ilu_apply_blocks_pf_kernel(IluDev F, const double *__restrict__ 
   }
 }
 
-// ---- grouped variant: several blocks per wavefront ----------------------------------------------------------------
-// In-block levels of a ~512-row block hold only ~8 rows, so a wavefront that owns ONE block issues every
-// instruction for ~8 useful lanes and the kernel becomes instruction-issue bound (measured: 44M VALU wave-
-// instructions per apply vs 17M for the SpMV).  Here a 64-lane workgroup owns 64/LPG blocks: lane group g runs the
-// level loop of block blockIdx.x*(64/LPG)+g in lockstep with the other groups (trip count = longest level chain
-// among them), each with its own LDS slice.  Same data layout and arithmetic as above.
-template <int BS, bool BWD>
-__device__ __forceinline__ void pfg_sweep(const IluDev &F, double *xs, int b0, int lev_begin, int lev_end, int tid, int T) {
-  const int32_t *lptr = BWD ? F.blev_ptr : F.flev_ptr;
-  int nlev = lev_end > lev_begin ? lev_end - lev_begin : 0;
-  int nmax = nlev;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
-  if (nmax == 0) return;
-  RowPF<BS> cur, nxt;
-  int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
-  if (nlev > 0) { s0 = lptr[lev_begin]; e0 = lptr[lev_begin + 1]; }
-  pf_ptrs<BS, BWD>(F, cur, s0 + tid, e0, b0);
-  pf_entries<BS, BWD>(F, cur);
-  s1 = e0; e1 = e0;
-  if (nlev > 1) e1 = lptr[lev_begin + 2];
-  pf_ptrs<BS, BWD>(F, nxt, s1 + tid, e1, b0);
-  for (int i = 0; i < nmax; ++i) {
-    RowPF<BS> nn;
-    pf_entries<BS, BWD>(F, nxt);
-    int s2 = e1, e2 = e1;
-    if (i + 2 < nlev) e2 = lptr[lev_begin + i + 3];
-    pf_ptrs<BS, BWD>(F, nn, s2 + tid, e2, b0);
-    pf_compute<BS, BWD>(F, cur, xs);
-    for (int idx = s0 + tid + T; idx < e0; idx += T) {
-      RowPF<BS> r;
-      pf_ptrs<BS, BWD>(F, r, idx, e0, b0);
-      pf_entries<BS, BWD>(F, r);
-      pf_compute<BS, BWD>(F, r, xs);
-    }
-    __syncthreads();
-    cur = nxt;
-    nxt = nn;
-    s0 = s1; e0 = e1;
-    s1 = s2; e1 = e2;
-  }
-}
-
-template <int BS, int LPG>
-__global__ __launch_bounds__(64) void ilu_apply_grouped_kernel(IluDev F, int nblocks, int maxrows, const double *__restrict__ bvec,
-                                                               double *__restrict__ xvec) {
-  extern __shared__ __attribute__((aligned(16))) double xs_all[];
-  constexpr int G = 64 / LPG;
-  const int grp = threadIdx.x / LPG, tid = threadIdx.x % LPG;
-  const int b = blockIdx.x * G + grp;
-  const bool live = b < nblocks;
-  double *xs = xs_all + (size_t)grp * maxrows * BS;
-  int b0 = 0, nr = 0;
-  if (live) { b0 = F.blk_ptr[b]; nr = F.blk_ptr[b + 1] - b0; }
-  for (int t = tid; t < nr; t += LPG) {
-    const int dev = F.rowmap[b0 + t];
-#pragma unroll
-    for (int e = 0; e < BS; ++e) xs[t * BS + e] = bvec[(size_t)dev * BS + e];
-  }
-  __syncthreads();
-  int fb = 0, fe = 0, bb = 0, be = 0;
-  if (live) { fb = F.flev_off[b] + 1; fe = F.flev_off[b + 1] - 1; bb = F.blev_off[b]; be = F.blev_off[b + 1] - 1; }
-  pfg_sweep<BS, false>(F, xs, b0, fb, fe, tid, LPG);
-  pfg_sweep<BS, true>(F, xs, b0, bb, be, tid, LPG);
-  for (int t = tid; t < nr; t += LPG) {
-    const int dev = F.rowmap[b0 + t];
-#pragma unroll
-    for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[t * BS + e];
-  }
-}
-
 // ---- chunked variant: one wavefront per block, 64 rows in flight regardless of level width --------------------------
 // The tail of a block's level structure is narrow (a few rows per level), so prefetching "the next level" keeps
 // only a few rows in flight and every level pays a full memory latency.  Here the wavefront walks the block's rows
@@ -728,226 +644,6 @@ __global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const d
   }
 }
 
-// ---- grouped chunked variant: 64/CH blocks per wavefront, CH rows of each in flight -----------------------------------------
-// PMC counters show the one-block-per-wavefront kernel is instruction-issue bound (~72M wave-instructions per apply for
-// ~8 useful lanes each).  Here lane group g (CH lanes) walks block blockIdx.x*(64/CH)+g in CH-row chunks, all groups in
-// lockstep: the same instruction stream advances 64/CH blocks at once.
-template <int BS, bool BWD, int CH>
-__device__ __forceinline__ void gchunk_sweep(const IluDev &F, double *xs, int b0, int b1, int skip_level0) {
-  const int lane = threadIdx.x, sub = lane % CH, gbase = lane - sub;
-  const int32_t *levs = BWD ? F.u_lev : F.l_lev;
-  const int nr = b1 - b0;
-  int nch = (nr + CH - 1) / CH;
-  int nch_max = nch;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) nch_max = max(nch_max, __shfl_xor(nch_max, off, 64));
-  RowPF<BS> cur, nxt, nn;
-  int lv_cur = -1, lv_nxt = -1, lv_nn = -1;
-  pf_ptrs<BS, BWD>(F, cur, b0 + sub, b1, b0);
-  if (b0 + sub < b1) lv_cur = levs[b0 + sub];
-  pf_entries<BS, BWD>(F, cur);
-  pf_ptrs<BS, BWD>(F, nxt, b0 + CH + sub, b1, b0);
-  if (b0 + CH + sub < b1) lv_nxt = levs[b0 + CH + sub];
-  for (int c = 0; c < nch_max; ++c) {
-    const int base = b0 + c * CH;
-    pf_entries<BS, BWD>(F, nxt);
-    pf_ptrs<BS, BWD>(F, nn, base + 2 * CH + sub, b1, b0);
-    lv_nn = (base + 2 * CH + sub < b1) ? levs[base + 2 * CH + sub] : -1;
-    const int nvalid = min(CH, b1 - base);  // <= 0 when this group's block is exhausted
-    int lo = __shfl(lv_cur, gbase, 64);
-    int hi = nvalid > 0 ? __shfl(lv_cur, gbase + max(nvalid, 1) - 1, 64) : -1;
-    if (nvalid <= 0) { lo = 0; hi = -1; }
-    lo = max(lo, skip_level0);
-    int steps = hi - lo + 1;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) steps = max(steps, __shfl_xor(steps, off, 64));
-    for (int it = 0; it < steps; ++it) {
-      const int lv = lo + it;
-      if (lv <= hi && lv_cur == lv) pf_compute<BS, BWD>(F, cur, xs);
-      __syncthreads();
-    }
-    cur = nxt; lv_cur = lv_nxt;
-    nxt = nn; lv_nxt = lv_nn;
-  }
-}
-template <int BS, int CH>
-__global__ __launch_bounds__(64) void ilu_apply_gchunk_kernel(IluDev F, int nblocks, int maxrows, const double *__restrict__ bvec,
-                                                              double *__restrict__ xvec) {
-  extern __shared__ __attribute__((aligned(16))) double xs_all[];
-  constexpr int G = 64 / CH;
-  const int grp = threadIdx.x / CH, sub = threadIdx.x % CH;
-  const int b = blockIdx.x * G + grp;
-  double *xs = xs_all + (size_t)grp * maxrows * BS;
-  int b0 = 0, b1 = 0;
-  if (b < nblocks) { b0 = F.blk_ptr[b]; b1 = F.blk_ptr[b + 1]; }
-  const int nr = b1 - b0;
-  for (int t = sub; t < nr; t += CH) {
-    const int dev = F.rowmap[b0 + t];
-#pragma unroll
-    for (int e = 0; e < BS; ++e) xs[t * BS + e] = bvec[(size_t)dev * BS + e];
-  }
-  __syncthreads();
-  gchunk_sweep<BS, false, CH>(F, xs, b0, b1, 1);
-  gchunk_sweep<BS, true, CH>(F, xs, b0, b1, 0);
-  for (int t = sub; t < nr; t += CH) {
-    const int dev = F.rowmap[b0 + t];
-#pragma unroll
-    for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[t * BS + e];
-  }
-}
-
-// ---- packed chunked variant ---------------------------------------------------------------------------------------------
-// Same algorithm as ilu_apply_chunked_kernel with compressed metadata: per row ONE u32 (level << 16 | entry count), the
-// entry offset of a lane = chunk base + wavefront exclusive scan of the counts, 16-bit block-local column ids.
-__device__ __forceinline__ int wave_excl_scan(int v, int lane) {
-  int inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += o;
-  }
-  return inc - v;
-}
-template <int BS>
-struct RowPK {
-  int lt, s, e, lev;
-  int col[PFW];
-  double val[PFW * BS * BS];
-  double dinv[BS * BS];
-};
-template <int BS, bool BWD>
-__device__ __forceinline__ void pk_meta(const IluDev &F, RowPK<BS> &R, int idx, int end, int b0, int chunk_base, int lane) {
-  unsigned m = 0;
-  if (idx < end) m = BWD ? F.a_umeta[idx] : F.a_lmeta[idx];
-  const int len = (int)(m & 0xffffu);
-  R.lev = (idx < end) ? (int)(m >> 16) : -1;
-  R.s = chunk_base + wave_excl_scan(len, lane);
-  R.e = R.s + len;
-  if (idx < end) {
-    if (BWD) {
-      R.lt = F.a_urow[idx];
-#pragma unroll
-      for (int i = 0; i < BS * BS; ++i) R.dinv[i] = F.dinv[(size_t)idx * BS * BS + i];
-    } else {
-      R.lt = idx - b0;
-    }
-  } else {
-    R.lt = -1;
-  }
-}
-template <int BS, bool BWD>
-__device__ __forceinline__ void pk_entries(const IluDev &F, RowPK<BS> &R) {
-  const uint16_t *cols = BWD ? F.a_ucol : F.a_lcol;
-  const double *vals = BWD ? F.u_val : F.l_val;
-#pragma unroll
-  for (int j = 0; j < PFW; ++j) {
-    if (R.s + j < R.e) {
-      R.col[j] = cols[R.s + j];
-#pragma unroll
-      for (int i = 0; i < BS * BS; ++i) R.val[j * BS * BS + i] = vals[(size_t)(R.s + j) * BS * BS + i];
-    }
-  }
-}
-template <int BS, bool BWD>
-__device__ __forceinline__ void pk_compute(const IluDev &F, const RowPK<BS> &R, double *xs) {
-  const uint16_t *cols = BWD ? F.a_ucol : F.a_lcol;
-  const double *vals = BWD ? F.u_val : F.l_val;
-  double v[BS];
-#pragma unroll
-  for (int e = 0; e < BS; ++e) v[e] = xs[R.lt * BS + e];
-#pragma unroll
-  for (int j = 0; j < PFW; ++j) {
-    if (R.s + j < R.e) {
-      const int k = R.col[j];
-      if (BS == 1) {
-        v[0] -= R.val[j] * xs[k];
-      } else {
-#pragma unroll
-        for (int e = 0; e < BS; ++e) {
-          double sum = 0.0;
-#pragma unroll
-          for (int d = 0; d < BS; ++d) sum += R.val[j * BS * BS + d * BS + e] * xs[k * BS + d];
-          v[e] -= sum;
-        }
-      }
-    }
-  }
-  for (int j = R.s + PFW; j < R.e; ++j) {
-    const int k = cols[j];
-#pragma unroll
-    for (int e = 0; e < BS; ++e) {
-      double sum = 0.0;
-#pragma unroll
-      for (int d = 0; d < BS; ++d) sum += vals[(size_t)j * BS * BS + d * BS + e] * xs[k * BS + d];
-      v[e] -= sum;
-    }
-  }
-  if (BWD) {
-    if (BS == 1) {
-      xs[R.lt] = R.dinv[0] * v[0];
-    } else {
-      double o[BS];
-#pragma unroll
-      for (int e = 0; e < BS; ++e) {
-        double sum = 0.0;
-#pragma unroll
-        for (int d = 0; d < BS; ++d) sum += R.dinv[d * BS + e] * v[d];
-        o[e] = sum;
-      }
-#pragma unroll
-      for (int e = 0; e < BS; ++e) xs[R.lt * BS + e] = o[e];
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < BS; ++e) xs[R.lt * BS + e] = v[e];
-  }
-}
-template <int BS, bool BWD>
-__device__ __forceinline__ void packed_sweep(const IluDev &F, double *xs, int b0, int b1, int chunk0, int skip_level0) {
-  const int lane = threadIdx.x;
-  const int32_t *cbase = BWD ? F.a_uchunk : F.a_lchunk;
-  const int nch = (b1 - b0 + 63) / 64;
-  RowPK<BS> cur, nxt, nn;
-  pk_meta<BS, BWD>(F, cur, b0 + lane, b1, b0, cbase[chunk0], lane);
-  pk_entries<BS, BWD>(F, cur);
-  pk_meta<BS, BWD>(F, nxt, b0 + 64 + lane, b1, b0, nch > 1 ? cbase[chunk0 + 1] : 0, lane);
-  for (int c = 0; c < nch; ++c) {
-    const int base = b0 + c * 64;
-    pk_entries<BS, BWD>(F, nxt);
-    pk_meta<BS, BWD>(F, nn, base + 128 + lane, b1, b0, c + 2 < nch ? cbase[chunk0 + c + 2] : 0, lane);
-    const int nvalid = min(64, b1 - base);
-    const int lv_lo = __shfl(cur.lev, 0, 64);
-    const int lv_hi = __shfl(cur.lev, nvalid - 1, 64);
-    for (int lv = max(lv_lo, skip_level0); lv <= lv_hi; ++lv) {
-      if (cur.lev == lv) pk_compute<BS, BWD>(F, cur, xs);
-      __syncthreads();
-    }
-    cur = nxt;
-    nxt = nn;
-  }
-}
-template <int BS>
-__global__ __launch_bounds__(64) void ilu_apply_packed_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec) {
-  extern __shared__ __attribute__((aligned(16))) double xs[];
-  const int b = blockIdx.x;
-  const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
-  const int nr = b1 - b0;
-  const int chunk0 = F.a_chunk_ptr[b];
-  for (int t = threadIdx.x; t < nr; t += 64) {
-    const int dev = F.rowmap[b0 + t];
-#pragma unroll
-    for (int e = 0; e < BS; ++e) xs[t * BS + e] = bvec[(size_t)dev * BS + e];
-  }
-  __syncthreads();
-  packed_sweep<BS, false>(F, xs, b0, b1, chunk0, 1);
-  packed_sweep<BS, true>(F, xs, b0, b1, chunk0, 0);
-  for (int t = threadIdx.x; t < nr; t += 64) {
-    const int dev = F.rowmap[b0 + t];
-#pragma unroll
-    for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[t * BS + e];
-  }
-}
-
 // GLOBAL mode kernels: x lives in HBM in ilu order
 template <int BS>
 __global__ void ilu_gather_kernel(double *xg, const double *bvec, const int32_t *rowmap, int64_t n, bool scatter) {
@@ -980,9 +676,6 @@ IluDev dev_view(jh_ilu M) {
   F.u_ptr = M->d_u_ptr.p; F.u_col = M->d_u_col.p; F.u_map = M->d_u_map.p;
   F.d_map = M->d_d_map.p; F.u_row = M->d_u_row.p; F.upos_of = M->d_upos_of.p;
   F.l_lev = M->d_l_lev.p; F.u_lev = M->d_u_lev.p;
-  F.a_lmeta = M->d_a_lmeta.p; F.a_umeta = M->d_a_umeta.p;
-  F.a_lcol = M->d_a_lcol.p; F.a_ucol = M->d_a_ucol.p; F.a_urow = M->d_a_urow.p;
-  F.a_chunk_ptr = M->d_a_chunk_ptr.p; F.a_lchunk = M->d_a_lchunk.p; F.a_uchunk = M->d_a_uchunk.p;
   F.l_val = M->l_val.p; F.u_val = M->u_val.p; F.dinv = M->dinv.p;
   return F;
 }
@@ -1154,40 +847,8 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     M->u_lev.resize(n);
     for (int64_t t = 0; t < n; ++t) M->l_lev[t] = flev[order[t]];
     for (int64_t pos = 0; pos < n; ++pos) M->u_lev[pos] = blev[order[uord[pos]]];
-    if (lds && maxrows < 65536 && maxlev < 65536 && getenv("JH_ILU_PACK")) {  // measured slower than int32 metadata: opt-in
-      bool ok = true;
-      M->a_chunk_ptr.assign(nb + 1, 0);
-      for (int64_t b = 0; b < nb; ++b) M->a_chunk_ptr[b + 1] = M->a_chunk_ptr[b] + (M->blk_ptr[b + 1] - M->blk_ptr[b] + 63) / 64;
-      const int64_t nchunks = M->a_chunk_ptr[nb];
-      M->a_lmeta.resize(n); M->a_umeta.resize(n); M->a_urow.resize(n);
-      M->a_lchunk.resize(nchunks); M->a_uchunk.resize(nchunks);
-      M->a_lcol.resize(M->l_col.size()); M->a_ucol.resize(M->u_col.size());
-      for (size_t j = 0; j < M->l_col.size(); ++j) M->a_lcol[j] = (uint16_t)M->l_col[j];
-      for (size_t j = 0; j < M->u_col.size(); ++j) M->a_ucol[j] = (uint16_t)M->u_col[j];
-      for (int64_t b = 0; b < nb && ok; ++b)
-        for (int32_t t = M->blk_ptr[b]; t < M->blk_ptr[b + 1]; ++t) {
-          const int32_t ll = M->l_ptr[t + 1] - M->l_ptr[t], ul = M->u_ptr[t + 1] - M->u_ptr[t];
-          if (ll > 65535 || ul > 65535) { ok = false; break; }
-          M->a_lmeta[t] = ((uint32_t)M->l_lev[t] << 16) | (uint32_t)ll;
-          M->a_umeta[t] = ((uint32_t)M->u_lev[t] << 16) | (uint32_t)ul;
-          M->a_urow[t] = (uint16_t)M->u_row[t];
-          if ((t - M->blk_ptr[b]) % 64 == 0) {
-            const int32_t c = M->a_chunk_ptr[b] + (t - M->blk_ptr[b]) / 64;
-            M->a_lchunk[c] = M->l_ptr[t];
-            M->a_uchunk[c] = M->u_ptr[t];
-          }
-        }
-      M->packed = ok;
-    }
     // upload
     hipStream_t s = M->ctx->stream;
-    if (M->packed) {
-      M->d_a_lmeta.upload(M->a_lmeta, s); M->d_a_umeta.upload(M->a_umeta, s); M->d_a_urow.upload(M->a_urow, s);
-      M->d_a_lcol.alloc(std::max<size_t>(M->a_lcol.size(), 1)); M->d_a_ucol.alloc(std::max<size_t>(M->a_ucol.size(), 1));
-      if (!M->a_lcol.empty()) JH_HIP(hipMemcpyAsync(M->d_a_lcol.p, M->a_lcol.data(), M->a_lcol.size() * 2, hipMemcpyHostToDevice, s));
-      if (!M->a_ucol.empty()) JH_HIP(hipMemcpyAsync(M->d_a_ucol.p, M->a_ucol.data(), M->a_ucol.size() * 2, hipMemcpyHostToDevice, s));
-      M->d_a_chunk_ptr.upload(M->a_chunk_ptr, s); M->d_a_lchunk.upload(M->a_lchunk, s); M->d_a_uchunk.upload(M->a_uchunk, s);
-    }
     M->d_l_lev.upload(M->l_lev, s); M->d_u_lev.upload(M->u_lev, s);
     M->d_rowmap.upload(M->rowmap, s); M->d_blk_ptr.upload(M->blk_ptr, s);
     M->d_flev_off.upload(M->flev_off, s); M->d_flev_ptr.upload(M->flev_ptr, s);
@@ -1203,15 +864,6 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     M->lds_bytes = lds ? (size_t)maxrows * P.bs * sizeof(double) : 0;
     // one wavefront per small block keeps many blocks resident per CU (the level loop is latency-bound)
     M->threads = maxrows <= 1024 ? 64 : (maxrows <= 2048 ? 128 : 256);
-    // narrow in-block levels: let several blocks share a wavefront (only if their LDS slices fit)
-    {
-      const double rows_per_level = (double)n / std::max<double>(1.0, (double)M->flev_ptr.size());
-      int lpg = 64;
-      (void)rows_per_level;  // grouping measured slower than one block per wavefront (profiles/ notes); opt-in only
-      if (const char *e = getenv("JH_ILU_LPG")) { int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) lpg = v; }
-      while (lpg < 64 && (size_t)(64 / lpg) * maxrows * P.bs * sizeof(double) > LDS_CAP_BYTES) lpg *= 2;
-      M->lanes_per_block = lpg;
-    }
     if (const char *e = getenv("JH_ILU_THREADS")) { int t = atoi(e); if (t == 64 || t == 128 || t == 256 || t == 512) M->threads = t; }
     JH_HIP(hipStreamSynchronize(s));
     *out = M.release();
@@ -1313,61 +965,13 @@ void ilu_apply(jh_ilu M, const double *b, double *x) {
       return;
     }
     static const bool no_chunk = getenv("JH_ILU_NO_CHUNK") != nullptr;
-    static const int gch = getenv("JH_ILU_GCH") ? atoi(getenv("JH_ILU_GCH")) : 0;
-    if (M->threads == 64 && (gch == 16 || gch == 32) && (size_t)(64 / gch) * M->lds_bytes <= LDS_CAP_BYTES) {
-      const int G = 64 / gch;
-      dim3 grid((unsigned)((nb + G - 1) / G));
-      const size_t lds = (size_t)G * M->lds_bytes;
-      const int mr = (int)M->max_block_rows, nbi = (int)nb;
-#define JH_GCH(BSV, CHV) hipLaunchKernelGGL((ilu_apply_gchunk_kernel<BSV, CHV>), grid, dim3(64), lds, s, F, nbi, mr, b, x)
-      switch (M->bs * 100 + gch) {
-        case 116: JH_GCH(1, 16); break;
-        case 132: JH_GCH(1, 32); break;
-        case 216: JH_GCH(2, 16); break;
-        case 232: JH_GCH(2, 32); break;
-        case 316: JH_GCH(3, 16); break;
-        case 332: JH_GCH(3, 32); break;
-      }
-#undef JH_GCH
-      return;
-    }
-    if (M->threads == 64 && M->lanes_per_block == 64 && !no_chunk && M->packed) {
-      switch (M->bs) {
-        case 1: hipLaunchKernelGGL(ilu_apply_packed_kernel<1>, dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x); break;
-        case 2: hipLaunchKernelGGL(ilu_apply_packed_kernel<2>, dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x); break;
-        case 3: hipLaunchKernelGGL(ilu_apply_packed_kernel<3>, dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x); break;
-      }
-      return;
-    }
-    if (M->threads == 64 && M->lanes_per_block == 64 && !no_chunk) {
+    if (M->threads == 64 && !no_chunk) {
       IluGather G0;
       switch (M->bs) {
         case 1: hipLaunchKernelGGL((ilu_apply_chunked_kernel<1, 0>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x, G0); break;
         case 2: hipLaunchKernelGGL((ilu_apply_chunked_kernel<2, 0>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x, G0); break;
         case 3: hipLaunchKernelGGL((ilu_apply_chunked_kernel<3, 0>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x, G0); break;
       }
-      return;
-    }
-    if (M->lanes_per_block < 64) {
-      const int G = 64 / M->lanes_per_block;
-      dim3 grid((unsigned)((nb + G - 1) / G));
-      const size_t lds = (size_t)G * M->max_block_rows * M->bs * sizeof(double);
-      const int mr = (int)M->max_block_rows, nbi = (int)nb;
-#define JH_GROUPED(BSV, LPGV) hipLaunchKernelGGL((ilu_apply_grouped_kernel<BSV, LPGV>), grid, dim3(64), lds, s, F, nbi, mr, b, x)
-      const int key = M->bs * 100 + M->lanes_per_block;
-      switch (key) {
-        case 108: JH_GROUPED(1, 8); break;
-        case 116: JH_GROUPED(1, 16); break;
-        case 132: JH_GROUPED(1, 32); break;
-        case 208: JH_GROUPED(2, 8); break;
-        case 216: JH_GROUPED(2, 16); break;
-        case 232: JH_GROUPED(2, 32); break;
-        case 308: JH_GROUPED(3, 8); break;
-        case 316: JH_GROUPED(3, 16); break;
-        case 332: JH_GROUPED(3, 32); break;
-        default: JH_THROW("bad lanes_per_block");
-      }
-#undef JH_GROUPED
       return;
     }
     switch (M->bs) {
@@ -1402,8 +1006,8 @@ void ilu_apply(jh_ilu M, const double *b, double *x) {
 #undef JH_BS_SWITCH
 }
 bool ilu_can_fuse_gather(jh_ilu M) {
-  static const bool off = getenv("JH_ILU_NO_CHUNK") != nullptr || getenv("JH_ILU_GCH") != nullptr || getenv("JH_NO_FUSE") != nullptr;
-  return M && M->lds_mode && M->threads == 64 && M->lanes_per_block == 64 && !M->packed && !off;
+  static const bool off = getenv("JH_ILU_NO_CHUNK") != nullptr || getenv("JH_NO_FUSE") != nullptr;
+  return M && M->lds_mode && M->threads == 64 && !off;
 }
 // x = M^-1 * (fused vector update), see IluGather / ilu_apply_chunked_kernel
 void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x) {
