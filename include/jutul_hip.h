@@ -172,6 +172,12 @@ int32_t jh_ilu0_info(jh_ilu M, int64_t *nblocks, int64_t *max_block_rows, int64_
  * [2] execution blocks, [3] 1 if the LDS (block-Jacobi) kernels are used, 0 for the level-per-launch kernels */
 int32_t jh_ilu0_stats(jh_ilu M, int64_t *stats4);
 
+/* DiagonalPreconditioner family (precond/diagonal.jl): kind 1 = JacobiPreconditioner(w) D_i = w*inv(A_ii)
+ * (precond/jacobi.jl:5-18), kind 2 = SPAI0Preconditioner D_i = A_ii / sum(row entries squared) (precond/spai.jl:40-60).
+ * The handle is used like an ILU(0) one: jh_ilu0_factor = update_preconditioner!, jh_ilu0_apply = apply!, usable as
+ * the preconditioner of jh_bicgstab / jh_newton_step. */
+int32_t jh_diag_precond_create(jh_csr A, int32_t kind, double w, jh_ilu *out);
+
 /* ---- a-14: Krylov ---------------------------------------------------------------------------------------------- */
 #define JH_SIDE_NONE 0
 #define JH_SIDE_LEFT 1  /* M = prec (distributed path, ext/JutulPartitionedArraysExt/krylov.jl:60)        */

@@ -26,7 +26,7 @@ from .discretization import compute_face_gdz, compute_face_trans, compute_half_f
 from .meshgen import cartesian_neighbors, tet_lattice_mesh  # noqa: F401
 
 __all__ = ["HIPContext", "LocalCommGroup", "TwoPointPotentialFlowHardCoded", "DeviceVector", "StaticSparsityMatrixCSR", "ConservationLaw",
-           "ILUZeroPreconditioner", "IterativeSolverConfig", "GenericKrylov", "LinearizedSystem", "linear_solve",
+           "ILUZeroPreconditioner", "JacobiPreconditioner", "SPAI0Preconditioner", "IterativeSolverConfig", "GenericKrylov", "LinearizedSystem", "linear_solve",
            "Simulator", "JutulHIPError", "mul_", "ilu0_csr", "ldiv_", "tet_lattice_mesh", "cartesian_neighbors"]
 
 REORDER = {"none": 0, "blocks": 1}
@@ -422,6 +422,44 @@ class ILUZeroPreconditioner(_Handle):
         check(_L().jh_ilu0_stats(self.h, pi(st)))
         return dict(nblocks=a.value, max_block_rows=b.value, max_levels=c.value, l_entries=int(st[0]),
                     u_entries=int(st[1]), exec_blocks=int(st[2]), lds_mode=bool(st[3]))
+
+
+class _DiagonalPreconditioner(_Handle):
+    """DiagonalPreconditioner (precond/diagonal.jl:7-45): D rebuilt from A on every update, x = D*y."""
+    _destroy = "jh_ilu0_destroy"
+    _kind, _w = 1, 1.0
+
+    def __init__(self):
+        super().__init__()
+        self.A, self.left, self.right = None, True, False
+
+    def update_preconditioner(self, A):
+        if self.A is not A:
+            self.close()
+            check(_L().jh_diag_precond_create(A.h, self._kind, float(self._w), C.byref(self.h)))
+            self.A = A
+        check(_L().jh_ilu0_factor(self.h))
+        return self
+
+    def apply(self, x, y):
+        check(_L().jh_ilu0_apply(self.h, y.h, x.h))
+        return x
+
+
+class JacobiPreconditioner(_DiagonalPreconditioner):
+    """JacobiPreconditioner(w = 2/3) (precond/jacobi.jl:5-18): D_i = w*inv(A_ii)."""
+
+    def __init__(self, w=2.0 / 3.0):
+        super().__init__()
+        self._kind, self._w = 1, w
+
+
+class SPAI0Preconditioner(_DiagonalPreconditioner):
+    """SPAI0Preconditioner (precond/spai.jl:4-60): D_i = A_ii / sum of the squared entries of row i."""
+
+    def __init__(self):
+        super().__init__()
+        self._kind = 2
 
 
 def ilu0_csr(A, partition=None):

@@ -86,6 +86,7 @@ SIGNATURES = {
     "jh_ilu0_get_factor": [H, F64P],
     "jh_ilu0_info": [H, I64P, I64P, I64P],
     "jh_ilu0_stats": [H, I64P],
+    "jh_diag_precond_create": [H, C.c_int32, C.c_double, C.POINTER(H)],
     "jh_krylov_create": [H, C.POINTER(H)],
     "jh_krylov_destroy": [H],
     "jh_krylov_profile": [H, C.c_int32, C.c_int32, F64P, I64P],

@@ -31,6 +31,8 @@ struct jh_ilu_s {
   std::shared_ptr<Pattern> pat;
   int bs = 1;
   int64_t n = 0;
+  int kind = 0;        // 0 ILU(0); 1 damped Jacobi (w*inv(A_ii)); 2 SPAI(0) (A_ii / sum of squared row entries)
+  double jacobi_w = 1.0;
   bool lds_mode = false;
   int64_t nparts = 1, max_block_rows = 0, max_levels = 0;
   int threads = 256;
@@ -667,6 +669,47 @@ __global__ void ilu_bwd_level_kernel(IluDev F, double *xg, int s, int e) {
   if (pos < e) bwd_row<BS>(F, pos, F.u_row[pos], xg);
 }
 
+// ---- DiagonalPreconditioner family (precond/diagonal.jl, jacobi.jl:5-18, spai.jl:40-60) --------------------------------
+template <int BS>
+__global__ void diag_precond_kernel(const int32_t *rowptr, const int32_t *diag, const double *val, double *D, int64_t n, int kind, double w) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int BB = BS * BS;
+  const Blk<BS> Aii = blk_load<BS>(val + (size_t)diag[i] * BB);
+  Blk<BS> out;
+  if (kind == 1) {  // diagonal_precond(A, i, jac) = w*inv(A_ii)
+    out = blk_inv<BS>(Aii);
+#pragma unroll
+    for (int e = 0; e < BB; ++e) out.a[e] *= w;
+  } else {          // SPAI(0): inv(norm_sum)*A_ii with norm_sum = sum of v^2 over all scalar entries of the row
+    double ns = 0.0;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
+#pragma unroll
+      for (int e = 0; e < BB; ++e) { const double v = val[(size_t)k * BB + e]; ns += v * v; }
+    const double inv = 1.0 / ns;
+#pragma unroll
+    for (int e = 0; e < BB; ++e) out.a[e] = inv * Aii.a[e];
+  }
+  blk_store<BS>(D + (size_t)i * BB, out);
+}
+template <int BS>
+__global__ void diag_apply_kernel(const double *D, const double *b, double *x, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v[BS], o[BS];
+#pragma unroll
+  for (int e = 0; e < BS; ++e) v[e] = b[i * BS + e];
+#pragma unroll
+  for (int e = 0; e < BS; ++e) {
+    double s = 0.0;
+#pragma unroll
+    for (int d = 0; d < BS; ++d) s += D[(size_t)i * BS * BS + d * BS + e] * v[d];
+    o[e] = s;
+  }
+#pragma unroll
+  for (int e = 0; e < BS; ++e) x[i * BS + e] = o[e];
+}
+
 IluDev dev_view(jh_ilu M) {
   IluDev F;
   F.rowmap = M->d_rowmap.p; F.blk_ptr = M->d_blk_ptr.p;
@@ -894,10 +937,37 @@ extern "C" int32_t jh_ilu0_stats(jh_ilu M, int64_t *stats4) {
   });
 }
 
+extern "C" int32_t jh_diag_precond_create(jh_csr A, int32_t kind, double w, jh_ilu *out) {
+  return guard([&] {
+    if (!A || !out) JH_THROW("null argument");
+    if (kind != 1 && kind != 2) JH_THROW("kind must be 1 (Jacobi) or 2 (SPAI0)");
+    for (int64_t i = 0; i < A->pat->n; ++i)
+      if (A->pat->diag[i] < 0) JH_THROW("Diagonal must be present in sparsity pattern.");
+    auto M = std::make_unique<jh_ilu_s>();
+    M->ctx = A->ctx; M->A = A; M->pat = A->pat; M->bs = A->pat->bs; M->n = A->pat->n;
+    M->kind = kind;
+    M->jacobi_w = w;
+    JH_HIP(hipSetDevice(M->ctx->device));
+    M->dinv.alloc((size_t)M->n * M->bs * M->bs);
+    *out = M.release();
+  });
+}
+
 namespace jh {
 void ilu_factor(jh_ilu M) {
   jh_context ctx = M->ctx;
   hipStream_t s = ctx->stream;
+  if (M->kind != 0) {
+    const Pattern &P = *M->pat;
+    dim3 g((unsigned)((M->n + 255) / 256));
+    switch (M->bs) {
+      case 1: hipLaunchKernelGGL(diag_precond_kernel<1>, g, dim3(256), 0, s, P.d_rowptr.p, P.d_diag.p, M->A->val.p, M->dinv.p, M->n, M->kind, M->jacobi_w); break;
+      case 2: hipLaunchKernelGGL(diag_precond_kernel<2>, g, dim3(256), 0, s, P.d_rowptr.p, P.d_diag.p, M->A->val.p, M->dinv.p, M->n, M->kind, M->jacobi_w); break;
+      case 3: hipLaunchKernelGGL(diag_precond_kernel<3>, g, dim3(256), 0, s, P.d_rowptr.p, P.d_diag.p, M->A->val.p, M->dinv.p, M->n, M->kind, M->jacobi_w); break;
+    }
+    M->factored = true;
+    return;
+  }
   const int bb = M->bs * M->bs;
   const double *aval = M->A->val.p;
   if (M->lds_mode && M->factor_lds_bytes) {
@@ -952,6 +1022,15 @@ void ilu_factor(jh_ilu M) {
 void ilu_apply(jh_ilu M, const double *b, double *x) {
   if (!M->factored) JH_THROW("ILU(0) applied before jh_ilu0_factor");
   hipStream_t s = M->ctx->stream;
+  if (M->kind != 0) {
+    dim3 g((unsigned)((M->n + 255) / 256));
+    switch (M->bs) {
+      case 1: hipLaunchKernelGGL(diag_apply_kernel<1>, g, dim3(256), 0, s, M->dinv.p, b, x, M->n); break;
+      case 2: hipLaunchKernelGGL(diag_apply_kernel<2>, g, dim3(256), 0, s, M->dinv.p, b, x, M->n); break;
+      case 3: hipLaunchKernelGGL(diag_apply_kernel<3>, g, dim3(256), 0, s, M->dinv.p, b, x, M->n); break;
+    }
+    return;
+  }
   IluDev F = dev_view(M);
   const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
   if (M->lds_mode) {
@@ -1007,7 +1086,7 @@ void ilu_apply(jh_ilu M, const double *b, double *x) {
 }
 bool ilu_can_fuse_gather(jh_ilu M) {
   static const bool off = getenv("JH_ILU_NO_CHUNK") != nullptr || getenv("JH_NO_FUSE") != nullptr;
-  return M && M->lds_mode && M->threads == 64 && !off;
+  return M && M->kind == 0 && M->lds_mode && M->threads == 64 && !off;
 }
 // x = M^-1 * (fused vector update), see IluGather / ilu_apply_chunked_kernel
 void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x) {
@@ -1053,6 +1132,7 @@ extern "C" int32_t jh_ilu0_get_factor(jh_ilu M, double *lu) {
   return guard([&] {
     if (!M || !lu) JH_THROW("null argument");
     if (!M->factored) JH_THROW("not factored");
+    if (M->kind != 0) JH_THROW("jh_ilu0_get_factor is for ILU(0) handles");
     const Pattern &P = *M->pat;
     const int bb = M->bs * M->bs;
     std::vector<double> l(M->l_val.n), u(M->u_val.n), d(M->dinv.n);

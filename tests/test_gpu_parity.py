@@ -505,3 +505,35 @@ def test_scalar_layouts_pattern_positions_values(ja, ctx, oracle, layout):
     assert np.array_equal(v.download(), r_blk)
     # block layout passes through
     assert np.array_equal(disc.pattern_layout("block_major")[1], osys.colidx)
+
+
+# ---- DiagonalPreconditioner family ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bs", [1, 2])
+def test_jacobi_and_spai0_preconditioners(ja, ctx, oracle, bs):
+    """JacobiPreconditioner w*inv(A_ii) (precond/jacobi.jl:14-17) and SPAI(0) A_ii/sum(v^2) (precond/spai.jl:40-60) vs numpy;
+    both usable as BiCGStab preconditioners."""
+    nc, rowptr, colidx, nz, rng = random_csr(oracle, (7, 6, 5), bs, seed=31)
+    A = ja.StaticSparsityMatrixCSR(context=ctx, n=nc, bs=bs, rowptr=rowptr, colidx=colidx, nzval=nz)
+    blocks = nz.reshape(-1, bs, bs).transpose(0, 2, 1)  # [nnzb, e, d]
+    rows = np.repeat(np.arange(nc), np.diff(rowptr))
+    dmask = colidx - 1 == rows
+    Aii = blocks[dmask]
+    y = rng.standard_normal(nc * bs)
+    w = 2.0 / 3.0
+    xj = ja.JacobiPreconditioner(w).update_preconditioner(A).apply(A.new_vector(), A.new_vector(y)).download()
+    ref = np.einsum("ied,id->ie", w * np.linalg.inv(Aii), y.reshape(nc, bs)).reshape(-1)
+    assert relerr(xj, ref) < 1e-13
+    ns = np.zeros(nc)
+    np.add.at(ns, rows, (blocks ** 2).sum((1, 2)))
+    xs = ja.SPAI0Preconditioner().update_preconditioner(A).apply(A.new_vector(), A.new_vector(y)).download()
+    ref = np.einsum("ied,id->ie", Aii / ns[:, None, None], y.reshape(nc, bs)).reshape(-1)
+    assert relerr(xs, ref) < 1e-13
+    b = rng.standard_normal(nc * bs)
+    for prec in (ja.JacobiPreconditioner(), ja.SPAI0Preconditioner()):
+        s = type("S", (), {})()
+        s.disc = type("D", (), {"ctx": ctx})()
+        s.jac, s.r, s.dx, s._x = A, A.new_vector(b), A.new_vector(), A.new_vector()
+        out = ja.linear_solve(s, ja.GenericKrylov("bicgstab", preconditioner=prec, relative_tolerance=1e-9, max_iterations=200))
+        assert out["ok"]
+        r = oracle.spmv(nc, bs, rowptr, colidx, nz, -s.dx.download()) - b
+        assert np.linalg.norm(r) <= 1e-7 * np.linalg.norm(b)
