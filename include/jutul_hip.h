@@ -121,6 +121,9 @@ int32_t jh_vec_upload_layout(jh_vec v, int32_t layout, const double *host);
 int32_t jh_vec_download_layout(jh_vec v, int32_t layout, double *host);
 /* mul!(y, A, x, alpha, beta) (StaticCSR/mat.jl:24-39; block: linsolve/block_cpu.jl:1-17) */
 int32_t jh_spmv(jh_csr A, jh_vec x, jh_vec y, double alpha, double beta);
+/* krylov_scale_system! / apply_scaling_to_linearized_system! (linsolve/krylov.jl:194, default.jl:325-385):
+ * kind 0 :none, 1 :diagonal (J <- diag(1/|A_ii[j,j]|) J, r likewise), 2 :dt (J <- dt J, r <- dt r).  In place. */
+int32_t jh_scale_system(jh_csr A, jh_vec r, int32_t kind, double dt);
 /* unit_diagonalize!(r, J, n_self) (ext/JutulPartitionedArraysExt/linalg.jl:18-35): rows of ghost cells -> -I,
  * r_ghost -> 0.  ghost rows are the device rows >= n_owned of a distributed discretisation. */
 int32_t jh_unit_diagonalize(jh_csr A, jh_vec r, int64_t n_owned);

@@ -26,7 +26,7 @@ from .discretization import compute_face_gdz, compute_face_trans, compute_half_f
 from .meshgen import cartesian_neighbors, tet_lattice_mesh  # noqa: F401
 
 __all__ = ["HIPContext", "LocalCommGroup", "TwoPointPotentialFlowHardCoded", "DeviceVector", "StaticSparsityMatrixCSR", "ConservationLaw",
-           "ILUZeroPreconditioner", "JacobiPreconditioner", "SPAI0Preconditioner", "IterativeSolverConfig", "GenericKrylov", "LinearizedSystem", "linear_solve",
+           "ILUZeroPreconditioner", "JacobiPreconditioner", "SPAI0Preconditioner", "IterativeSolverConfig", "GenericKrylov", "LinearizedSystem", "linear_solve", "scale_system",
            "Simulator", "JutulHIPError", "mul_", "ilu0_csr", "ldiv_", "tet_lattice_mesh", "cartesian_neighbors"]
 
 REORDER = {"none": 0, "blocks": 1}
@@ -494,11 +494,12 @@ class GenericKrylov(_Handle):
     """GenericKrylov(:bicgstab; preconditioner, ...) (linsolve/krylov.jl:27-58)."""
     _destroy = "jh_krylov_destroy"
 
-    def __init__(self, solver="bicgstab", preconditioner=None, **cfg):
+    def __init__(self, solver="bicgstab", preconditioner=None, scaling="none", **cfg):
         super().__init__()
         if solver != "bicgstab":
             raise NotImplementedError("only :bicgstab is on the MI355X hot path")
-        self.solver, self.preconditioner = solver, preconditioner
+        assert scaling in ("none", "diagonal", "dt")  # GenericKrylov.scaling (linsolve/krylov.jl:27-58)
+        self.solver, self.preconditioner, self.scaling = solver, preconditioner, scaling
         self.config = IterativeSolverConfig(**cfg)
         self.A = None
 
@@ -540,7 +541,13 @@ class LinearizedSystem:
         return self.jac.nzval
 
 
-def linear_solve(sys, krylov, atol=None, rtol=None, update_preconditioner=True):
+def scale_system(sys, scaling, dt=1.0):
+    """apply_scaling_to_linearized_system! (linsolve/default.jl:325-352) on the device, in place."""
+    kind = {"none": 0, "diagonal": 1, "dt": 2}[scaling]
+    check(_L().jh_scale_system(sys.jac.h, sys.r.h, kind, float(dt)))
+
+
+def linear_solve(sys, krylov, atol=None, rtol=None, update_preconditioner=True, dt=None):
     """linear_solve!(sys, krylov::GenericKrylov, ...) (linsolve/krylov.jl:71-182): updates the preconditioner,
     runs BiCGStab on sys.r, writes dx = -x.  Returns linear_solve_return-like dict (default.jl:450-465)."""
     cfg = krylov.config
@@ -548,6 +555,8 @@ def linear_solve(sys, krylov, atol=None, rtol=None, update_preconditioner=True):
     rtol = cfg.tolerance("relative") if rtol is None else rtol
     prec = krylov.preconditioner
     ctx = sys.disc.ctx
+    if getattr(krylov, "scaling", "none") != "none":  # krylov_scale_system! (linsolve/krylov.jl:194)
+        scale_system(sys, krylov.scaling, 1.0 if dt is None else dt)
     ctx.timer_start()
     if prec is not None and update_preconditioner:
         prec.update_preconditioner(sys.jac)

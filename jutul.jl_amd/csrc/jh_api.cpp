@@ -280,6 +280,17 @@ extern "C" int32_t jh_spmv(jh_csr A, jh_vec x, jh_vec y, double alpha, double be
     JH_HIP(hipGetLastError());
   });
 }
+extern "C" int32_t jh_scale_system(jh_csr A, jh_vec r, int32_t kind, double dt) {
+  return guard([&] {
+    if (!A || !r) JH_THROW("null argument");
+    if (kind == 0) return;
+    if (kind != 1 && kind != 2) JH_THROW("scaling must be 0 (:none), 1 (:diagonal) or 2 (:dt)");
+    if (r->len != A->pat->n * A->pat->bs) JH_THROW("dimension mismatch");
+    JH_HIP(hipSetDevice(A->ctx->device));
+    k_scale_system(A->ctx->stream, *A->pat, A->val.p, r->d.p, kind, dt);
+    JH_HIP(hipGetLastError());
+  });
+}
 extern "C" int32_t jh_unit_diagonalize(jh_csr A, jh_vec r, int64_t n_owned) {
   return guard([&] {
     if (!A || !r) JH_THROW("null argument");

@@ -206,6 +206,7 @@ void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x
 void ensure_partials(jh_context ctx, size_t min_stride);
 void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max);
 void k_unit_diag(hipStream_t s, const Pattern &P, double *val, double *r, int64_t n_owned);
+void k_scale_system(hipStream_t s, const Pattern &P, double *val, double *r, int kind, double dt);
 
 // ---- assembly (jh_assembly.hip) -------------------------------------------------------------------------------
 void k_gather_face_data(hipStream_t s, double *nzdata, const int32_t *nz_face, const double *face_data, int64_t nnzb,

@@ -370,6 +370,27 @@ __global__ void unit_diag_kernel(const int32_t *rowptr, const int32_t *col, doub
       for (int e = 0; e < bs; ++e) A[e * bs + e] = -1.0;
   }
 }
+// apply_scaling_to_linearized_system! (linsolve/default.jl:325-352): kind 1 = :diagonal, F = 1/|A_ii[j,j]| (scalar
+// entries ~ 0 -> 1, default.jl:354-385), J <- diag(F) J, r <- F .* r ; kind 2 = :dt, J <- dt J, r <- dt r.
+__global__ void scale_system_kernel(const int32_t *rowptr, const int32_t *diag, double *val, double *r, int64_t n, int bs, int kind, double dt) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double F[3];
+  for (int e = 0; e < bs; ++e) {
+    if (kind == 2) { F[e] = dt; continue; }
+    const double a = val[(size_t)diag[i] * bs * bs + e * bs + e];
+    // scalar variant guards `A_ii ≈ 0` (default.jl:374-379); isapprox against 0 with the default rtol holds only for 0
+    F[e] = (bs == 1 && a == 0.0) ? 1.0 : 1.0 / fabs(a);
+  }
+  for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
+    for (int d = 0; d < bs; ++d)
+      for (int e = 0; e < bs; ++e) val[(size_t)k * bs * bs + d * bs + e] *= F[e];  // D_mat * block: row e scaled by F[e]
+  for (int e = 0; e < bs; ++e) r[i * bs + e] *= F[e];
+}
+void k_scale_system(hipStream_t s, const Pattern &P, double *val, double *r, int kind, double dt) {
+  if (P.n) hipLaunchKernelGGL(scale_system_kernel, dim3((unsigned)((P.n + 255) / 256)), dim3(256), 0, s, P.d_rowptr.p, P.d_diag.p, val, r, P.n, P.bs, kind, dt);
+}
+
 void k_unit_diag(hipStream_t s, const Pattern &P, double *val, double *r, int64_t n_owned) {
   int64_t ng = P.n - n_owned;
   if (ng <= 0) return;

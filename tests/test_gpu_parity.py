@@ -537,3 +537,25 @@ def test_jacobi_and_spai0_preconditioners(ja, ctx, oracle, bs):
         assert out["ok"]
         r = oracle.spmv(nc, bs, rowptr, colidx, nz, -s.dx.download()) - b
         assert np.linalg.norm(r) <= 1e-7 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("bs", [1, 2])
+def test_system_scaling(ja, ctx, oracle, bs):
+    """:diagonal and :dt scaling of the linearized system (linsolve/default.jl:325-385): J <- diag(F) J, r <- F.*r."""
+    nc, rowptr, colidx, nz, rng = random_csr(oracle, (6, 5, 4), bs, seed=41)
+    rows = np.repeat(np.arange(nc), np.diff(rowptr))
+    blocks = nz.reshape(-1, bs, bs).transpose(0, 2, 1)  # [nnzb, e, d]
+    r = rng.standard_normal(nc * bs)
+    for scaling, dt in (("diagonal", 1.0), ("dt", 3.5)):
+        A = ja.StaticSparsityMatrixCSR(context=ctx, n=nc, bs=bs, rowptr=rowptr, colidx=colidx, nzval=nz)
+        s = type("S", (), {})()
+        s.jac, s.r = A, A.new_vector(r)
+        ja.scale_system(s, scaling, dt)
+        if scaling == "dt":
+            F = np.full((nc, bs), dt)
+        else:
+            Aii = blocks[colidx - 1 == rows]
+            F = 1.0 / np.abs(np.einsum("iee->ie", Aii))
+        ref_blocks = blocks * F[rows][:, :, None]
+        assert relerr(A.nzval, ref_blocks.transpose(0, 2, 1).reshape(-1)) < 1e-15
+        assert relerr(s.r.download(), (r.reshape(nc, bs) * F).reshape(-1)) < 1e-15
