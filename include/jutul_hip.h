@@ -212,8 +212,9 @@ typedef struct {
   int32_t linear_status;
   int32_t converged;       /* all(error < tol) (and solve skipped, check_before_solve = true) */
 } jh_newton_report;
-/* One Newton iteration: assemble -> convergence check -> (if not converged or force_solve) ILU factor +
- * BiCGStab + dx = -x + primary update.  tol: per-equation residual tolerance (1e-3 default in the reference). */
+/* One Newton iteration: assemble -> convergence check -> ILU factor + BiCGStab + dx = -x + primary update.
+ * force_solve: 0 solve unless converged, 1 always solve, -1 never solve (assembly + convergence only).
+ * tol: per-equation residual tolerance (1e-3 default in the reference). */
 int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_vec r, jh_vec dx, double dt, double tol,
                        int32_t force_solve, double rtol, double atol, int64_t itmax, int32_t side,
                        jh_newton_report *rep);

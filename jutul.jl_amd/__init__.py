@@ -600,7 +600,7 @@ class Simulator:
         rep = NewtonReport()
         cfg = ks.config
         # converged && iteration > min_nonlinear_iterations (simulator.jl:484): the first iteration always solves
-        force = 1 if (iteration <= self.min_it and solve) else 0
+        force = -1 if not solve else (1 if iteration <= self.min_it else 0)
         check(_L().jh_newton_step(self.law.h, self.lsys.jac.h, prec.h if prec is not None else None, K, self.lsys.r.h,
                                   self.lsys.dx.h, float(dt), float(self.tol), force, cfg.tolerance("relative"),
                                   cfg.tolerance("absolute"), int(cfg.max_iterations),

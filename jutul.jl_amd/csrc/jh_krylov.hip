@@ -336,7 +336,9 @@ extern "C" int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_
       if (!(err[e] < tol)) conv = false;
     }
     rep->converged = conv ? 1 : 0;
-    if (conv && !force_solve) return;  // check_before_solve (simulator.jl:435-441)
+    // force_solve: 0 = solve unless converged (check_before_solve, simulator.jl:435-441); 1 = always solve
+    // (iteration <= min_nonlinear_iterations, :484); -1 = assemble + check only (solve = false past max_iter, :566-570)
+    if (force_solve < 0 || (conv && force_solve == 0)) return;
     // -- linear solve
     JH_HIP(hipEventRecord(e0, st));
     if (M) ilu_factor(M);
