@@ -93,11 +93,12 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
     const double *__restrict__ X0, double *__restrict__ nz, double *__restrict__ r, double dt, LawPar par, int reg_row) {
   constexpr int N = (KIND == JH_LAW_TWOPHASE) ? 2 : 1;
   constexpr int NN = N * N;
-  __shared__ double qv[TILE_NNZ * N];    // flux values per entry
-  __shared__ double dsv[TILE_NNZ * NN];  // d q / d x_self per entry (column-major N x N)
+  constexpr int TNNZ = (N == 1) ? TILE_NNZ : TILE_NNZ / 2;  // tile entry budget (Pattern::build_tiles)
+  __shared__ double qv[TNNZ * N];    // flux values per entry
+  __shared__ double dsv[TNNZ * NN];  // d q / d x_self per entry (column-major N x N)
   __shared__ double xs[TILE_ROWS * N];   // primary variables of the tile's rows
   __shared__ int32_t rp[TILE_ROWS + 1];
-  __shared__ uint8_t rowof[TILE_NNZ];
+  __shared__ uint8_t rowof[TNNZ];
   const int t = xcd_tile_a(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int r0 = tile_row[t], r1 = tile_row[t + 1];
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
   // The off-diagonal blocks stay in registers until phase 3 so that every nzval line of the tile is written once,
   // full and coalesced (8-byte diagonal stores from the row lanes cost a 32-byte HBM write each: +0.32 GB at 10M
   // cells, measured with WRITE_SIZE).
-  constexpr int KPT = TILE_NNZ / TILE_THREADS;  // entries per lane
+  constexpr int KPT = TNNZ / TILE_THREADS;  // entries per lane
   double off[KPT][NN];
   bool isdiag[KPT];
 #pragma unroll

@@ -19,13 +19,16 @@ const std::string &last_error() { return g_err; }
 void Pattern::build_tiles() {
   tile_row.clear();
   tile_row.push_back(0);
+  // block entries carry bs*bs values: halve the entry budget of a tile for bs > 1 (keeps the assembly kernel's LDS
+  // footprint near 30 KB so that several workgroups stay resident per CU)
+  const int64_t max_nnz = bs == 1 ? TILE_NNZ : TILE_NNZ / 2;
   int64_t r = 0;
   while (r < n) {
     int64_t r1 = r;
     int64_t base = rowptr[r];
     // always take at least one row (a row longer than TILE_NNZ forms its own tile: "long row" path)
     ++r1;
-    while (r1 < n && (r1 - r) < TILE_ROWS && (rowptr[r1 + 1] - base) <= TILE_NNZ) ++r1;
+    while (r1 < n && (r1 - r) < TILE_ROWS && (rowptr[r1 + 1] - base) <= max_nnz) ++r1;
     tile_row.push_back((int32_t)r1);
     r = r1;
   }
@@ -251,7 +254,7 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
       }
     }
     for (int64_t i = 0; i < nc; ++i)
-      if (pat->rowptr[i + 1] - pat->rowptr[i] > TILE_NNZ) JH_THROW("cell with more than 1023 faces is not supported");
+      if (pat->rowptr[i + 1] - pat->rowptr[i] > TILE_NNZ / 2) JH_THROW("cell with more than 511 faces is not supported");
     pat->build_tiles();
     pat->upload();
     d->d_nz_face.upload(d->nz_face, ctx->stream);
