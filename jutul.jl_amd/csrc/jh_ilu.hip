@@ -614,7 +614,7 @@ __global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const d
   } else if (GM == 2) {
     const double rho = G.sc[G.rho_slot], rho_next = G.sc[G.rho_next_slot];
     const double alpha = rho / G.sc[G.cv_slot];
-    cb = G.sc[G.ts_slot] / G.sc[G.ts_slot + 1];  // omega
+    cb = G.sc[G.ts_slot + 1] == 0.0 ? 0.0 : G.sc[G.ts_slot] / G.sc[G.ts_slot + 1];  // omega (0/0 guard, see bicg_omega)
     ca = (rho_next / rho) * (alpha / cb);        // beta
   }
   for (int t = threadIdx.x; t < nr; t += 64) {

@@ -65,6 +65,9 @@ struct jh_krylov_s {
 };
 
 namespace {
+// omega = <t,s>/<t,t>.  When the first half-step is already exact (s == 0, e.g. ILU(0) == LU on a chain or a 1-cell
+// problem) Krylov.jl's formula is 0/0; the guard makes that case converge (x = x + alpha*y, r = 0) instead of NaN.
+__device__ __forceinline__ double bicg_omega(double ts, double tt) { return tt == 0.0 ? 0.0 : ts / tt; }
 // scalar slots in ctx->scalars
 // (rho, ||r||^2) live in two ping-pong pairs so that one fused reduction can write (rho_next, ||r_next||^2) contiguously
 enum { S_PAIR0 = 0 /* rho, rr */, S_CV = 3, S_TS = 4, S_TT = 5, S_PAIR1 = 6 /* rho, rr */, S_ERR = 8 /* ..10 */ };
@@ -79,7 +82,7 @@ __global__ void bicg_s_kernel(double *s, const double *r, const double *v, const
 __global__ void bicg_xr_kernel(double *x, double *r, const double *y, const double *z, const double *s, const double *t,
                                const double *sc, int rho_slot, int64_t n) {
   const double alpha = sc[rho_slot] / sc[S_CV];
-  const double omega = sc[S_TS] / sc[S_TT];
+  const double omega = bicg_omega(sc[S_TS], sc[S_TT]);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double xi = x[i];
     xi += alpha * y[i];  // x_aux = x + alpha*y
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void bicg_xr_dots_kernel(double *x, double *r,
                                                            int64_t nd, double *part, size_t stride) {
   __shared__ double sm[4];
   const double alpha = sc[rho_slot] / sc[S_CV];
-  const double omega = sc[S_TS] / sc[S_TT];
+  const double omega = bicg_omega(sc[S_TS], sc[S_TT]);
   double d0 = 0.0, d1 = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double xi = x[i];
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void bicg_xr_dots_kernel(double *x, double *r,
 __global__ void bicg_p_kernel(double *p, const double *r, const double *v, const double *sc, int rho_slot, int rho_next_slot, int64_t n) {
   const double rho = sc[rho_slot], rho_next = sc[rho_next_slot];
   const double alpha = rho / sc[S_CV];
-  const double omega = sc[S_TS] / sc[S_TT];
+  const double omega = bicg_omega(sc[S_TS], sc[S_TT]);
   const double beta = (rho_next / rho) * (alpha / omega);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     double pa = p[i] - omega * v[i];

@@ -918,7 +918,9 @@ int jo_bicgstab(I64 n, int bs, const I64 *rowptr, const I64 *colidx, const doubl
     jo_spmv(n, bs, rowptr, colidx, nz, zz, d, 1.0, 0.0);
     const double *tt = d;
     if (left) { jo_ilu0_apply(P, t, d); tt = t; }
-    double omega = dotp(m, tt, s) / dotp(m, tt, tt);
+    double ttn = dotp(m, tt, tt);
+    /* 0/0 guard for an exact first half-step (s == 0): Krylov.jl's formula would give NaN */
+    double omega = (ttn == 0.0) ? 0.0 : dotp(m, tt, s) / ttn;
     for (I64 i = 0; i < m; ++i) x[i] += omega * zz[i];
     for (I64 i = 0; i < m; ++i) r[i] = s[i] - omega * tt[i];
     double rho_next = dotp(m, c, r);

@@ -559,3 +559,72 @@ def test_system_scaling(ja, ctx, oracle, bs):
         ref_blocks = blocks * F[rows][:, :, None]
         assert relerr(A.nzval, ref_blocks.transpose(0, 2, 1).reshape(-1)) < 1e-15
         assert relerr(s.r.download(), (r.reshape(nc, bs) * F).reshape(-1)) < 1e-15
+
+
+# ---- edge cases -----------------------------------------------------------------------------------------------------------------------
+def test_single_cell_no_faces_scalar_kat(ja, ctx):
+    """ScalarTestSystem analogue (test/test_systems/scalar.jl:12-40): one cell, no faces, dX/dt = 1 -> X = 1 after dt = 1 and
+    0.5 after a half step (empty neighborship: get_facepos branch utils.jl:862-866, flux.jl:185-188)."""
+    N = np.zeros((2, 0), dtype=np.int64)
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, 1)
+    assert disc.nnzb == 1 and disc.nhf == 0
+    assert list(disc.conn["face_pos"]) == [1, 1]
+    law = ja.ConservationLaw(disc, "poisson")
+    law.set_state([0.0])
+    law.set_state0([0.0])
+    law.set_sources([1], [-1.0])  # r = (X - X0)/dt - 1
+    sim = ja.Simulator(law, ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(), relative_tolerance=1e-12))
+    assert sim.solve_timestep(0.5) == 2
+    assert np.isclose(law.get_state()[0], 0.5, rtol=1e-14)
+    assert sim.solve_timestep(0.5) == 2
+    assert np.isclose(law.get_state()[0], 1.0, rtol=1e-14)
+
+
+def test_ragged_grid_with_isolated_cells(ja, ctx, oracle):
+    """Cells without any face (isolated) mixed with connected ones: empty rows segments, diagonal-only CSR rows."""
+    N = np.array([[1, 2, 5], [2, 3, 6]], dtype=np.int64)  # cells 4, 7, 8 are isolated
+    nc = 8
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, reorder="blocks", block_rows=3)
+    h = oracle.half_face_map(N, nc)
+    assert np.array_equal(disc.conn["face_pos"], h["face_pos"]) and np.array_equal(disc.conn["other"], h["other"])
+    rp, ci = disc.pattern()
+    orp, oci = oracle.csr_pattern(nc, h)
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
+    rng = np.random.default_rng(5)
+    law = ja.ConservationLaw(disc, "poisson")
+    T, U, U0 = rng.uniform(1, 2, 3), rng.standard_normal(nc), rng.standard_normal(nc)
+    law.set_face_trans(T)
+    law.set_state(U)
+    law.set_state0(U0)
+    lsys = ja.LinearizedSystem(disc)
+    law.update_equation_and_linearized_system(0.3, lsys.jac, lsys.r)
+    osys = oracle.TPFASystem(N, nc)
+    nz_o, r_o = osys.assemble(oracle.Law("poisson", 0.3), U, U0, np.ones(nc), T)
+    assert relerr(lsys.r.download(), r_o) < RTOL and relerr(lsys.jac.nzval, nz_o) < RTOL
+    F = ja.ILUZeroPreconditioner(partition="blocks").update_preconditioner(lsys.jac)
+    x = F.apply(lsys.jac.new_vector(), lsys.r).download()
+    assert np.all(np.isfinite(x))
+
+
+def test_argument_validation(ja, ctx, oracle):
+    nc, rowptr, colidx, nz, rng = random_csr(oracle, (4, 3), 1, seed=51)
+    A = ja.StaticSparsityMatrixCSR(context=ctx, n=nc, bs=1, rowptr=rowptr, colidx=colidx, nzval=nz)
+    with pytest.raises(ja.JutulHIPError):  # partition ids must be >= 1 (par_ilu0.jl:49)
+        ja.ilu0_csr(A, np.zeros(nc, dtype=np.int64))
+    with pytest.raises(ja.JutulHIPError):  # empty block (partitioning.jl:47)
+        p = np.ones(nc, dtype=np.int64)
+        p[0] = 3
+        ja.ilu0_csr(A, p)
+    with pytest.raises(ja.JutulHIPError):  # unsorted columns
+        ja.StaticSparsityMatrixCSR(context=ctx, n=2, bs=1, rowptr=[1, 3, 4], colidx=[2, 1, 2], nzval=[1.0, 2.0, 3.0])
+    g, _ = tet_case(ja, (2, 2, 2))
+    disc1 = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], g["nc"])
+    with pytest.raises(ja.JutulHIPError):  # two-phase law needs block_n = 2
+        ja.ConservationLaw(disc1, "twophase")
+    law = ja.ConservationLaw(disc1, "compressible")
+    lsys = ja.LinearizedSystem(disc1)
+    with pytest.raises(ja.JutulHIPError):  # dt must be positive for the compressible law
+        law.update_equation_and_linearized_system(0.0, lsys.jac, lsys.r)
+    F = ja.ILUZeroPreconditioner()
+    with pytest.raises(Exception):  # apply before update_preconditioner!
+        F.apply(lsys.dx, lsys.r)
