@@ -628,3 +628,28 @@ def test_argument_validation(ja, ctx, oracle):
     F = ja.ILUZeroPreconditioner()
     with pytest.raises(Exception):  # apply before update_preconditioner!
         F.apply(lsys.dx, lsys.r)
+
+
+def test_bitwise_run_to_run_determinism(ja, ctx, oracle):
+    """Owner-computes assembly (no atomics) + ordered two-stage reductions: two identical Newton steps give identical bits
+    (the reference's thread-safety-by-construction, SURVEY section 5 'race detection')."""
+    g, rng = tet_case(ja, (12, 10, 9), seed=61)
+    nc = g["nc"]
+    outs = []
+    for _ in range(2):
+        disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, reorder="blocks", block_rows=256)
+        law = ja.ConservationLaw(disc, "compressible", rho0=(1.0, 1.0), compressibility=(1e-2, 0.0), viscosity=(1.0, 1.0), p_ref=1.0)
+        law.set_face_trans(g["Tn"])
+        law.set_volumes(g["volumes"])
+        law.set_face_gdz(g["gdz"])
+        X0 = 1.0 + 0.1 * np.random.default_rng(7).random(nc)
+        law.set_state(X0)
+        law.set_state0(X0)
+        law.set_sources([1, nc], [0.3, -0.3])
+        sim = ja.Simulator(law, ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"),
+                                                 relative_tolerance=1e-8, max_iterations=200), tolerance=1e-8)
+        ok, its, rep = sim.solve_ministep(0.4)
+        assert ok
+        outs.append((law.get_state(), sim.lsys.jac.nzval, sim.lsys.r.download(), its, rep.linear_iterations))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2]) and outs[0][3:] == outs[1][3:]
