@@ -279,7 +279,26 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
     continue;
   }
   for (int i = tid; i <= nrows; i += TILE_THREADS) rp[i] = rowptr[r0 + i] - base;
-  for (int k = tid; k < cnt; k += TILE_THREADS) {
+  if (BS == 1) {
+    // all (col, val) loads of the lane's entries are issued before the dependent x gathers: 4 + 4 + 4 loads in flight
+    constexpr int KPT = TILE_NNZ / TILE_THREADS;
+    int cidx[KPT];
+    double vv[KPT], xg[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int k = tid + j * TILE_THREADS;
+      cidx[j] = (k < cnt) ? col[base + k] : 0;
+      vv[j] = (k < cnt) ? val[base + k] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) xg[j] = x[cidx[j]];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int k = tid + j * TILE_THREADS;
+      if (k < cnt) prod[k] = vv[j] * xg[j];
+    }
+  }
+  for (int k = tid; k < cnt && BS > 1; k += TILE_THREADS) {
     const int c = col[base + k];
     if (BS == 1) {
       prod[k] = val[base + k] * x[c];
