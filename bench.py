@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--dt", type=float, default=5.0)
     ap.add_argument("--cpu-cells", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    # the same side for every N keeps the scaling series one algorithm; Jutul's IterativeSolverConfig default is :right
+    # (linsolve/utils.jl:25), its MPI extension hard-codes M = prec, i.e. left (ext/.../krylov.jl:60): --precond-side left
+    ap.add_argument("--precond-side", default="right", choices=["left", "right"])
     args = ap.parse_args()
 
     # the contract is ONE JSON line on stdout: NCCL_DEBUG=VERSION (set in this image) makes RCCL print a banner there
@@ -116,7 +119,7 @@ def main():
         law.set_sources(src_cells, src_vals)
     prec = ja.ILUZeroPreconditioner(partition="blocks")
     ks = ja.GenericKrylov("bicgstab", preconditioner=prec, relative_tolerance=args.rtol, max_iterations=100,
-                          precond_side="right" if (world == 1 and not force_dist) else "left")
+                          precond_side=args.precond_side)
     sim = ja.Simulator(law, ks)
     t_setup = time.time() - t_setup
 
@@ -153,7 +156,7 @@ def main():
     kern = {}
     B_asm = 44.0 * n_loc + 20.0 * nhf_loc                      # SURVEY 8(d), N = 1
     # SpMV 12*nnz + 20*n + 8*n for the vector of the fused dot epilogue (<c,q> or <t,s>,<t,t>) on one rank
-    fused = world == 1 and not force_dist
+    fused = args.precond_side == "right"
     B_spmv = 12.0 * nnz_loc + 20.0 * n_loc + (8.0 * n_loc if fused else 0.0)
     # ILU(0) apply: kept factor entries (val 8 + col 4) + D 8 + row pointers 8 + b 8 + x 8 per row; on one rank the
     # BiCGStab s-/p-updates are fused into the gather: the input is rebuilt from r, q (and p) and stored: +20*n on average

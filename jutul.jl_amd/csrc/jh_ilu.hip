@@ -626,11 +626,11 @@ __global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const d
       if (GM == 0) {
         v = bvec[o];
       } else if (GM == 1) {
-        v = G.r[o] - ca * G.q[o];
+        v = (dev < G.n_owned_rows) ? G.r[o] - ca * G.q[o] : 0.0;
         G.out[o] = v;
       } else {
         const double pa = G.out[o] - cb * G.q[o];
-        v = G.r[o] + ca * pa;
+        v = (dev < G.n_owned_rows) ? G.r[o] + ca * pa : 0.0;
         G.out[o] = v;
       }
       xs[t * BS + e] = v;

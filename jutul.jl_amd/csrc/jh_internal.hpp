@@ -226,6 +226,7 @@ struct IluGather {
   double *out = nullptr;    // s (mode 1) or p (mode 2, read-modify-write)
   const double *sc = nullptr;
   int rho_slot = 0, rho_next_slot = 0, cv_slot = 0, ts_slot = 0;
+  int n_owned_rows = 0x7fffffff;  // rows >= n_owned_rows are ghosts: their preconditioner input is zero (linalg.jl:78-88)
 };
 }  // namespace jh
 

@@ -208,7 +208,8 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   int rs = S_PAIR0;                       // pair holding the current (rho, rr); the next one goes to the other pair
   ensure_partials(ctx, 4096);
   // right preconditioning on one rank: the s- and p-updates are fused into the gather phase of the ILU(0) apply
-  const bool fuse = right && !dist && ilu_can_fuse_gather(M);
+  const bool fuse = right && ilu_can_fuse_gather(M);
+  const int ghost_from = dist ? (int)(nd / P.bs) : 0x7fffffff;
   int prev_rs = -1, prev_rn = -1;         // scalar pairs of the previous iteration (deferred p-update)
   while (!solved && it < itmax && status == 0) {
     ++it;
@@ -217,7 +218,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     if (fuse && prev_rs >= 0) {  // p = r + beta*(p - omega*q) of the previous iteration, then y = N^-1 p
       IluGather G;
       G.mode = 2; G.r = K->r.p; G.q = K->q.p; G.out = K->p.p; G.sc = sc;
-      G.rho_slot = prev_rs; G.rho_next_slot = prev_rn; G.cv_slot = S_CV; G.ts_slot = S_TS;
+      G.rho_slot = prev_rs; G.rho_next_slot = prev_rn; G.cv_slot = S_CV; G.ts_slot = S_TS; G.n_owned_rows = ghost_from;
       K->mark(1, st);
       ilu_apply_fused(M, G, K->y.p);
       K->mark(1, st);
@@ -237,7 +238,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     if (fuse) {  // s = r - alpha*q fused into z = N^-1 s
       IluGather G;
       G.mode = 1; G.r = K->r.p; G.q = vv; G.out = K->s.p; G.sc = sc;
-      G.rho_slot = rs; G.cv_slot = S_CV;
+      G.rho_slot = rs; G.cv_slot = S_CV; G.n_owned_rows = ghost_from;
       K->mark(1, st);
       ilu_apply_fused(M, G, K->z.p);
       K->mark(1, st);
