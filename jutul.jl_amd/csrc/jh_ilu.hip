@@ -366,44 +366,9 @@ __device__ __forceinline__ void bwd_row(const IluDev &F, int pos, int lt, double
   }
 }
 
-template <int BS>
-__global__ void ilu_apply_blocks_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec) {
-  extern __shared__ __attribute__((aligned(16))) double xs[];
-  const int b = blockIdx.x;
-  const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
-  const int nr = b1 - b0;
-  for (int t = threadIdx.x; t < nr; t += blockDim.x) {
-    const int dev = F.rowmap[b0 + t];
-#pragma unroll
-    for (int e = 0; e < BS; ++e) xs[t * BS + e] = bvec[(size_t)dev * BS + e];
-  }
-  __syncthreads();
-  {
-    const int l0 = F.flev_off[b], l1 = F.flev_off[b + 1] - 1;
-    for (int lev = l0 + 1; lev < l1; ++lev) {
-      const int s = F.flev_ptr[lev], e = F.flev_ptr[lev + 1];
-      for (int t = s + threadIdx.x; t < e; t += blockDim.x) fwd_row<BS>(F, t, t - b0, xs);
-      __syncthreads();
-    }
-  }
-  {
-    const int l0 = F.blev_off[b], l1 = F.blev_off[b + 1] - 1;
-    for (int lev = l0; lev < l1; ++lev) {
-      const int s = F.blev_ptr[lev], e = F.blev_ptr[lev + 1];
-      for (int pos = s + threadIdx.x; pos < e; pos += blockDim.x) bwd_row<BS>(F, pos, F.u_row[pos], xs);
-      __syncthreads();
-    }
-  }
-  for (int t = threadIdx.x; t < nr; t += blockDim.x) {
-    const int dev = F.rowmap[b0 + t];
-#pragma unroll
-    for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[t * BS + e];
-  }
-}
-
 // ---- software-pipelined LDS apply -------------------------------------------------------------------------------
-// The level loop above is latency-bound: every level issues two dependent global loads (row pointers, then
-// entries) before it can touch LDS.  Nothing but the LDS vector depends on earlier levels, so the factor data of
+// A plain level loop is latency-bound: every level issues two dependent global loads (row pointers, then
+// entries) before it can touch LDS (0.66 ms at 10M cells).  Nothing but the LDS vector depends on earlier levels, so the factor data of
 // level l+1 (entries) and l+2 (row pointers) is fetched into registers while level l computes: the per-level
 // critical path shrinks to LDS latency + one barrier.  Rows longer than PFW entries take a slow tail loop.
 constexpr int PFW = 4;
@@ -1034,25 +999,6 @@ void ilu_apply(jh_ilu M, const double *b, double *x) {
   IluDev F = dev_view(M);
   const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
   if (M->lds_mode) {
-    static const bool no_pf = getenv("JH_ILU_NO_PREFETCH") != nullptr;
-    if (no_pf) {
-      switch (M->bs) {
-        case 1: hipLaunchKernelGGL(ilu_apply_blocks_kernel<1>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
-        case 2: hipLaunchKernelGGL(ilu_apply_blocks_kernel<2>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
-        case 3: hipLaunchKernelGGL(ilu_apply_blocks_kernel<3>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
-      }
-      return;
-    }
-    static const bool no_chunk = getenv("JH_ILU_NO_CHUNK") != nullptr;
-    if (M->threads == 64 && !no_chunk) {
-      IluGather G0;
-      switch (M->bs) {
-        case 1: hipLaunchKernelGGL((ilu_apply_chunked_kernel<1, 0>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x, G0); break;
-        case 2: hipLaunchKernelGGL((ilu_apply_chunked_kernel<2, 0>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x, G0); break;
-        case 3: hipLaunchKernelGGL((ilu_apply_chunked_kernel<3, 0>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x, G0); break;
-      }
-      return;
-    }
     switch (M->bs) {
       case 1: hipLaunchKernelGGL(ilu_apply_blocks_pf_kernel<1>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
       case 2: hipLaunchKernelGGL(ilu_apply_blocks_pf_kernel<2>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;

@@ -351,12 +351,10 @@ extern "C" int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_
     JH_HIP(hipEventElapsedTime(&ms, e0, e1));
     rep->precond_ms = ms;
     JH_HIP(hipEventRecord(e0, st));
-    double hist[2] = {0, 0};
     std::vector<double> h((size_t)itmax + 2, 0.0);
     int64_t iters = 0;
-    // the solve produces x into K's scratch `y`?  no: use dx as the solution vector, then negate in place
+    // dx receives the solution x, then is negated in place
     int status = jh::bicgstab(K, M, M ? side : JH_SIDE_NONE, r->d.p, dx->d.p, rtol, atol, itmax, &iters, h.data(), (int64_t)h.size());
-    (void)hist;
     k_negate(st, dx->d.p, dx->d.p, dx->len);  // update_dx_from_vector!: dx = -x (default.jl:444-446)
     JH_HIP(hipEventRecord(e1, st));
     JH_HIP(hipEventSynchronize(e1));
