@@ -653,3 +653,116 @@ def test_bitwise_run_to_run_determinism(ja, ctx, oracle):
         outs.append((law.get_state(), sim.lsys.jac.nzval, sim.lsys.r.download(), its, rep.linear_iterations))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][2], outs[1][2]) and outs[0][3:] == outs[1][3:]
+
+
+# ---- randomized unstructured graphs (not mesh-like) -----------------------------------------------------------------------------------
+def random_graph(rng, nc, avg_deg):
+    """Random connected simple graph as a neighborship: a random spanning tree plus random extra edges."""
+    edges = set()
+    order = rng.permutation(nc)
+    for i in range(1, nc):
+        a, b = int(order[i]), int(order[rng.integers(0, i)])
+        edges.add((min(a, b), max(a, b)))
+    while len(edges) < nc * avg_deg // 2:
+        a, b = (int(v) for v in rng.integers(0, nc, 2))
+        if a != b:
+            edges.add((min(a, b), max(a, b)))
+    E = np.array(sorted(edges), dtype=np.int64)
+    flip = rng.random(len(E)) < 0.5  # random left/right orientation
+    E[flip] = E[flip][:, ::-1]
+    return (E[rng.permutation(len(E))].T + 1).copy()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_graphs_full_chain_parity(ja, ctx, oracle, seed):
+    """Irregular degrees (1 .. ~25), random orientation and face order: tables bit-exact, assembly / SpMV / ILU(0) /
+    BiCGStab within the fp64 tolerances, for scalar and 2x2-block laws, both device orderings."""
+    rng = np.random.default_rng(100 + seed)
+    nc = int(rng.integers(300, 1500))
+    N = random_graph(rng, nc, avg_deg=int(rng.integers(3, 9)))
+    nf = N.shape[1]
+    kind = ["poisson", "compressible", "twophase", "twophase"][seed]
+    nblk = 2 if kind == "twophase" else 1
+    reorder = "blocks" if seed % 2 else "none"
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, block_n=nblk, reorder=reorder, block_rows=int(rng.integers(16, 200)))
+    osys = oracle.TPFASystem(N, nc, nblk)
+    c = disc.conn
+    assert np.array_equal(c["face_pos"], osys.hfm["face_pos"]) and np.array_equal(c["face"], osys.hfm["faces"])
+    assert np.array_equal(c["other"], osys.hfm["other"]) and np.array_equal(c["face_sign"], osys.hfm["face_sign"])
+    rp, ci = disc.pattern()
+    assert np.array_equal(rp, osys.rowptr) and np.array_equal(ci, osys.colidx)
+    pa, pf = disc.jacobian_positions()
+    assert np.array_equal(pa, osys.pos_acc) and np.array_equal(pf, osys.pos_flux)
+    par = dict(rho0=(1.0, 0.7), compressibility=(2e-2, 1e-2), viscosity=(1.0, 3.0), p_ref=1.0)
+    law = ja.ConservationLaw(disc, kind, **par)
+    T, vol, gdz = rng.uniform(0.2, 3.0, nf), rng.uniform(0.5, 2.0, nc), rng.standard_normal(nf) * 0.05
+    if nblk == 1:
+        X, X0 = rng.uniform(1, 2, nc), rng.uniform(1, 2, nc)
+    else:
+        X = np.stack([rng.uniform(1, 2, nc), rng.uniform(0.2, 0.8, nc)]).T.reshape(-1)
+        X0 = np.stack([rng.uniform(1, 2, nc), rng.uniform(0.2, 0.8, nc)]).T.reshape(-1)
+    law.set_face_trans(T)
+    law.set_volumes(vol)
+    if kind != "poisson":
+        law.set_face_gdz(gdz)
+    law.set_state(X)
+    law.set_state0(X0)
+    dt = 0.37
+    lsys = ja.LinearizedSystem(disc)
+    law.update_equation_and_linearized_system(dt, lsys.jac, lsys.r)
+    olaw = oracle.Law(kind, dt, rho0=par["rho0"], comp=par["compressibility"], mu=par["viscosity"], p_ref=par["p_ref"])
+    nz_o, r_o = osys.assemble(olaw, X, X0, vol, T, gdz if kind != "poisson" else None)
+    assert relerr(lsys.r.download(), r_o) < RTOL and relerr(lsys.jac.nzval, nz_o) < RTOL
+    x = rng.standard_normal(nc * nblk)
+    y = ja.mul_(ja.DeviceVector(disc), lsys.jac, ja.DeviceVector(disc, x), 1.5, 0.0).download()
+    assert relerr(y, oracle.spmv(nc, nblk, osys.rowptr, osys.colidx, nz_o, x, alpha=1.5)) < RTOL
+    if reorder == "none":  # same elimination order as the reference: factors and solves comparable entry by entry
+        F = ja.ilu0_csr(lsys.jac)
+        Fo = oracle.ILU0(nc, nblk, osys.rowptr, osys.colidx, nz_o)
+        lu_o = Fo.export(nz_o.size)
+        assert relerr(F.factor_values(), lu_o) < 1e-10
+        b = rng.standard_normal(nc * nblk)
+        assert relerr(F.apply(lsys.jac.new_vector(), lsys.jac.new_vector(b)).download(), Fo.apply(b)) < 1e-9
+        ks = ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(), relative_tolerance=1e-9, max_iterations=300)
+        out = ja.linear_solve(lsys, ks)
+        xo, st = oracle.bicgstab(nc, nblk, osys.rowptr, osys.colidx, nz_o, r_o, prec=Fo, rtol=1e-9, atol=1e-12, itmax=300)
+        assert out["ok"] and st["solved"] and abs(out["iterations"] - st["iterations"]) <= 1
+        assert relerr(-lsys.dx.download(), xo) < 1e-6
+    else:
+        ks = ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"), relative_tolerance=1e-9,
+                              max_iterations=400)
+        out = ja.linear_solve(lsys, ks)
+        assert out["ok"]
+        res = oracle.spmv(nc, nblk, osys.rowptr, osys.colidx, nz_o, -lsys.dx.download()) - r_o
+        assert np.linalg.norm(res) <= 1e-7 * np.linalg.norm(r_o)
+
+
+def test_time_dependent_poisson_2x2_schedule(ja, ctx, oracle):
+    """test/test_systems/variable_poisson.jl:71-115: time-dependent Poisson on a 2x2 mesh, dt = [0.1, 0.9, 10, 100],
+    K = face trans of k = 1, sources +-1: the report steps are taken with the Newton / ministep control of SURVEY A.8 and the
+    states equal backward-Euler steps computed with dense solves."""
+    geo = oracle.cartesian_geometry((2, 2), (1.0, 1.0))
+    nc = 4
+    h = oracle.half_face_map(geo["N"], nc)
+    Tf = oracle.face_trans(oracle.half_face_trans(geo, np.ones((1, nc)), h), h["faces"], geo["nf"])
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, geo["N"], nc)
+    law = ja.ConservationLaw(disc, "poisson")
+    law.set_face_trans(Tf)
+    U = np.ones(nc)
+    law.set_state(U)
+    law.set_state0(U)
+    law.set_sources([1, nc], [1.0, -1.0])
+    sim = ja.Simulator(law, ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(), relative_tolerance=1e-12))
+    dts = [0.1, 0.9, 10.0, 100.0]
+    its = sim.simulate(dts)
+    assert its == [2, 2, 2, 2]  # linear law: 2 assemblies + 1 solve per ministep, no cuts
+    # dense backward Euler: (I/dt + L) U1 = U0/dt - src
+    L = np.zeros((nc, nc))
+    for f in range(geo["nf"]):
+        a, b = geo["N"][0, f] - 1, geo["N"][1, f] - 1
+        L[a, a] += Tf[f]; L[b, b] += Tf[f]; L[a, b] -= Tf[f]; L[b, a] -= Tf[f]
+    src = np.array([1.0, 0, 0, -1.0])
+    for dt in dts:
+        U = np.linalg.solve(np.eye(nc) / dt + L, U / dt - src)
+    assert np.allclose(law.get_state(), U, rtol=1e-9, atol=1e-9)
+    assert np.isclose(sum(dts), 111.0)
