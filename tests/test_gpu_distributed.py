@@ -173,3 +173,53 @@ def test_ghost_cells_do_not_break_lds_blocks(ja):
     law.update_equation_and_linearized_system(0.5, lsys.jac, lsys.r)
     prec = ja.ILUZeroPreconditioner(partition="blocks").update_preconditioner(lsys.jac)
     assert prec.info()["lds_mode"]
+
+
+def test_eight_ranks_many_neighbours(ja):
+    """8 ranks (the node size the bench targets), RCB parts with up to 7 neighbours each: plan symmetry, ghost consistency and
+    the distributed right-preconditioned Newton step == single rank."""
+    from jutul_amd import dd
+    g, T, X0, _ = problem(ja, dims=(20, 18, 16), seed=3)
+    nc = g["nc"]
+    nranks = 8
+    part = dd.partition_rcb(g["cell_centroids"], nranks)
+    subs = [dd.local_subdomain(g["N"], part, r + 1) for r in range(nranks)]
+    assert max(len(s["neighbors"]) for s in subs) >= 3
+    for r, s in enumerate(subs):  # what r sends to q is what q expects from r, in the same global order
+        for q, snd in zip(s["neighbors"], s["send"]):
+            sq = subs[int(q)]
+            j = list(sq["neighbors"]).index(r)
+            assert np.array_equal(s["cells"][snd - 1], sq["cells"][sq["recv"][j] - 1])
+    dt = 0.5
+    src = ([1, nc], np.array([[1.0], [-1.0]]))
+
+    def make_sim(law):
+        ks = ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"),
+                              relative_tolerance=1e-11, max_iterations=300, precond_side="right")
+        return ja.Simulator(law, ks, tolerance=1e-9)
+
+    ctx0 = ja.HIPContext(0)
+    disc0 = ja.TwoPointPotentialFlowHardCoded(ctx0, g["N"], nc, reorder="blocks", block_rows=256)
+    law0 = ja.ConservationLaw(disc0, "poisson")
+    law0.set_face_trans(T); law0.set_volumes(g["volumes"]); law0.set_state(X0); law0.set_state0(X0)
+    law0.set_sources(src[0], src[1].reshape(-1))
+    ok0, _, _ = make_sim(law0).solve_ministep(dt)
+    assert ok0
+    X_ref = law0.get_state()
+    group = ja.LocalCommGroup(nranks)
+
+    def rank_fn(r):
+        ctx = ja.HIPContext(0)
+        ctx.comm_init_local(group, r)
+        disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, r, T, g["volumes"], X0, sources=src, block_rows=256)
+        ok, its, rep = make_sim(law).solve_ministep(dt)
+        X = law.get_state()
+        ctx.comm_finalize()
+        return ok, sub, X
+
+    X = np.zeros(nc)
+    for ok, sub, Xl in run_ranks(nranks, rank_fn):
+        assert ok
+        X[sub["cells"][: sub["n_owned"]] - 1] = Xl[: sub["n_owned"]]
+        assert np.allclose(Xl[sub["n_owned"]:], X_ref[sub["cells"][sub["n_owned"]:] - 1], rtol=1e-7, atol=1e-9)
+    assert np.abs(X - X_ref).max() <= 1e-7 * np.abs(X_ref).max()
