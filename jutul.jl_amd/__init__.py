@@ -476,17 +476,26 @@ class IterativeSolverConfig:
     """IterativeSolverConfig (linsolve/utils.jl:3-41) with the reference's defaults."""
 
     def __init__(self, relative_tolerance=1e-3, absolute_tolerance=None, max_iterations=100, min_iterations=1,
+                 nonlinear_relative_tolerance=None, relaxed_relative_tolerance=0.1, true_residual=False,
                  precond_side="right", verbose=False):
         assert precond_side in ("left", "right")
+        if min_iterations > 1:
+            raise NotImplementedError("min_iterations > 1 (callback termination, krylov.jl:120-131) is not on the device path")
         self.relative_tolerance = relative_tolerance
         self.absolute_tolerance = absolute_tolerance
         self.max_iterations = max_iterations
         self.min_iterations = min_iterations
+        self.nonlinear_relative_tolerance = nonlinear_relative_tolerance
+        self.relaxed_relative_tolerance = relaxed_relative_tolerance
+        self.true_residual = true_residual
         self.precond_side = precond_side
         self.verbose = verbose
 
     def tolerance(self, variant):  # linear_solver_tolerance (linsolve/utils.jl:43-60)
-        tol = self.relative_tolerance if variant == "relative" else self.absolute_tolerance
+        if variant == "nonlinear_relative":
+            return self.nonlinear_relative_tolerance
+        tol = {"relative": self.relative_tolerance, "absolute": self.absolute_tolerance,
+               "relaxed_relative": self.relaxed_relative_tolerance}[variant]
         return 1e-12 if tol is None else float(tol)
 
 
@@ -502,6 +511,7 @@ class GenericKrylov(_Handle):
         self.solver, self.preconditioner, self.scaling = solver, preconditioner, scaling
         self.config = IterativeSolverConfig(**cfg)
         self.A = None
+        self.r_norm = None  # first-Newton-iteration residual norm for the relaxed tolerance (krylov.jl:107-117)
 
     def _workspace(self, A):
         if self.A is not A:
@@ -547,7 +557,7 @@ def scale_system(sys, scaling, dt=1.0):
     check(_L().jh_scale_system(sys.jac.h, sys.r.h, kind, float(dt)))
 
 
-def linear_solve(sys, krylov, atol=None, rtol=None, update_preconditioner=True, dt=None):
+def linear_solve(sys, krylov, atol=None, rtol=None, update_preconditioner=True, dt=None, subiteration=None):
     """linear_solve!(sys, krylov::GenericKrylov, ...) (linsolve/krylov.jl:71-182): updates the preconditioner,
     runs BiCGStab on sys.r, writes dx = -x.  Returns linear_solve_return-like dict (default.jl:450-465)."""
     cfg = krylov.config
@@ -557,6 +567,17 @@ def linear_solve(sys, krylov, atol=None, rtol=None, update_preconditioner=True, 
     ctx = sys.disc.ctx
     if getattr(krylov, "scaling", "none") != "none":  # krylov_scale_system! (linsolve/krylov.jl:194)
         scale_system(sys, krylov.scaling, 1.0 if dt is None else dt)
+    rtol_nl = cfg.tolerance("nonlinear_relative")
+    use_relaxed = subiteration is not None and rtol_nl is not None
+    if use_relaxed or cfg.true_residual:  # krylov.jl:96-118
+        r_k = sys.r.dot(sys.r) ** 0.5
+        if cfg.true_residual:  # avoid a relative reduction in the preconditioned norm
+            atol, rtol = atol + rtol * r_k, 0.0
+        if use_relaxed:
+            if subiteration == 1:
+                krylov.r_norm = r_k
+            elif krylov.r_norm is not None:
+                rtol = max(min(krylov.r_norm * rtol_nl / r_k, cfg.tolerance("relaxed_relative")), rtol)
     ctx.timer_start()
     if prec is not None and update_preconditioner:
         prec.update_preconditioner(sys.jac)

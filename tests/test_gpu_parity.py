@@ -766,3 +766,32 @@ def test_time_dependent_poisson_2x2_schedule(ja, ctx, oracle):
         U = np.linalg.solve(np.eye(nc) / dt + L, U / dt - src)
     assert np.allclose(law.get_state(), U, rtol=1e-9, atol=1e-9)
     assert np.isclose(sum(dts), 111.0)
+
+
+def test_krylov_tolerance_options(ja, ctx, oracle):
+    """true_residual and the Newton-history relaxed tolerance of linear_solve! (linsolve/krylov.jl:96-118) change only the
+    (atol, rtol) handed to BiCGStab: check them through the residual the solve stops at."""
+    nc, rowptr, colidx, nz, rng = random_csr(oracle, (10, 9, 8), 1, seed=71)
+    b = rng.standard_normal(nc)
+    A = ja.StaticSparsityMatrixCSR(context=ctx, n=nc, bs=1, rowptr=rowptr, colidx=colidx, nzval=nz)
+
+    def solve(sub=None, **cfg):
+        s = type("S", (), {})()
+        s.disc = type("D", (), {"ctx": ctx})()
+        s.jac, s.r, s.dx, s._x = A, A.new_vector(b), A.new_vector(), A.new_vector()
+        ks = solve.ks if sub not in (None, 1) else ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(), **cfg)
+        solve.ks = ks
+        return ja.linear_solve(s, ks, subiteration=sub), ks
+
+    base, _ = solve(relative_tolerance=1e-6, precond_side="left")
+    tr, _ = solve(relative_tolerance=1e-6, precond_side="left", true_residual=True)
+    # true_residual: stop on ||r_prec|| <= atol + rtol*||b|| (unpreconditioned norm of b) instead of a relative reduction
+    assert tr["residuals"][-1] <= 1e-12 + 1e-6 * np.linalg.norm(b) * 1.0001
+    assert tr["iterations"] <= base["iterations"] + 1
+    first, ks = solve(sub=1, relative_tolerance=1e-8, nonlinear_relative_tolerance=1e-2, relaxed_relative_tolerance=0.1)
+    assert ks.r_norm is not None and np.isclose(ks.r_norm, np.linalg.norm(b))
+    second, _ = solve(sub=2)  # same ||r||: rtol = max(min(r0*1e-2/r_k, 0.1), 1e-8) = 1e-2
+    assert second["iterations"] < first["iterations"]
+    assert second["residuals"][-1] <= 1e-12 + 1e-2 * second["residuals"][0] * 1.0001
+    with pytest.raises(NotImplementedError):
+        ja.IterativeSolverConfig(min_iterations=3)
