@@ -192,6 +192,11 @@ int32_t jh_krylov_destroy(jh_krylov K);
  * status: 0 solved, 1 itmax reached, 2 breakdown.  hist: ||r_k||, k = 0..iters (at most hist_cap entries). */
 int32_t jh_bicgstab(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh_vec x, double rtol, double atol, int64_t itmax,
                     int64_t *iters, int32_t *status, double *hist, int64_t hist_cap);
+/* GenericKrylov(:gmres) (linsolve/krylov.jl:214-218; ext/JutulPartitionedArraysExt/krylov.jl:126-148) = Krylov.jl gmres!:
+ * MGS Arnoldi + Givens rotations, restart = false (the basis grows with the iteration count), x0 = 0, same stopping
+ * rule, status and history conventions as jh_bicgstab. */
+int32_t jh_gmres(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh_vec x, double rtol, double atol, int64_t itmax,
+                 int64_t *iters, int32_t *status, double *hist, int64_t hist_cap);
 /* PrecondWrapper-style instrumentation (linsolve/krylov.jl:5-25): accumulated HIP-event time [ms] and launch
  * count of [0] the SpMV and [1] the preconditioner apply inside jh_bicgstab / jh_newton_step.  Reads the
  * totals (ms2/count2 may be NULL), then optionally resets them and enables/disables further profiling. */

@@ -505,8 +505,8 @@ class GenericKrylov(_Handle):
 
     def __init__(self, solver="bicgstab", preconditioner=None, scaling="none", **cfg):
         super().__init__()
-        if solver != "bicgstab":
-            raise NotImplementedError("only :bicgstab is on the MI355X hot path")
+        if solver not in ("bicgstab", "gmres"):
+            raise NotImplementedError("only :bicgstab and :gmres are on the MI355X hot path")
         assert scaling in ("none", "diagonal", "dt")  # GenericKrylov.scaling (linsolve/krylov.jl:27-58)
         self.solver, self.preconditioner, self.scaling = solver, preconditioner, scaling
         self.config = IterativeSolverConfig(**cfg)
@@ -587,8 +587,9 @@ def linear_solve(sys, krylov, atol=None, rtol=None, update_preconditioner=True, 
     hist = np.zeros(cfg.max_iterations + 2)
     side = SIDE[cfg.precond_side] if prec is not None else 0
     ctx.timer_start()
-    check(_L().jh_bicgstab(K, prec.h if prec is not None else None, side, sys.r.h, sys._x.h, float(rtol), float(atol),
-                           int(cfg.max_iterations), C.byref(iters), C.byref(status), pf(hist), hist.size))
+    solve = _L().jh_gmres if krylov.solver == "gmres" else _L().jh_bicgstab
+    check(solve(K, prec.h if prec is not None else None, side, sys.r.h, sys._x.h, float(rtol), float(atol),
+                int(cfg.max_iterations), C.byref(iters), C.byref(status), pf(hist), hist.size))
     check(_L().jh_vec_negate_into(sys.dx.h, sys._x.h))  # update_dx_from_vector!: dx = -x (default.jl:444-446)
     t_solve = ctx.timer_stop_ms()
     n = iters.value

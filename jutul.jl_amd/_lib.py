@@ -92,6 +92,7 @@ SIGNATURES = {
     "jh_krylov_destroy": [H],
     "jh_krylov_profile": [H, C.c_int32, C.c_int32, F64P, I64P],
     "jh_bicgstab": [H, H, C.c_int32, H, H, C.c_double, C.c_double, C.c_int64, I64P, I32P, F64P, C.c_int64],
+    "jh_gmres": [H, H, C.c_int32, H, H, C.c_double, C.c_double, C.c_int64, I64P, I32P, F64P, C.c_int64],
     "jh_newton_step": [H, H, H, H, H, H, C.c_double, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_int64,
                        C.c_int32, C.POINTER(NewtonReport)],
     "jh_comm_unique_id": [C.c_char_p],

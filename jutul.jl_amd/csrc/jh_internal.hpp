@@ -190,6 +190,7 @@ void k_gather_blocks(hipStream_t s, double *dst, const double *src, const int32_
 // dot products: result(s) land in ctx->scalars[slot..]; deterministic two-stage reduction
 void k_dot(jh_context ctx, const double *a, const double *b, int64_t n, int slot);
 void k_dot2(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, int slot);
+void k_dot2_to(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, double *out);
 void k_absmax_strided(jh_context ctx, const double *r, int64_t ncell, int bs, int slot);
 double read_scalar(jh_context ctx, int slot);                  // sync + D2H
 void read_scalars(jh_context ctx, int slot, int count, double *out);

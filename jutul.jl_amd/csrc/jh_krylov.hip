@@ -8,6 +8,7 @@
 // test ||r|| <= atol + rtol*||r0||.
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "jh_internal.hpp"
@@ -28,6 +29,11 @@ struct jh_krylov_s {
   int64_t len = 0;      // doubles per vector
   int64_t len_dot = 0;  // owned part (dots / norms)
   DevBuf<double> r, p, c, s, q, y, z, d, v, t;
+  // GMRES workspace: Krylov basis (grows on demand, Krylov.jl `restart = false`), device/pinned Hessenberg column
+  std::vector<std::unique_ptr<DevBuf<double>>> gV;
+  DevBuf<double> gh;
+  double *gh_host = nullptr;
+  size_t gh_cap = 0;
   // optional in-solve profiling with HIP events on the context stream (PrecondWrapper-style time/count,
   // linsolve/krylov.jl:5-25): [0] spmv, [1] preconditioner apply
   bool profiling = false;
@@ -38,6 +44,7 @@ struct jh_krylov_s {
   int64_t prof_cnt[2] = {0, 0};
   ~jh_krylov_s() {
     for (auto e : ev_pool) (void)hipEventDestroy(e);
+    if (gh_host) (void)hipHostFree(gh_host);
   }
   void mark(int kind, hipStream_t st) {  // call before and after the profiled launch
     if (!profiling) return;
@@ -285,7 +292,140 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   return status;
 }
 
+// w -= h*v with h read from device memory (modified Gram-Schmidt step; no host round trip between the dot and the update)
+__global__ void gmres_axpy_dev_kernel(double *w, const double *v, const double *h, int64_t n) {
+  const double a = *h;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) w[i] -= a * v[i];
+}
+
+// GMRES (Krylov.jl 0.9 `gmres!`, third-party, restated from its published algorithm: MGS Arnoldi + Givens rotations,
+// restart = false, x0 = 0, stop on |zeta_{k+1}| <= atol + rtol*||r0||; call sites linsolve/krylov.jl:214-218 and
+// ext/JutulPartitionedArraysExt/krylov.jl:126-148).  side as in bicgstab.  Returns 0 solved / 1 itmax / 2 breakdown.
+int gmres(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, double rtol, double atol, int64_t itmax,
+          int64_t *iters_out, double *hist, int64_t hist_cap) {
+  jh_context ctx = K->ctx;
+  hipStream_t st = ctx->stream;
+  const Pattern &P = *K->A->pat;
+  jh_tpfa disc = K->A->disc;
+  const bool dist = disc && disc->halo.active;
+  if (dist) K->len_dot = disc->halo.n_owned * P.bs;
+  const int64_t n = K->len, nd = K->len_dot;
+  const bool left = (side == JH_SIDE_LEFT) && M, right = (side == JH_SIDE_RIGHT) && M;
+  if (K->v.n == 0) { K->v.alloc(n); K->t.alloc(n); }
+  if (K->gh_cap < (size_t)itmax + 4) {
+    if (K->gh_host) (void)hipHostFree(K->gh_host);
+    K->gh_cap = (size_t)itmax + 4;
+    K->gh.alloc(K->gh_cap);
+    JH_HIP(hipHostMalloc((void **)&K->gh_host, K->gh_cap * sizeof(double), hipHostMallocDefault));
+  }
+  auto basis = [&](size_t j) -> double * {
+    while (K->gV.size() <= j) { K->gV.emplace_back(new DevBuf<double>()); K->gV.back()->alloc(n); }
+    return K->gV[j]->p;
+  };
+  auto prec = [&](double *in, double *out) {
+    if (dist && n > nd) k_fill(st, in + nd, n - nd, 0.0);
+    K->mark(1, st);
+    ilu_apply(M, in, out);
+    K->mark(1, st);
+  };
+  auto dot_to = [&](const double *a, const double *bb, double *out) {
+    k_dot2_to(ctx, a, bb, nullptr, nullptr, nd, out);
+    comm_allreduce_dev(ctx, out, 1, 0);
+  };
+  auto read = [&](int count) {
+    JH_HIP(hipMemcpyAsync(K->gh_host, K->gh.p, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    JH_HIP(hipStreamSynchronize(st));
+  };
+  double *w = K->q.p, *tmp = K->v.p, *pp = K->t.p;
+  k_fill(st, x, n, 0.0);
+  k_copy(st, tmp, b_in, n);
+  if (dist) halo_exchange(disc, tmp, P.bs);
+  if (left) prec(tmp, w); else k_copy(st, w, tmp, n);  // r0 = M^-1 b
+  dot_to(w, w, K->gh.p);
+  read(1);
+  const double beta = std::sqrt(K->gh_host[0]);
+  const double eps = atol + rtol * beta;
+  if (hist && hist_cap > 0) hist[0] = beta;
+  int64_t it = 0;
+  int status = 0;
+  bool solved = beta <= eps;
+  std::vector<double> R, cs, sn, z;  // R packed by columns: column k holds k+1 entries
+  std::vector<size_t> colptr(1, 0);
+  z.push_back(beta);
+  if (!solved) k_axpby(st, basis(0), 1.0 / beta, w, 0.0, n);
+  while (!solved && it < itmax && status == 0) {
+    const size_t k = (size_t)it;
+    ++it;
+    double *vk = basis(k);
+    double *in = vk;
+    if (right) { k_copy(st, tmp, vk, n); prec(tmp, pp); in = pp; }
+    else if (dist) { k_copy(st, pp, vk, n); in = pp; }  // the halo exchange writes ghost entries: keep the basis vector intact
+    if (dist) halo_exchange(disc, in, P.bs);
+    K->mark(0, st);
+    k_spmv(ctx, P, K->A->val.p, in, w, 1.0, 0.0);
+    K->mark(0, st);
+    if (left) { prec(w, tmp); k_copy(st, w, tmp, n); }
+    for (size_t i = 0; i <= k; ++i) {  // modified Gram-Schmidt
+      dot_to(basis(i), w, K->gh.p + i);
+      hipLaunchKernelGGL(gmres_axpy_dev_kernel, vgrid(n), dim3(256), 0, st, w, basis(i), K->gh.p + i, n);
+    }
+    dot_to(w, w, K->gh.p + k + 1);
+    read((int)k + 2);
+    std::vector<double> h(K->gh_host, K->gh_host + k + 1);
+    const double hbis = std::sqrt(K->gh_host[k + 1]);
+    for (size_t i = 0; i < k; ++i) {  // previous rotations
+      const double a = cs[i] * h[i] + sn[i] * h[i + 1];
+      h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+      h[i] = a;
+    }
+    const double rr = std::hypot(h[k], hbis);  // sym_givens
+    const double c = rr == 0.0 ? 1.0 : h[k] / rr, s2 = rr == 0.0 ? 0.0 : hbis / rr;
+    cs.push_back(c);
+    sn.push_back(s2);
+    h[k] = rr;
+    R.insert(R.end(), h.begin(), h.end());
+    colptr.push_back(R.size());
+    z.push_back(-s2 * z[k]);
+    z[k] = c * z[k];
+    const double rnorm = std::fabs(z[k + 1]);
+    if (hist && it < hist_cap) hist[it] = rnorm;
+    solved = rnorm <= eps;
+    if (!solved) {
+      if (hbis == 0.0) { status = 2; break; }
+      k_axpby(st, basis(k + 1), 1.0 / hbis, w, 0.0, n);
+    }
+  }
+  // y = R \ z, x = N^-1 (V y)
+  const size_t m = cs.size();
+  std::vector<double> y(m);
+  for (size_t jj = m; jj-- > 0;) {
+    double acc = z[jj];
+    for (size_t l = jj + 1; l < m; ++l) acc -= R[colptr[l] + jj] * y[l];
+    y[jj] = acc / R[colptr[jj] + jj];
+  }
+  k_fill(st, tmp, n, 0.0);
+  for (size_t jj = 0; jj < m; ++jj) k_axpby(st, tmp, y[jj], basis(jj), 1.0, n);
+  if (right) prec(tmp, x); else k_copy(st, x, tmp, n);
+  if (dist) halo_exchange(disc, x, P.bs);
+  if (solved) status = 0;
+  else if (status == 0 && it >= itmax) status = 1;
+  *iters_out = it;
+  K->collect();
+  JH_HIP(hipGetLastError());
+  return status;
+}
+
 }  // namespace jh
+
+extern "C" int32_t jh_gmres(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh_vec x, double rtol, double atol, int64_t itmax,
+                            int64_t *iters, int32_t *status, double *hist, int64_t hist_cap) {
+  return guard([&] {
+    if (!K || !b || !x || !iters || !status) JH_THROW("null argument");
+    if (b->len != K->len || x->len != K->len) JH_THROW("dimension mismatch in gmres");
+    JH_HIP(hipSetDevice(K->ctx->device));
+    *status = jh::gmres(K, M, side, b->d.p, x->d.p, rtol, atol, itmax, iters, hist, hist_cap);
+  });
+}
 
 extern "C" int32_t jh_krylov_profile(jh_krylov K, int32_t enable, int32_t reset, double *ms2, int64_t *count2) {
   return guard([&] {

@@ -939,6 +939,80 @@ int jo_bicgstab(I64 n, int bs, const I64 *rowptr, const I64 *colidx, const doubl
   return status;
 }
 
+/* GMRES (Krylov.jl 0.9 `gmres!`, third-party, restated from its published algorithm: MGS Arnoldi + Givens rotations,
+ * restart = false so the basis grows with the iterations, x0 = 0; call site src/linsolve/krylov.jl:214-218).
+ * Same conventions as jo_bicgstab.  "Parity unpinned" per iterate. */
+int jo_gmres(I64 n, int bs, const I64 *rowptr, const I64 *colidx, const double *nz, const jo_ilu_par *P, int side,
+             const double *b, double *x, double rtol, double atol, I64 itmax, I64 *iters_out, double *hist, I64 hist_cap) {
+  I64 m = n * bs;
+  int left = (side == 1 && P), right = (side == 2 && P);
+  double *V = (double *)calloc((size_t)m * (size_t)(itmax + 1), sizeof(double));
+  double *w = (double *)calloc((size_t)m, sizeof(double)), *tmp = (double *)calloc((size_t)m, sizeof(double));
+  double *R = (double *)calloc((size_t)(itmax + 1) * (size_t)(itmax + 1), sizeof(double));
+  double *cs = (double *)calloc((size_t)itmax + 1, sizeof(double)), *sn = (double *)calloc((size_t)itmax + 1, sizeof(double));
+  double *z = (double *)calloc((size_t)itmax + 2, sizeof(double)), *h = (double *)calloc((size_t)itmax + 2, sizeof(double));
+  for (I64 i = 0; i < m; ++i) x[i] = 0.0;
+  if (left) jo_ilu0_apply(P, w, b); else memcpy(w, b, sizeof(double) * m);
+  double beta = sqrt(dotp(m, w, w));
+  double eps = atol + rtol * beta;
+  if (hist && hist_cap > 0) hist[0] = beta;
+  I64 it = 0, ld = itmax + 1;
+  int status = 0, solved = beta <= eps;
+  z[0] = beta;
+  if (!solved) for (I64 i = 0; i < m; ++i) V[i] = w[i] / beta;
+  while (!solved && it < itmax && status == 0) {
+    I64 k = it++;
+    const double *vk = V + (size_t)k * m;
+    const double *in = vk;
+    if (right) { jo_ilu0_apply(P, tmp, vk); in = tmp; }
+    jo_spmv(n, bs, rowptr, colidx, nz, in, w, 1.0, 0.0);
+    if (left) { jo_ilu0_apply(P, tmp, w); memcpy(w, tmp, sizeof(double) * m); }
+    for (I64 i = 0; i <= k; ++i) {
+      const double *vi = V + (size_t)i * m;
+      h[i] = dotp(m, vi, w);
+      for (I64 l = 0; l < m; ++l) w[l] -= h[i] * vi[l];
+    }
+    double hbis = sqrt(dotp(m, w, w));
+    for (I64 i = 0; i < k; ++i) {
+      double a = cs[i] * h[i] + sn[i] * h[i + 1];
+      h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+      h[i] = a;
+    }
+    double rr = hypot(h[k], hbis);
+    cs[k] = rr == 0.0 ? 1.0 : h[k] / rr;
+    sn[k] = rr == 0.0 ? 0.0 : hbis / rr;
+    h[k] = rr;
+    for (I64 i = 0; i <= k; ++i) R[(size_t)k * ld + i] = h[i];
+    z[k + 1] = -sn[k] * z[k];
+    z[k] = cs[k] * z[k];
+    double rnorm = fabs(z[k + 1]);
+    if (hist && it < hist_cap) hist[it] = rnorm;
+    solved = rnorm <= eps;
+    if (!solved) {
+      if (hbis == 0.0) { status = 2; break; }
+      double *vn = V + (size_t)(k + 1) * m;
+      for (I64 l = 0; l < m; ++l) vn[l] = w[l] / hbis;
+    }
+  }
+  I64 mm = it;
+  if (status == 2) mm = it;  /* the last column was completed before the breakdown test */
+  for (I64 j = mm - 1; j >= 0; --j) {
+    double acc = z[j];
+    for (I64 l = j + 1; l < mm; ++l) acc -= R[(size_t)l * ld + j] * h[l];
+    h[j] = acc / R[(size_t)j * ld + j];  /* h reused as y */
+  }
+  for (I64 i = 0; i < m; ++i) tmp[i] = 0.0;
+  for (I64 j = 0; j < mm; ++j) {
+    const double *vj = V + (size_t)j * m;
+    for (I64 l = 0; l < m; ++l) tmp[l] = h[j] * vj[l] + tmp[l];
+  }
+  if (right) jo_ilu0_apply(P, x, tmp); else memcpy(x, tmp, sizeof(double) * m);
+  if (solved) status = 0; else if (status == 0 && it >= itmax) status = 1;
+  *iters_out = it;
+  free(V); free(w); free(tmp); free(R); free(cs); free(sn); free(z); free(h);
+  return status;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Partition helpers (src/partitioning.jl)                                                    */
 /* ------------------------------------------------------------------------------------------ */

@@ -370,6 +370,17 @@ def bicgstab(n, bs, rowptr, colidx, nz, b, prec=None, side="right", rtol=1e-3, a
     return x, dict(status=st, solved=(st == 0), iterations=iters.value, residuals=hist[: iters.value + 1].copy())
 
 
+def gmres(n, bs, rowptr, colidx, nz, b, prec=None, side="right", rtol=1e-3, atol=1e-12, itmax=100):
+    x = np.zeros(n * bs)
+    iters = C.c_int64(0)
+    hist = np.zeros(itmax + 2)
+    st = lib().jo_gmres(C.c_int64(n), C.c_int(bs), _pi(_i(rowptr)), _pi(_i(colidx)), _pf(_f(nz)),
+                        prec.h if prec is not None else None, C.c_int(SIDE[side] if prec is not None else 0),
+                        _pf(_f(b)), _pf(x), C.c_double(rtol), C.c_double(atol), C.c_int64(itmax), C.byref(iters),
+                        _pf(hist), C.c_int64(hist.size))
+    return x, dict(status=st, solved=(st == 0), iterations=iters.value, residuals=hist[: iters.value + 1].copy())
+
+
 # ---------------------------------------------------------------------------------------------------
 # partition / distributed helpers
 # ---------------------------------------------------------------------------------------------------

@@ -223,3 +223,51 @@ def test_eight_ranks_many_neighbours(ja):
         X[sub["cells"][: sub["n_owned"]] - 1] = Xl[: sub["n_owned"]]
         assert np.allclose(Xl[sub["n_owned"]:], X_ref[sub["cells"][sub["n_owned"]:] - 1], rtol=1e-7, atol=1e-9)
     assert np.abs(X - X_ref).max() <= 1e-7 * np.abs(X_ref).max()
+
+
+def test_distributed_gmres_matches_single_rank(ja):
+    """GMRES is the second Krylov method of the reference's distributed path (ext/.../krylov.jl:126-148)."""
+    from jutul_amd import dd
+    g, T, X0, _ = problem(ja, dims=(9, 8, 7), seed=5)
+    nc = g["nc"]
+    src = ([1, nc], np.array([[1.0], [-1.0]]))
+    dt = 0.5
+
+    def run_one(ctx, disc, law):
+        lsys = ja.LinearizedSystem(disc)
+        law.synchronize_ghosts() if disc.n_owned < disc.nc else None
+        law.update_equation_and_linearized_system(dt, lsys.jac, lsys.r)
+        if disc.n_owned < disc.nc:
+            ja._lib.check(ja._lib.load().jh_unit_diagonalize(lsys.jac.h, lsys.r.h, disc.n_owned))
+        ks = ja.GenericKrylov("gmres", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"), relative_tolerance=1e-11,
+                              max_iterations=150, precond_side="left")
+        out = ja.linear_solve(lsys, ks)
+        return out, lsys.dx.download()
+
+    ctx0 = ja.HIPContext(0)
+    disc0 = ja.TwoPointPotentialFlowHardCoded(ctx0, g["N"], nc, reorder="blocks", block_rows=128)
+    law0 = ja.ConservationLaw(disc0, "poisson")
+    law0.set_face_trans(T); law0.set_volumes(g["volumes"]); law0.set_state(X0); law0.set_state0(X0)
+    law0.set_sources(src[0], src[1].reshape(-1))
+    out0, dx_ref = run_one(ctx0, disc0, law0)
+    assert out0["ok"]
+    nranks = 3
+    part = dd.partition_rcb(g["cell_centroids"], nranks)
+    group = ja.LocalCommGroup(nranks)
+
+    def rank_fn(r):
+        ctx = ja.HIPContext(0)
+        ctx.comm_init_local(group, r)
+        disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, r, T, g["volumes"], X0, sources=src, block_rows=128)
+        out, dx = run_one(ctx, disc, law)
+        ctx.comm_finalize()
+        return out, sub, dx
+
+    dx = np.zeros(nc)
+    its = set()
+    for out, sub, dxl in run_ranks(nranks, rank_fn):
+        assert out["ok"]
+        its.add(out["iterations"])
+        dx[sub["cells"][: sub["n_owned"]] - 1] = dxl[: sub["n_owned"]]
+    assert len(its) == 1
+    assert np.abs(dx - dx_ref).max() <= 1e-7 * np.abs(dx_ref).max()

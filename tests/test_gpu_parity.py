@@ -795,3 +795,30 @@ def test_krylov_tolerance_options(ja, ctx, oracle):
     assert second["residuals"][-1] <= 1e-12 + 1e-2 * second["residuals"][0] * 1.0001
     with pytest.raises(NotImplementedError):
         ja.IterativeSolverConfig(min_iterations=3)
+
+
+# ---- GMRES -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("side", ["right", "left"])
+@pytest.mark.parametrize("bs", [1, 2])
+def test_gmres_parity(ja, ctx, oracle, side, bs):
+    nc, rowptr, colidx, nz, rng = random_csr(oracle, (11, 9, 8), bs, seed=81)
+    b = rng.standard_normal(nc * bs)
+    A = ja.StaticSparsityMatrixCSR(context=ctx, n=nc, bs=bs, rowptr=rowptr, colidx=colidx, nzval=nz)
+    s = type("S", (), {})()
+    s.disc = type("D", (), {"ctx": ctx})()
+    s.jac, s.r, s.dx, s._x = A, A.new_vector(b), A.new_vector(), A.new_vector()
+    ks = ja.GenericKrylov("gmres", preconditioner=ja.ILUZeroPreconditioner(), relative_tolerance=1e-9, absolute_tolerance=1e-14,
+                          max_iterations=80, precond_side=side)
+    out = ja.linear_solve(s, ks)
+    Fo = oracle.ILU0(nc, bs, rowptr, colidx, nz)
+    xo, st = oracle.gmres(nc, bs, rowptr, colidx, nz, b, prec=Fo, side=side, rtol=1e-9, atol=1e-14, itmax=80)
+    assert out["ok"] and st["solved"] and abs(out["iterations"] - st["iterations"]) <= 1
+    assert relerr(-s.dx.download(), xo) < 1e-7
+    n = min(len(out["residuals"]), len(st["residuals"]))
+    assert np.allclose(out["residuals"][: n - 1], st["residuals"][: n - 1], rtol=1e-6, atol=1e-12 * st["residuals"][0])
+    r = oracle.spmv(nc, bs, rowptr, colidx, nz, -s.dx.download()) - b
+    assert np.linalg.norm(r) <= 1e-7 * np.linalg.norm(b)
+    # itmax reached
+    ks2 = ja.GenericKrylov("gmres", preconditioner=None, relative_tolerance=1e-14, max_iterations=4)
+    out2 = ja.linear_solve(s, ks2)
+    assert not out2["ok"] and out2["iterations"] == 4 and out2["status"] == 1

@@ -442,3 +442,24 @@ def test_unit_diagonalize(oracle):
     assert np.all(r2[12:] == 0) and np.all(r2[:12] == 1)
     A0 = dense_from_csr(nc, 2, rowptr, colidx, nz)
     assert np.array_equal(A[:12], A0[:12])
+
+
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_gmres_converges_and_residual_history_is_true_residual(oracle, side):
+    """GMRES (Krylov.jl gmres!, third party): the Givens-recurrence residual equals the true (preconditioned) residual
+    norm, the history is non-increasing, and without restarts it converges in <= n iterations."""
+    nc, rowptr, colidx, nz = random_system(oracle, (6, 5, 4), 1, seed=17)
+    A = dense_from_csr(nc, 1, rowptr, colidx, nz)
+    b = np.random.default_rng(18).standard_normal(nc)
+    F = oracle.ILU0(nc, 1, rowptr, colidx, nz)
+    x, st = oracle.gmres(nc, 1, rowptr, colidx, nz, b, prec=F, side=side, rtol=1e-10, atol=1e-14, itmax=60)
+    assert st["solved"] and st["iterations"] < 25
+    res = st["residuals"]
+    assert np.all(np.diff(res) <= 1e-12 * res[0])
+    r = b - A @ x
+    rn = np.linalg.norm(F.apply(r)) if side == "left" else np.linalg.norm(r)
+    assert abs(rn - res[-1]) <= 1e-8 * res[0]
+    xb, stb = oracle.bicgstab(nc, 1, rowptr, colidx, nz, b, prec=F, side=side, rtol=1e-10, atol=1e-14, itmax=100)
+    assert np.allclose(x, xb, rtol=1e-6, atol=1e-8)
+    x0, st0 = oracle.gmres(nc, 1, rowptr, colidx, nz, b, prec=None, rtol=1e-10, atol=1e-14, itmax=nc)
+    assert st0["solved"] and st0["iterations"] <= nc
