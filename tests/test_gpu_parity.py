@@ -822,3 +822,34 @@ def test_gmres_parity(ja, ctx, oracle, side, bs):
     ks2 = ja.GenericKrylov("gmres", preconditioner=None, relative_tolerance=1e-14, max_iterations=4)
     out2 = ja.linear_solve(s, ks2)
     assert not out2["ok"] and out2["iterations"] == 4 and out2["status"] == 1
+
+
+def test_no_device_memory_leak_over_handle_lifetimes(ja, ctx, oracle):
+    """Handles own their device memory: repeated create / use / destroy cycles do not grow the device footprint."""
+    import gc
+    import torch
+    g, rng = tet_case(ja, (14, 12, 10), seed=91)
+    nc = g["nc"]
+
+    def cycle():
+        disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, reorder="blocks", block_rows=256)
+        law = ja.ConservationLaw(disc, "poisson")
+        law.set_face_trans(g["Tn"])
+        law.set_state(np.ones(nc))
+        law.set_state0(np.ones(nc))
+        law.set_sources([1, nc], [1.0, -1.0])
+        sim = ja.Simulator(law, ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks")))
+        sim.solve_timestep(1.0)
+        for obj in (sim.linear_solver.preconditioner, sim.linear_solver, sim.lsys.jac, sim.lsys.r, sim.lsys.dx, sim.lsys._x, law, disc):
+            obj.close()
+
+    cycle()
+    gc.collect()
+    ctx.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(10):
+        cycle()
+    gc.collect()
+    ctx.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20  # < 8 MiB drift (allocator granularity), one cycle allocates > 100 MiB
