@@ -114,8 +114,15 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(SO_PATH):
-        raise JutulHIPError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                            "(there is no CPU fallback)")
+        try:  # the build is in-tree and cheap (hipcc cross-compiles gfx950 without a GPU)
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("jh_build", os.path.join(_HERE, "build.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mod.build()
+        except Exception as e:  # noqa: BLE001
+            raise JutulHIPError(f"{SO_PATH} is missing and could not be built ({e}); run "
+                                "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)") from e
     try:
         import torch  # noqa: F401  (loads libamdhip64 / librccl that torch ships; ours then binds to the same)
     except Exception:
