@@ -77,6 +77,24 @@ function setup_equation_storage(model::SimulationModel{<:Any, <:Any, <:Any, HIPC
     return HIPConservationLawStorage(disc[], law[], jac[], r[], dx[], nc, ne, NaN)
 end
 
+# ---- linearized system (seam: setup_linearized_system!, models.jl:654-668; LinearizedSystem, linsolve/default.jl:34-42) -----
+# The Jacobian / residual / increment live on the device behind the equation storage's handles; this wrapper is what
+# `storage[:LinearizedSystem]` holds so that `linear_solve!(sys, ...)` dispatches here.
+struct HIPLinearizedSystem <: Jutul.JutulLinearSystem
+    eq_s::HIPConservationLawStorage
+    r_buffer::Vector{Float64}    # host mirrors, filled only on request (check_convergence on the host, debugging)
+    dx_buffer::Vector{Float64}
+end
+
+function Jutul.setup_linearized_system!(storage, model::SimulationModel{<:Any, <:Any, <:Any, HIPContext})
+    eq_s = first(values(storage[:equations]))::HIPConservationLawStorage   # single conservation law per model on this path
+    n = eq_s.nc * eq_s.N
+    lsys = HIPLinearizedSystem(eq_s, zeros(n), zeros(n))
+    storage[:LinearizedSystem] = lsys
+    return lsys
+end
+Jutul.align_equations_to_linearized_system!(storage, model::SimulationModel{<:Any, <:Any, <:Any, HIPContext}; kwarg...) = nothing
+
 # pattern / alignment: the library owns the device pattern; the host tables are available bit-exact if Jutul needs
 # them (conservation.jl:486-505, :143-216)
 function declare_pattern(model, eq::ConservationLaw, s::HIPConservationLawStorage, ::Cells)
@@ -133,9 +151,10 @@ mutable struct HIPKrylov
     handle::Ptr{Cvoid}
     HIPKrylov() = new(C_NULL)
 end
-function linear_solve!(s::HIPConservationLawStorage, krylov::GenericKrylov, context::HIPContext, model, storage = nothing,
+function linear_solve!(sys::HIPLinearizedSystem, krylov::GenericKrylov, context::HIPContext, model, storage = nothing,
         dt = nothing, recorder = nothing, executor = nothing; dx = nothing, r = nothing,
         atol = Jutul.linear_solver_tolerance(krylov, :absolute), rtol = Jutul.linear_solver_tolerance(krylov, :relative), kwarg...)
+    s = sys.eq_s
     prec = krylov.preconditioner::HIPILUZero
     t_prec = @elapsed update_preconditioner!(prec, s, nothing, context, executor)
     ws = krylov.storage
@@ -149,7 +168,11 @@ function linear_solve!(s::HIPConservationLawStorage, krylov::GenericKrylov, cont
     iters = Ref{Int64}(0); status = Ref{Int32}(0)
     hist = zeros(cfg.max_iterations + 2)
     x = s.dx  # solution lands in dx, then negated in place (update_dx_from_vector!, default.jl:444-446)
-    @jh :jh_bicgstab (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int64, Ref{Int64}, Ref{Int32}, Ptr{Float64}, Int64) ws.handle prec.handle side s.r x rtol atol cfg.max_iterations iters status hist length(hist)
+    if krylov.solver == :gmres   # the reference's second Krylov method (linsolve/krylov.jl:214-218)
+        @jh :jh_gmres (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int64, Ref{Int64}, Ref{Int32}, Ptr{Float64}, Int64) ws.handle prec.handle side s.r x rtol atol cfg.max_iterations iters status hist length(hist)
+    else
+        @jh :jh_bicgstab (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Int64, Ref{Int64}, Ref{Int32}, Ptr{Float64}, Int64) ws.handle prec.handle side s.r x rtol atol cfg.max_iterations iters status hist length(hist)
+    end
     @jh :jh_vec_negate_into (Ptr{Cvoid}, Ptr{Cvoid}) s.dx x
     n = iters[]
     solved = status[] == 0
