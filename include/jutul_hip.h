@@ -199,7 +199,9 @@ int32_t jh_gmres(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh_vec x, double
                  int64_t *iters, int32_t *status, double *hist, int64_t hist_cap);
 /* PrecondWrapper-style instrumentation (linsolve/krylov.jl:5-25): accumulated HIP-event time [ms] and launch
  * count of [0] the SpMV and [1] the preconditioner apply inside jh_bicgstab / jh_newton_step.  Reads the
- * totals (ms2/count2 may be NULL), then optionally resets them and enables/disables further profiling. */
+ * totals (ms2/count2 may be NULL), then optionally resets them and enables/disables further profiling.
+ * enable = n > 1 times the launches of every n-th Krylov iteration only (an event pair costs ~4.5 us of stream time,
+ * which is visible on small per-GPU problems); enable = 1 times every launch. */
 int32_t jh_krylov_profile(jh_krylov K, int32_t enable, int32_t reset, double *ms2, int64_t *count2);
 /* update_dx_from_vector! (linsolve/default.jl:444-446): dx = -x */
 int32_t jh_vec_negate_into(jh_vec dx, jh_vec x);

@@ -521,10 +521,11 @@ class GenericKrylov(_Handle):
         return self.h
 
     def profile(self, enable=True, reset=True):
-        """PrecondWrapper-like counters: dict(spmv_ms, spmv_count, precond_ms, precond_count) since last reset."""
+        """PrecondWrapper-like counters: dict(spmv_ms, spmv_count, precond_ms, precond_count) since last reset.
+        enable = n > 1 times the launches of every n-th Krylov iteration only (cheaper on small problems)."""
         ms = np.zeros(2)
         cnt = np.zeros(2, dtype=np.int64)
-        check(_L().jh_krylov_profile(self.h, 1 if enable else 0, 1 if reset else 0, pf(ms), pi(cnt)))
+        check(_L().jh_krylov_profile(self.h, int(enable), 1 if reset else 0, pf(ms), pi(cnt)))
         return dict(spmv_ms=ms[0], spmv_count=int(cnt[0]), precond_ms=ms[1], precond_count=int(cnt[1]))
 
 

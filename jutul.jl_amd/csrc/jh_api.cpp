@@ -35,6 +35,8 @@ extern "C" int32_t jh_context_create(int32_t device_id, jh_context *out) {
     c->scalars.alloc(32);
     JH_HIP(hipMemsetAsync(c->scalars.p, 0, 32 * sizeof(double), c->stream));
     JH_HIP(hipHostMalloc((void **)&c->h_scalars, 32 * sizeof(double), hipHostMallocDefault));
+    JH_HIP(hipHostMalloc((void **)&c->h_pub, 2 * jh::JH_PUB_LEN * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_pub, 0, 2 * jh::JH_PUB_LEN * sizeof(double));
     JH_HIP(hipStreamSynchronize(c->stream));
     *out = c.release();
   });
@@ -48,6 +50,7 @@ extern "C" int32_t jh_context_destroy(jh_context ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+    if (ctx->h_pub) (void)hipHostFree(ctx->h_pub);
     ctx->partials.release();
     ctx->scalars.release();
     ctx->stage.release();

@@ -91,6 +91,8 @@ struct jh_context_s {
   jh::DevBuf<double> scalars;  // 32 doubles
   double *h_scalars = nullptr; // pinned, 32 doubles
   jh::DevBuf<double> stage;    // staging for permuted uploads/downloads
+  double *h_pub = nullptr;     // pinned + coherent: 2 records of JH_PUB_LEN doubles the solver loop publishes to (see jh_krylov.hip)
+  uint64_t pub_seq = 0;        // sequence number of the last published record
   jh::Comm *comm = nullptr;
   void ensure_stage(size_t n) {
     if (stage.n < n) stage.alloc(n);
@@ -202,10 +204,13 @@ struct SpmvDot {
   int slot = 0;
   int64_t n_rows = 0;
 };
+constexpr int JH_PUB_LEN = 16;  // doubles per published record: [0..8) scalars, [8] converged flag, [15] sequence number
+constexpr int S_DONE = 20;      // ctx->scalars slot: != 0 once the running Krylov solve has converged (speculative launches exit)
+// done != nullptr: the launch is skipped on the device when *done != 0 (speculative Krylov iteration past convergence)
 void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta,
-            const SpmvDot *dot = nullptr);
+            const SpmvDot *dot = nullptr, const double *done = nullptr);
 void ensure_partials(jh_context ctx, size_t min_stride);
-void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max);
+void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max, const double *done = nullptr);
 void k_unit_diag(hipStream_t s, const Pattern &P, double *val, double *r, int64_t n_owned);
 void k_scale_system(hipStream_t s, const Pattern &P, double *val, double *r, int kind, double dt);
 
@@ -228,8 +233,59 @@ struct IluGather {
   const double *sc = nullptr;
   int rho_slot = 0, rho_next_slot = 0, cv_slot = 0, ts_slot = 0;
   int n_owned_rows = 0x7fffffff;  // rows >= n_owned_rows are ghosts: their preconditioner input is zero (linalg.jl:78-88)
+  const double *done = nullptr;   // launch is a no-op when *done != 0
 };
 }  // namespace jh
+
+#if defined(__HIPCC__)
+namespace jh {
+// Second stage of the deterministic two-stage reductions: ONE 1024-thread block sums (or maxes) nparts partials of
+// `count` slots in a fixed order.  The loads of a thread are independent (8 accumulators), so even ~50k partials cost a few
+// microseconds instead of a serial latency chain.  out[k] is written by thread 0.
+// (Folding this stage into the producing kernel -- "the last workgroup to arrive reduces" -- was measured and rejected:
+// 2048 same-address device-scope arrivals serialise, 10M-cell SpMV+dot 0.223 -> 0.279 ms with write-through partials and
+// 0.357 ms with a release fence per workgroup.)
+constexpr int FIN_THREADS = 1024;
+template <bool MAX>
+__device__ __forceinline__ void final_reduce_body(const double *part, size_t stride, int nparts, int count, double *out) {
+  __shared__ double sm[FIN_THREADS / 64];
+  for (int k = 0; k < count; ++k) {
+    const double *p = part + k * stride;
+    double a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.0;
+    int i = threadIdx.x;
+    for (; i + 7 * FIN_THREADS < nparts; i += 8 * FIN_THREADS) {
+      double v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[i + j * FIN_THREADS];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = MAX ? ((v[j] > a[j] || v[j] != v[j]) ? v[j] : a[j]) : a[j] + v[j];
+    }
+    for (int j = 0; i < nparts; i += FIN_THREADS, ++j) {
+      const double v = p[i];
+      a[j & 7] = MAX ? ((v > a[j & 7] || v != v) ? v : a[j & 7]) : a[j & 7] + v;
+    }
+    double s = a[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) s = MAX ? ((a[j] > s || a[j] != a[j]) ? a[j] : s) : s + a[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double o = __shfl_down(s, off, 64);
+      s = MAX ? ((o > s || o != o) ? o : s) : s + o;
+    }
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double r = sm[0];
+      for (int w = 1; w < FIN_THREADS / 64; ++w) r = MAX ? ((sm[w] > r || sm[w] != sm[w]) ? sm[w] : r) : r + sm[w];
+      out[k] = r;
+    }
+    __syncthreads();
+  }
+}
+}  // namespace jh
+#endif
 
 // ---- ILU (jh_ilu.hip) -------------------------------------------------------------------------------------------------
 struct jh_ilu_s;

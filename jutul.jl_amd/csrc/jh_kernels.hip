@@ -135,42 +135,12 @@ __global__ __launch_bounds__(256) void absmax_partial_kernel(const double *r, in
   double r0 = block_reduce<true>(m, sm);
   if (threadIdx.x == 0) part[blockIdx.x] = r0;
 }
-// final: one 1024-thread block sums nparts partials of `count` slots in a fixed order.  The loads of a thread are
-// independent (8 accumulators), so ~50k tile partials cost a few microseconds instead of a serial latency chain.
-constexpr int FIN_THREADS = 1024;
+// final stage: see final_reduce_body (jh_internal.hpp)
 template <bool MAX>
-__global__ __launch_bounds__(FIN_THREADS) void final_reduce_kernel(const double *part, size_t stride, int nparts, int count, double *out) {
-  __shared__ double sm[FIN_THREADS / 64];
-  for (int k = 0; k < count; ++k) {
-    const double *p = part + k * stride;
-    double a[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = 0.0;
-    int i = threadIdx.x;
-    for (; i + 7 * FIN_THREADS < nparts; i += 8 * FIN_THREADS) {
-      double v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = p[i + j * FIN_THREADS];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = MAX ? ((v[j] > a[j] || v[j] != v[j]) ? v[j] : a[j]) : a[j] + v[j];
-    }
-    for (int j = 0; i < nparts; i += FIN_THREADS, ++j) {
-      const double v = p[i];
-      a[j & 7] = MAX ? ((v > a[j & 7] || v != v) ? v : a[j & 7]) : a[j & 7] + v;
-    }
-    double s = a[0];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) s = MAX ? ((a[j] > s || a[j] != a[j]) ? a[j] : s) : s + a[j];
-    s = MAX ? wave_max(s) : wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double r = sm[0];
-      for (int w = 1; w < FIN_THREADS / 64; ++w) r = MAX ? ((sm[w] > r || sm[w] != sm[w]) ? sm[w] : r) : r + sm[w];
-      out[k] = r;
-    }
-    __syncthreads();
-  }
+__global__ __launch_bounds__(FIN_THREADS) void final_reduce_kernel(const double *part, size_t stride, int nparts, int count, double *out,
+                                                                   const double *done) {
+  if (done && *done != 0.0) return;
+  final_reduce_body<MAX>(part, stride, nparts, count, out);
 }
 
 void ensure_partials(jh_context ctx, size_t min_stride) {
@@ -180,11 +150,11 @@ void ensure_partials(jh_context ctx, size_t min_stride) {
     ctx->partials.alloc(ctx->partial_stride * 4);
   }
 }
-void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max) {
+void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max, const double *done) {
   if (is_max)
-    hipLaunchKernelGGL(final_reduce_kernel<true>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, nparts, count, ctx->scalars.p + slot);
+    hipLaunchKernelGGL(final_reduce_kernel<true>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, nparts, count, ctx->scalars.p + slot, done);
   else
-    hipLaunchKernelGGL(final_reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, nparts, count, ctx->scalars.p + slot);
+    hipLaunchKernelGGL(final_reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, nparts, count, ctx->scalars.p + slot, done);
 }
 
 void k_dot2_to(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, double *out) {
@@ -193,7 +163,7 @@ void k_dot2_to(jh_context ctx, const double *a, const double *b, const double *c
   if (g > RED_BLOCKS) g = RED_BLOCKS;
   hipLaunchKernelGGL(dot2_partial_kernel, dim3(g), dim3(256), 0, ctx->stream, a, b, c, d, n, ctx->partials.p, ctx->partial_stride);
   hipLaunchKernelGGL(final_reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, g,
-                     c ? 2 : 1, out);
+                     c ? 2 : 1, out, (const double *)nullptr);
 }
 void k_dot2(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, int slot) {
   k_dot2_to(ctx, a, b, c, d, n, ctx->scalars.p + slot);
@@ -207,7 +177,7 @@ void k_absmax_strided(jh_context ctx, const double *r, int64_t ncell, int bs, in
   for (int e = 0; e < bs; ++e) {
     hipLaunchKernelGGL(absmax_partial_kernel, dim3(g), dim3(256), 0, ctx->stream, r, ncell, bs, e, ctx->partials.p);
     hipLaunchKernelGGL(final_reduce_kernel<true>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, g, 1,
-                       ctx->scalars.p + slot + e);
+                       ctx->scalars.p + slot + e, (const double *)nullptr);
   }
 }
 
@@ -232,7 +202,9 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
                                                                  const double *__restrict__ val,
                                                                  const double *__restrict__ x, double *__restrict__ y,
                                                                  double alpha, double beta, const double *__restrict__ dw,
-                                                                 int dot_rows, double *__restrict__ part, size_t pstride) {
+                                                                 int dot_rows, double *__restrict__ part, size_t pstride,
+                                                                 const double *done) {
+  if (done && *done != 0.0) return;
   __shared__ double prod[TILE_NNZ * BS];
   __shared__ int32_t rp[TILE_ROWS + 1];
   __shared__ double red[8];
@@ -351,7 +323,7 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
 }
 
 void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta,
-            const SpmvDot *dot) {
+            const SpmvDot *dot, const double *done) {
   if (P.n == 0) return;
   int chunk = (P.ntiles + NUM_XCD - 1) / NUM_XCD;
   static const int wg_per_xcd = getenv("JH_SPMV_WGS") ? atoi(getenv("JH_SPMV_WGS")) : 256;  // 32 CUs x 8 workgroups
@@ -363,7 +335,7 @@ void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x
   const int drows = dot ? (int)dot->n_rows : 0;
   double *part = ctx->partials.p;
   const size_t ps = ctx->partial_stride;
-#define JH_SPMV(BSV, DV) hipLaunchKernelGGL((spmv_tile_kernel<BSV, DV>), grid, block, 0, ctx->stream, P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta, dw, drows, part, ps)
+#define JH_SPMV(BSV, DV) hipLaunchKernelGGL((spmv_tile_kernel<BSV, DV>), grid, block, 0, ctx->stream, P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta, dw, drows, part, ps, done)
   switch (P.bs * 10 + mode) {
     case 10: JH_SPMV(1, 0); break;
     case 11: JH_SPMV(1, 1); break;
@@ -377,7 +349,7 @@ void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x
     default: JH_THROW("unsupported block size");
   }
 #undef JH_SPMV
-  if (mode) k_final_reduce(ctx, (int)grid.x, mode == 2 ? 2 : 1, dot->slot, false);
+  if (mode) k_final_reduce(ctx, (int)grid.x, mode == 2 ? 2 : 1, dot->slot, false, done);
 }
 
 // unit_diagonalize!: ghost rows -> -I, r_ghost -> 0 (ext/JutulPartitionedArraysExt/linalg.jl:18-35)

@@ -28,7 +28,8 @@ struct jh_krylov_s {
   jh_csr A = nullptr;
   int64_t len = 0;      // doubles per vector
   int64_t len_dot = 0;  // owned part (dots / norms)
-  DevBuf<double> r, p, c, s, q, y, z, d, v, t;
+  DevBuf<double> r, p, c, s, q, y, z, d, v, t, xalt;
+  int64_t cur_it = 0;  // Krylov iteration the launches being enqueued belong to (profiling marks of speculative ones are dropped)
   // GMRES workspace: Krylov basis (grows on demand, Krylov.jl `restart = false`), device/pinned Hessenberg column
   std::vector<std::unique_ptr<DevBuf<double>>> gV;
   DevBuf<double> gh;
@@ -37,8 +38,10 @@ struct jh_krylov_s {
   // optional in-solve profiling with HIP events on the context stream (PrecondWrapper-style time/count,
   // linsolve/krylov.jl:5-25): [0] spmv, [1] preconditioner apply
   bool profiling = false;
+  int prof_stride = 1;  // time the launches of every prof_stride-th Krylov iteration only (an event pair costs ~4.5 us of stream time)
   std::vector<hipEvent_t> ev_pool;
   std::vector<int> ev_kind;
+  std::vector<int64_t> ev_it;
   size_t ev_used = 0;
   double prof_ms[2] = {0, 0};
   int64_t prof_cnt[2] = {0, 0};
@@ -48,20 +51,24 @@ struct jh_krylov_s {
   }
   void mark(int kind, hipStream_t st) {  // call before and after the profiled launch
     if (!profiling) return;
+    if (prof_stride > 1 && cur_it % prof_stride != 1) return;
     if (ev_used == ev_pool.size()) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) return;
       ev_pool.push_back(e);
       ev_kind.push_back(kind);
+      ev_it.push_back(0);
     }
     ev_kind[ev_used] = kind;
+    ev_it[ev_used] = cur_it;
     (void)hipEventRecord(ev_pool[ev_used++], st);
   }
-  void collect() {
+  void collect(int64_t last_it = INT64_MAX) {  // marks of iterations > last_it were speculative: not counted
     if (!profiling || ev_used < 2) { ev_used = 0; return; }
     (void)hipEventSynchronize(ev_pool[ev_used - 1]);
     for (size_t i = 0; i + 1 < ev_used; i += 2) {
       float ms = 0;
+      if (ev_it[i] > last_it) continue;
       if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) {
         prof_ms[ev_kind[i]] += ms;
         prof_cnt[ev_kind[i]]++;
@@ -85,32 +92,36 @@ __global__ void bicg_s_kernel(double *s, const double *r, const double *v, const
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     s[i] = r[i] - alpha * v[i];
 }
-// x += alpha*y + omega*z ; r = s - omega*t
-__global__ void bicg_xr_kernel(double *x, double *r, const double *y, const double *z, const double *s, const double *t,
-                               const double *sc, int rho_slot, int64_t n) {
-  const double alpha = sc[rho_slot] / sc[S_CV];
-  const double omega = bicg_omega(sc[S_TS], sc[S_TT]);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double xi = x[i];
-    xi += alpha * y[i];  // x_aux = x + alpha*y
-    xi += omega * z[i];  // x = x_aux + omega*z
-    x[i] = xi;
-    r[i] = s[i] - omega * t[i];
-  }
+// One record per Krylov iteration goes to pinned host memory so that the host can follow the solve without a stream
+// synchronisation: [0..8) scalars, [8] converged flag, [15] sequence number (written last, after a system-scope fence).
+__device__ __forceinline__ void publish_record(double *sc, int pair_slot, double eps, double *rec, double seq) {
+  const double rr = sc[pair_slot + 1];
+  const double conv = (sqrt(rr) <= eps) ? 1.0 : 0.0;
+  if (conv != 0.0) sc[S_DONE] = 1.0;  // later launches of this solve (one speculative iteration) become no-ops
+  for (int i = 0; i < 8; ++i) __hip_atomic_store(rec + i, sc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(rec + 8, conv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __hip_atomic_store(rec + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// fused: x += alpha*y + omega*z ; r = s - omega*t ; partial sums of <c,r> and <r,r> over the first nd entries
-__global__ __launch_bounds__(256) void bicg_xr_dots_kernel(double *x, double *r, const double *y, const double *z, const double *s,
-                                                           const double *t, const double *c, const double *sc, int rho_slot, int64_t n,
-                                                           int64_t nd, double *part, size_t stride) {
+__global__ void bicg_publish_kernel(double *sc, int pair_slot, double eps, double *rec, double seq) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) publish_record(sc, pair_slot, eps, rec, seq);
+}
+// fused: x_out = x_in + alpha*y + omega*z ; r = s - omega*t ; partial sums of <c,r> and <r,r> over the first nd entries.
+// x ping-pongs between two buffers so that the iterate of iteration k survives the speculatively enqueued iteration k+1.
+__global__ __launch_bounds__(256) void bicg_xr_dots_kernel(const double *x_in, double *x_out, double *r, const double *y, const double *z,
+                                                           const double *s, const double *t, const double *c, const double *sc,
+                                                           int rho_slot, int64_t n, int64_t nd, double *part, size_t stride,
+                                                           const double *done) {
+  if (done && *done != 0.0) return;
   __shared__ double sm[4];
   const double alpha = sc[rho_slot] / sc[S_CV];
   const double omega = bicg_omega(sc[S_TS], sc[S_TT]);
   double d0 = 0.0, d1 = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double xi = x[i];
-    xi += alpha * y[i];
-    xi += omega * z[i];
-    x[i] = xi;
+    double xi = x_in[i];
+    xi += alpha * y[i];  // x_aux = x + alpha*y
+    xi += omega * z[i];  // x = x_aux + omega*z
+    x_out[i] = xi;
     const double ri = s[i] - omega * t[i];
     r[i] = ri;
     if (i < nd) { d0 += c[i] * ri; d1 += ri * ri; }
@@ -126,6 +137,15 @@ __global__ __launch_bounds__(256) void bicg_xr_dots_kernel(double *x, double *r,
   if (lane == 0) sm[w] = d1;
   __syncthreads();
   if (threadIdx.x == 0) part[stride + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+// second stage of the reduction above: (rho_next, ||r||^2) -> sc[out_slot..+1]; without a communicator the same launch
+// publishes the iteration's record (otherwise bicg_publish_kernel does, after the all-reduce)
+__global__ __launch_bounds__(FIN_THREADS) void bicg_reduce_publish_kernel(const double *part, size_t stride, int nparts, double *sc,
+                                                                          int out_slot, const double *done, double eps, double *rec,
+                                                                          double seq) {
+  if (done && *done != 0.0) return;
+  final_reduce_body<false>(part, stride, nparts, 2, sc + out_slot);
+  if (rec && threadIdx.x == 0) publish_record(sc, out_slot, eps, rec, seq);
 }
 // p = r + beta*(p - omega*v), beta = (rho'/rho)*(alpha/omega)
 __global__ void bicg_p_kernel(double *p, const double *r, const double *v, const double *sc, int rho_slot, int rho_next_slot, int64_t n) {
@@ -161,7 +181,31 @@ extern "C" int32_t jh_krylov_destroy(jh_krylov K) {
 
 namespace jh {
 
+// Wait (spinning on pinned memory, no stream synchronisation) until the record with sequence number seq has been published.
+static void wait_published(jh_context ctx, int rec, double seq, double *out) {
+  volatile double *r = ctx->h_pub + rec * JH_PUB_LEN;
+  for (uint64_t spin = 1;; ++spin) {
+    if (r[15] == seq) break;
+    if ((spin & 0x3fff) == 0) {  // the stream must still be busy, otherwise the record was lost (kernel fault)
+      hipError_t q = hipStreamQuery(ctx->stream);
+      if (q == hipSuccess) {
+        if (r[15] == seq) break;
+        JH_THROW("Krylov iteration record was not published");
+      } else if (q != hipErrorNotReady) {
+        JH_HIP(q);
+      }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  for (int i = 0; i < 9; ++i) out[i] = r[i];
+}
+
 // returns status; x must hold len doubles
+//
+// Host/device protocol: iteration k+1 is enqueued BEFORE the host looks at the outcome of iteration k, so the stream never
+// drains between iterations (the synchronous version idled the GPU ~30 us per iteration, 15% at 1.25M cells per GPU).  The
+// iterate ping-pongs between x and K->xalt, which keeps x_k intact while the speculative iteration k+1 runs; on
+// convergence the device raises sc[S_DONE] and the kernels of the speculative iteration return immediately.
 int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, double rtol, double atol, int64_t itmax,
              int64_t *iters_out, double *hist, int64_t hist_cap) {
   jh_context ctx = K->ctx;
@@ -173,7 +217,11 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   const int64_t n = K->len, nd = K->len_dot;
   const bool left = (side == JH_SIDE_LEFT) && M, right = (side == JH_SIDE_RIGHT) && M;
   if (left && K->v.n == 0) { K->v.alloc(n); K->t.alloc(n); }
+  if (K->xalt.n == 0) K->xalt.alloc(n);
+  double *X[2] = {x, K->xalt.p};
   double *sc = ctx->scalars.p;
+  const double *done = sc + S_DONE;
+  JH_HIP(hipMemsetAsync(sc + S_DONE, 0, sizeof(double), st));
   auto prec = [&](double *in, double *out) {
     // parray_preconditioner_apply! (ext/.../linalg.jl:78-88): ghost part of the input zeroed, local apply
     if (dist && n > nd) k_fill(st, in + nd, n - nd, 0.0);
@@ -189,10 +237,11 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   auto spmv = [&](double *in, double *out, const SpmvDot *dot) {
     if (dist) halo_exchange(disc, in, P.bs);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
     K->mark(0, st);
-    k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot);
+    k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done);
     K->mark(0, st);
     if (dot) comm_allreduce_dev(ctx, sc + dot->slot, dot->mode == 2 ? 2 : 1, 0);
   };
+  K->cur_it = 0;
   k_fill(st, x, n, 0.0);
   k_copy(st, K->c.p, b_in, n);  // scratch copy of b (the ghost zeroing of the preconditioner must not touch b)
   if (dist) halo_exchange(disc, K->c.p, P.bs);  // consistent!(b) (ext/.../krylov.jl:54)
@@ -208,24 +257,27 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   double rnorm = std::sqrt(h2[1]);
   const double eps = atol + rtol * rnorm;
   if (hist && hist_cap > 0) hist[0] = rnorm;
-  int64_t it = 0;
   int status = 0;
   bool solved = rnorm <= eps;
   if (rho == 0.0 && !solved) status = 2;  // "Breakdown b'c = 0"
-  int rs = S_PAIR0;                       // pair holding the current (rho, rr); the next one goes to the other pair
   ensure_partials(ctx, 4096);
-  // right preconditioning on one rank: the s- and p-updates are fused into the gather phase of the ILU(0) apply
+  // right preconditioning: the s- and p-updates are fused into the gather phase of the ILU(0) apply
   const bool fuse = right && ilu_can_fuse_gather(M);
   const int ghost_from = dist ? (int)(nd / P.bs) : 0x7fffffff;
-  int prev_rs = -1, prev_rn = -1;         // scalar pairs of the previous iteration (deferred p-update)
-  while (!solved && it < itmax && status == 0) {
-    ++it;
-    const int rn = (rs == S_PAIR0) ? S_PAIR1 : S_PAIR0;
+  static const int lag = getenv("JH_SYNC_LOOP") ? 0 : 1;
+  double seq_of[2] = {0, 0};
+  // pair holding (rho, rr) at the start of iteration k; the next one goes to the other pair
+  auto pair_of = [](int64_t k) { return (k & 1) ? (int)S_PAIR0 : (int)S_PAIR1; };
+  auto enqueue = [&](int64_t k) {
+    K->cur_it = k;
+    const int rs = pair_of(k), rn = pair_of(k + 1);
+    const double *xin = X[(k - 1) & 1];
+    double *xout = X[k & 1];
     double *yy = K->p.p;
-    if (fuse && prev_rs >= 0) {  // p = r + beta*(p - omega*q) of the previous iteration, then y = N^-1 p
+    if (fuse && k > 1) {  // p = r + beta*(p - omega*q) of the previous iteration, then y = N^-1 p
       IluGather G;
-      G.mode = 2; G.r = K->r.p; G.q = K->q.p; G.out = K->p.p; G.sc = sc;
-      G.rho_slot = prev_rs; G.rho_next_slot = prev_rn; G.cv_slot = S_CV; G.ts_slot = S_TS; G.n_owned_rows = ghost_from;
+      G.mode = 2; G.r = K->r.p; G.q = K->q.p; G.out = K->p.p; G.sc = sc; G.done = done;
+      G.rho_slot = pair_of(k - 1); G.rho_next_slot = rs; G.cv_slot = S_CV; G.ts_slot = S_TS; G.n_owned_rows = ghost_from;
       K->mark(1, st);
       ilu_apply_fused(M, G, K->y.p);
       K->mark(1, st);
@@ -244,7 +296,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     double *zz = K->s.p;
     if (fuse) {  // s = r - alpha*q fused into z = N^-1 s
       IluGather G;
-      G.mode = 1; G.r = K->r.p; G.q = vv; G.out = K->s.p; G.sc = sc;
+      G.mode = 1; G.r = K->r.p; G.q = vv; G.out = K->s.p; G.sc = sc; G.done = done;
       G.rho_slot = rs; G.cv_slot = S_CV; G.n_owned_rows = ghost_from;
       K->mark(1, st);
       ilu_apply_fused(M, G, K->z.p);
@@ -264,30 +316,41 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       SpmvDot d2{2, K->s.p, S_TS, rows_dot};  // <t,s>, <t,t> fused
       spmv(zz, K->d.p, &d2);
     }
-    {
-      dim3 g = vgrid(n);
-      hipLaunchKernelGGL(bicg_xr_dots_kernel, g, dim3(256), 0, st, x, K->r.p, yy, zz, K->s.p, tt, K->c.p, sc, rs, n, nd,
-                         ctx->partials.p, ctx->partial_stride);
-      k_final_reduce(ctx, (int)g.x, 2, rn, false);  // (rho_next, ||r||^2) -> the other pair
+    const double seq = (double)(++ctx->pub_seq);
+    seq_of[k & 1] = seq;
+    double *rec = ctx->h_pub + (k & 1) * JH_PUB_LEN;
+    dim3 g = vgrid(n);
+    // (rho_next, ||r||^2) -> the other pair; without a communicator the kernel also publishes the record
+    hipLaunchKernelGGL(bicg_xr_dots_kernel, g, dim3(256), 0, st, xin, xout, K->r.p, yy, zz, K->s.p, tt, K->c.p, sc, rs, n, nd,
+                       ctx->partials.p, ctx->partial_stride, done);
+    hipLaunchKernelGGL(bicg_reduce_publish_kernel, dim3(1), dim3(FIN_THREADS), 0, st, ctx->partials.p, ctx->partial_stride, (int)g.x,
+                       sc, rn, done, eps, ctx->comm ? nullptr : rec, seq);
+    if (ctx->comm) {
       comm_allreduce_dev(ctx, sc + rn, 2, 0);
+      hipLaunchKernelGGL(bicg_publish_kernel, dim3(1), dim3(64), 0, st, sc, rn, eps, rec, seq);
     }
-    if (fuse) { prev_rs = rs; prev_rn = rn; }  // p-update deferred into the next iteration's first ILU apply
-    else hipLaunchKernelGGL(bicg_p_kernel, vgrid(n), dim3(256), 0, st, K->p.p, K->r.p, vv, sc, rs, rn, n);
-    double h[8];
-    read_scalars(ctx, 0, 8, h);
-    const double rho_cur = h[rs], cv = h[S_CV];
+    // p-update: deferred into the next iteration's first ILU apply when fused
+    if (!fuse) hipLaunchKernelGGL(bicg_p_kernel, vgrid(n), dim3(256), 0, st, K->p.p, K->r.p, vv, sc, rs, rn, n);
+  };
+  int64_t it = 0, enq = 0;
+  while (!solved && it < itmax && status == 0) {
+    while (enq < std::min<int64_t>(itmax, it + 1 + lag)) enqueue(++enq);
+    ++it;
+    double h[9];
+    wait_published(ctx, (int)(it & 1), seq_of[it & 1], h);
+    const double rho_cur = h[pair_of(it)], cv = h[S_CV];
     const double alpha = rho_cur / cv;
-    rnorm = std::sqrt(h[rn + 1]);
+    rnorm = std::sqrt(h[pair_of(it + 1) + 1]);
     if (hist && it < hist_cap) hist[it] = rnorm;
-    solved = rnorm <= eps;
+    solved = h[8] != 0.0;
     if (alpha == 0.0 || alpha != alpha) status = 2;
-    rs = rn;
   }
   if (solved) status = 0;
   else if (status == 0 && it >= itmax) status = 1;
+  if (it & 1) k_copy(st, x, X[1], n);  // iterate of the last accepted iteration
   if (dist) halo_exchange(disc, x, P.bs);  // consistent!(x) (ext/.../krylov.jl:75)
   *iters_out = it;
-  K->collect();
+  K->collect(it);
   JH_HIP(hipGetLastError());
   return status;
 }
@@ -434,6 +497,7 @@ extern "C" int32_t jh_krylov_profile(jh_krylov K, int32_t enable, int32_t reset,
     if (count2) { count2[0] = K->prof_cnt[0]; count2[1] = K->prof_cnt[1]; }
     if (reset) { K->prof_ms[0] = K->prof_ms[1] = 0; K->prof_cnt[0] = K->prof_cnt[1] = 0; }
     K->profiling = enable != 0;
+    K->prof_stride = enable > 1 ? enable : 1;
   });
 }
 
