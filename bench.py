@@ -42,7 +42,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cells", type=int, default=10_000_000)
     ap.add_argument("--law", default="poisson", choices=["poisson", "compressible"])
-    ap.add_argument("--block-rows", type=int, default=512)
+    ap.add_argument("--block-rows", type=int, default=0,
+                    help="rows per block-Jacobi ILU(0) block; 0 = the library default for the rank-local size (512, 256 below 2M cells)")
     ap.add_argument("--rtol", type=float, default=1e-3)
     ap.add_argument("--dt", type=float, default=5.0)
     ap.add_argument("--cpu-cells", type=int, default=1_000_000)
@@ -196,7 +197,7 @@ def main():
             "config": {"workload": f"{args.law} TPFA conservation law, {nc_g}-cell Kuhn-split tet lattice "
                                    f"({nx}x{ny}x{nz}x6, scrambled numbering), nf={nf_g}, 1 Newton iteration/step: "
                                    f"assembly + block-Jacobi ILU(0) factor + BiCGStab(rtol={args.rtol})",
-                       "cells": nc_g, "faces": nf_g, "dt": args.dt, "block_rows": args.block_rows,
+                       "cells": nc_g, "faces": nf_g, "dt": args.dt, "block_rows": args.block_rows or (256 if disc.nc < 2_000_000 else 512),
                        "parallelism": f"dd{world}" if world > 1 else "single", "precond_side": ks.config.precond_side,
                        "ilu_blocks": info["nblocks"], "ilu_max_levels": info["max_levels"],
                        "linear_iterations_per_step": round(float(np.mean(lin_its)), 2),

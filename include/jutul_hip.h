@@ -58,7 +58,8 @@ int32_t jh_timer_stop_ms(jh_context ctx, double *ms);
  * N: 2 x nf neighborship, column-major, 1-based.  block_n: equations = primary variables per cell.
  * partition (may be NULL): nc entries, 1-based part id per cell; cells of one part become contiguous on the
  * device (used as the block-Jacobi ILU(0) partition, precond/ilu.jl:37-60).  block_rows: target rows per
- * automatically grown block when partition == NULL and reorder == JH_REORDER_BLOCKS (0 = default).
+ * automatically grown block when partition == NULL and reorder == JH_REORDER_BLOCKS (0 = default: 512, or 256
+ * below 2M cells).
  * n_owned: for a rank-local subdomain whose cells are [owned..., ghosts...] (ext/JutulPartitionedArraysExt/
  * utils.jl:178-184) the number of owned cells; ghosts stay the last device rows.  <= 0 or nc: no ghosts. */
 int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const int64_t *N, int32_t block_n, int32_t reorder,
