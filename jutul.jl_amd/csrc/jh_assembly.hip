@@ -90,13 +90,16 @@ template <int KIND>
 __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
     const int32_t *__restrict__ tile_row, int ntiles, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const int32_t *__restrict__ diag, const double *__restrict__ Tnz, const double *__restrict__ gnz, const double *__restrict__ X,
-    const double *__restrict__ X0, double *__restrict__ nz, double *__restrict__ r, double dt, LawPar par, int reg_row) {
+    const double *__restrict__ X0, double *__restrict__ nz, double *__restrict__ r, double dt, LawPar par, int reg_row,
+    int nrows_total) {
   constexpr int N = (KIND == JH_LAW_TWOPHASE) ? 2 : 1;
   constexpr int NN = N * N;
   constexpr int TNNZ = (N == 1) ? TILE_NNZ : TILE_NNZ / 2;  // tile entry budget (Pattern::build_tiles)
   __shared__ double qv[TNNZ * N];    // flux values per entry
   __shared__ double dsv[TNNZ * NN];  // d q / d x_self per entry (column-major N x N)
-  __shared__ double xs[TILE_ROWS * N];   // primary variables of the tile's rows
+  // rows staged on either side of the tile: >80% of the neighbour cells lie inside (compact graph blocks)
+  constexpr int WIN = (N == 1) ? 128 : 64;
+  __shared__ double xs[(TILE_ROWS + 2 * WIN) * N];  // primary variables of rows [w0, w0 + wn)
   __shared__ int32_t rp[TILE_ROWS + 1];
   __shared__ uint8_t rowof[TNNZ];
   const int t = xcd_tile_a(blockIdx.x, ntiles);
@@ -106,8 +109,21 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
   const int base = rowptr[r0];
   const int cnt = rowptr[r1] - base;  // TPFA rows are short: cnt <= TILE_NNZ is guaranteed by the host (checked)
   const int tid = threadIdx.x;
+  constexpr int KPT = TNNZ / TILE_THREADS;  // entries per lane
+  // the (col, T) stream of the lane's entries is requested first: it is in flight while the row table is built
+  int cidx[KPT];
+  double Tk[KPT];
+#pragma unroll
+  for (int kk = 0; kk < KPT; ++kk) {
+    const int k = tid + kk * TILE_THREADS;
+    cidx[kk] = (k < cnt) ? col[base + k] : 0;
+    Tk[kk] = (k < cnt) ? Tnz[base + k] : 0.0;
+  }
+  const int w0 = max(0, r0 - WIN);
+  const int wn = min(nrows_total, r0 + TILE_ROWS + WIN) - w0;
+  const int own = r0 - w0;  // offset of the tile's first row inside the window
   for (int i = tid; i <= nrows; i += TILE_THREADS) rp[i] = rowptr[r0 + i] - base;
-  for (int i = tid; i < nrows * N; i += TILE_THREADS) xs[i] = X[(size_t)r0 * N + i];
+  for (int i = tid; i < wn * N; i += TILE_THREADS) xs[i] = X[(size_t)w0 * N + i];
   __syncthreads();
   if (tid < nrows)
     for (int j = rp[tid]; j < rp[tid + 1]; ++j) rowof[j] = (uint8_t)tid;
@@ -116,7 +132,6 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
   // The off-diagonal blocks stay in registers until phase 3 so that every nzval line of the tile is written once,
   // full and coalesced (8-byte diagonal stores from the row lanes cost a 32-byte HBM write each: +0.32 GB at 10M
   // cells, measured with WRITE_SIZE).
-  constexpr int KPT = TNNZ / TILE_THREADS;  // entries per lane
   double off[KPT][NN];
   bool isdiag[KPT];
 #pragma unroll
@@ -125,8 +140,10 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
     isdiag[kk] = false;
     if (k >= cnt) continue;
     const int lr = rowof[k];
-    const int c = col[base + k];
-    const double T = Tnz[base + k];
+    const int c = cidx[kk];
+    const double T = Tk[kk];
+    const unsigned cw = (unsigned)(c - w0);  // position of the neighbour inside the LDS window (if < wn)
+    const bool inl = cw < (unsigned)wn;
     if (c == r0 + lr) {  // diagonal slot: no flux; its block is produced by the row lane in phase 2
 #pragma unroll
       for (int e = 0; e < N; ++e) qv[k * N + e] = 0.0;
@@ -137,15 +154,15 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
     }
     if (KIND == JH_LAW_POISSON) {
       // q = -K[face]*(U_other - U_self)  (variable_poisson.jl:99,124); dq/dU_self = K, dq/dU_other = -K
-      const double Us = xs[lr];
-      const double Uo = (c >= r0 && c < r1) ? xs[c - r0] : X[c];
+      const double Us = xs[own + lr];
+      const double Uo = inl ? xs[cw] : X[c];
       qv[k] = -(T * (Uo - Us));
       dsv[k] = T;
       off[kk][0] = -T;
     } else if (KIND == JH_LAW_COMPRESSIBLE) {
       const double gz = gnz ? gnz[base + k] : 0.0;
-      Dual<2> ps = dvar<2>(xs[lr], 0);
-      Dual<2> po = dvar<2>((c >= r0 && c < r1) ? xs[c - r0] : X[c], 1);
+      Dual<2> ps = dvar<2>(xs[own + lr], 0);
+      Dual<2> po = dvar<2>(inl ? xs[cw] : X[c], 1);
       Dual<2> rs = density(par, 0, ps), ro = density(par, 0, po);
       Dual<2> ravg = 0.5 * (rs + ro);             // face_average (flux.jl:372-375)
       Dual<2> dphi = (ps - po) + gz * ravg;       // two_point_potential_drop (flux.jl:335-338)
@@ -155,10 +172,9 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
       off[kk][0] = q.d[1];
     } else {
       const double gz = gnz ? gnz[base + k] : 0.0;
-      const bool inl = (c >= r0 && c < r1);
-      Dual<4> ps = dvar<4>(xs[lr * 2], 0), ss_w = dvar<4>(xs[lr * 2 + 1], 1);
-      Dual<4> po = dvar<4>(inl ? xs[(c - r0) * 2] : X[(size_t)c * 2], 2);
-      Dual<4> so_w = dvar<4>(inl ? xs[(c - r0) * 2 + 1] : X[(size_t)c * 2 + 1], 3);
+      Dual<4> ps = dvar<4>(xs[(own + lr) * 2], 0), ss_w = dvar<4>(xs[(own + lr) * 2 + 1], 1);
+      Dual<4> po = dvar<4>(inl ? xs[cw * 2] : X[(size_t)c * 2], 2);
+      Dual<4> so_w = dvar<4>(inl ? xs[cw * 2 + 1] : X[(size_t)c * 2 + 1], 3);
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph) {
         Dual<4> rs = density(par, ph, ps), ro = density(par, ph, po);
@@ -190,7 +206,7 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
       dk = diag[row] - base;
       const double vol = Tnz[base + dk];
       if (KIND == JH_LAW_POISSON) {
-        const double U = xs[tid];
+        const double U = xs[own + tid];
         if (dt > 0.0) {
           ar[0] = (vol * U - vol * X0[row]) / dt;
           ap[0] = vol / dt;
@@ -199,14 +215,14 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
           ap[0] = (row == reg_row) ? 1e-10 : 0.0;
         }
       } else if (KIND == JH_LAW_COMPRESSIBLE) {
-        Dual<2> p = dvar<2>(xs[tid], 0);
+        Dual<2> p = dvar<2>(xs[own + tid], 0);
         Dual<2> M = vol * density(par, 0, p);
         double M0 = vol * density(par, 0, dconst<2>(X0[row])).v;
         Dual<2> a = ddiv(M - dconst<2>(M0), dt);
         ar[0] = a.v;
         ap[0] = a.d[0];
       } else {
-        Dual<4> p = dvar<4>(xs[tid * 2], 0), sw = dvar<4>(xs[tid * 2 + 1], 1);
+        Dual<4> p = dvar<4>(xs[(own + tid) * 2], 0), sw = dvar<4>(xs[(own + tid) * 2 + 1], 1);
         Dual<4> so = dconst<4>(1.0) - sw;
         const double p0 = X0[(size_t)row * 2], sw0 = X0[(size_t)row * 2 + 1];
         Dual<4> Mw = vol * (density(par, 0, p) * sw);
@@ -288,7 +304,7 @@ void k_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
   int chunk = (P.ntiles + NUM_XCD - 1) / NUM_XCD;
   dim3 grid(chunk * NUM_XCD), block(TILE_THREADS);
   const double *g = L->has_gdz ? L->gnz.p : nullptr;
-#define JH_ASM_ARGS P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, P.d_diag.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row
+#define JH_ASM_ARGS P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, P.d_diag.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row, (int)P.n
   switch (L->kind) {
     case JH_LAW_POISSON: hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_POISSON>, grid, block, 0, ctx->stream, JH_ASM_ARGS); break;
     case JH_LAW_COMPRESSIBLE: hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_COMPRESSIBLE>, grid, block, 0, ctx->stream, JH_ASM_ARGS); break;
