@@ -86,6 +86,11 @@ int32_t jh_tpfa_get_positions_layout(jh_tpfa d, int32_t layout, int64_t *pos_acc
 /* device cell order: perm[i] = host cell (1-based) stored at device position i; block_ptr (nblocks+1,
  * 0-based device rows) of the contiguous blocks.  Pass NULL to skip an output. */
 int32_t jh_tpfa_get_ordering(jh_tpfa d, int64_t *perm, int64_t *nblocks, int64_t *block_ptr, int64_t block_ptr_cap);
+/* Rank-local subdomains (n_owned < nc, JH_REORDER_BLOCKS): the device order is [interior blocks | boundary blocks |
+ * ghost blocks]; interior = no cell of the block has a ghost neighbour, so those rows neither feed nor need the ghost
+ * exchange (consistent!, ext/JutulPartitionedArraysExt/linalg.jl:46) and the solver overlaps it with them.  Returns the
+ * number of leading interior device rows / blocks / SpMV tiles, -1 when the discretisation is not split. */
+int32_t jh_tpfa_get_split(jh_tpfa d, int64_t *interior_rows, int64_t *interior_blocks, int64_t *interior_tiles);
 
 /* ---- device vectors ------------------------------------------------------------------------------------- */
 /* A vector of nc*block_n doubles attached to a discretisation (cell-ordered: upload/download apply the device

@@ -51,10 +51,13 @@ class _Handle:
                 getattr(_L(), self._destroy)(self.h)
             except Exception:
                 pass
-            self.h = C.c_void_p()
+            self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
 
 class HIPContext(_Handle):
@@ -182,6 +185,12 @@ class TwoPointPotentialFlowHardCoded(_Handle):
         if nb.value:
             check(_L().jh_tpfa_get_ordering(self.h, None, None, pi(bp), bp.size))
         return perm, bp
+
+    def split(self):
+        """(interior_rows, interior_blocks, interior_tiles) of a rank-local subdomain's device order, -1 if not split."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(_L().jh_tpfa_get_split(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def set_halo(self, n_owned, nbr_ranks, send_lists, recv_lists):
         """Halo plan: per neighbour rank the local owned cells to send / ghost cells to receive (1-based)."""

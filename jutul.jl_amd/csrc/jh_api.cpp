@@ -51,6 +51,12 @@ extern "C" int32_t jh_context_destroy(jh_context ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     if (ctx->h_pub) (void)hipHostFree(ctx->h_pub);
+    if (ctx->comm_stream) {
+      (void)hipStreamSynchronize(ctx->comm_stream);
+      (void)hipEventDestroy(ctx->ev_halo_ready);
+      (void)hipEventDestroy(ctx->ev_halo_done);
+      (void)hipStreamDestroy(ctx->comm_stream);
+    }
     ctx->partials.release();
     ctx->scalars.release();
     ctx->stage.release();

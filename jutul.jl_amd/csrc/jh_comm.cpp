@@ -118,13 +118,11 @@ void comm_allreduce_dev(jh_context ctx, double *p, int n, int op) {
 void halo_pack_launch(hipStream_t s, double *buf, const double *v, const int32_t *idx, int64_t n, int bs);
 void halo_unpack_launch(hipStream_t s, double *v, const double *buf, const int32_t *idx, int64_t n, int bs);
 
-// consistent!(v): pack owned values -> grouped ncclSend/ncclRecv per neighbour -> unpack into ghost rows
-void halo_exchange(jh_tpfa d, double *v, int bs) {
+// consistent!(v): pack owned values -> grouped ncclSend/ncclRecv per neighbour -> unpack into ghost rows, all on stream s
+static void halo_exchange_on(jh_tpfa d, double *v, int bs, hipStream_t s) {
   auto &H = d->halo;
-  if (!H.active) return;
   jh_context ctx = d->ctx;
   if (!ctx->comm) JH_THROW("halo exchange without a communicator (jh_comm_init)");
-  hipStream_t s = ctx->stream;
   if (H.n_send) halo_pack_launch(s, H.d_send_buf.p, v, H.d_send_idx.p, H.n_send, bs);
   if (ctx->comm->local) {
     LocalGroup &G = *ctx->comm->local;
@@ -157,6 +155,33 @@ void halo_exchange(jh_tpfa d, double *v, int bs) {
   }
   JH_NCCL(R.GroupEnd());
   if (H.n_recv) halo_unpack_launch(s, v, H.d_recv_buf.p, H.d_recv_idx.p, H.n_recv, bs);
+}
+
+void halo_exchange(jh_tpfa d, double *v, int bs) {
+  if (!d->halo.active) return;
+  halo_exchange_on(d, v, bs, d->ctx->stream);
+}
+
+// Overlapped form.  begin: everything enqueued on the compute stream so far (in particular the rows that are sent) is
+// what the exchange sees; it runs on the context's communication stream while the compute stream goes on with work
+// that neither writes v's owned boundary rows nor touches its ghost rows.  end: the compute stream waits for the ghosts.
+void halo_exchange_begin(jh_tpfa d, double *v, int bs) {
+  if (!d->halo.active) return;
+  jh_context ctx = d->ctx;
+  if (!ctx->comm_stream) {
+    JH_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    JH_HIP(hipEventCreateWithFlags(&ctx->ev_halo_ready, hipEventDisableTiming));
+    JH_HIP(hipEventCreateWithFlags(&ctx->ev_halo_done, hipEventDisableTiming));
+  }
+  JH_HIP(hipEventRecord(ctx->ev_halo_ready, ctx->stream));
+  JH_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_halo_ready, 0));
+  halo_exchange_on(d, v, bs, ctx->comm_stream);
+  JH_HIP(hipEventRecord(ctx->ev_halo_done, ctx->comm_stream));
+}
+void halo_exchange_end(jh_tpfa d) {
+  if (!d->halo.active) return;
+  jh_context ctx = d->ctx;
+  JH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_halo_done, 0));
 }
 
 }  // namespace jh
@@ -218,6 +243,7 @@ extern "C" int32_t jh_comm_finalize(jh_context ctx) {
   return guard([&] {
     if (!ctx || !ctx->comm) return;
     JH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) JH_HIP(hipStreamSynchronize(ctx->comm_stream));
     if (ctx->comm->comm) rccl().CommDestroy(ctx->comm->comm);
     delete ctx->comm;
     ctx->comm = nullptr;

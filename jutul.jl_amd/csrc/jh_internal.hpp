@@ -94,6 +94,9 @@ struct jh_context_s {
   double *h_pub = nullptr;     // pinned + coherent: 2 records of JH_PUB_LEN doubles the solver loop publishes to (see jh_krylov.hip)
   uint64_t pub_seq = 0;        // sequence number of the last published record
   jh::Comm *comm = nullptr;
+  // second stream + events of the overlapped halo exchange (created on first use, jh_comm.cpp)
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_halo_ready = nullptr, ev_halo_done = nullptr;
   void ensure_stage(size_t n) {
     if (stage.n < n) stage.alloc(n);
   }
@@ -113,6 +116,11 @@ struct Pattern {
   std::vector<int32_t> iperm;     // iperm[host] = device position
   std::vector<int32_t> nz_hslot;  // device block slot -> host block slot (empty => identity)
   std::vector<int32_t> block_ptr; // contiguous device row blocks (block-Jacobi partition), may be empty
+  // rank-local subdomains: blocks [0, interior_blocks) = rows [0, interior_rows) have no ghost neighbour (their SpMV rows /
+  // ILU blocks neither feed nor need the halo exchange); then the boundary blocks, then the ghost blocks.  -1: not split.
+  int64_t interior_rows = -1;
+  int32_t interior_blocks = -1;
+  int32_t interior_tiles = -1;    // tiles [0, interior_tiles) cover exactly the interior rows
   // tiles
   std::vector<int32_t> tile_row;
   int32_t ntiles = 0;
@@ -206,9 +214,15 @@ struct SpmvDot {
 };
 constexpr int JH_PUB_LEN = 16;  // doubles per published record: [0..8) scalars, [8] converged flag, [15] sequence number
 constexpr int S_DONE = 20;      // ctx->scalars slot: != 0 once the running Krylov solve has converged (speculative launches exit)
-// done != nullptr: the launch is skipped on the device when *done != 0 (speculative Krylov iteration past convergence)
-void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta,
-            const SpmvDot *dot = nullptr, const double *done = nullptr);
+// done != nullptr: the launch is skipped on the device when *done != 0 (speculative Krylov iteration past convergence).
+// rng: only tiles [t0, t1); the fused-dot partials go behind part_off earlier ones and the second reduction stage runs
+// only if `reduce` (last launch of a split product).  Returns the number of partials this launch produced.
+struct SpmvRange {
+  int t0 = 0, t1 = 0, part_off = 0;
+  bool reduce = true;
+};
+int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta,
+           const SpmvDot *dot = nullptr, const double *done = nullptr, const SpmvRange *rng = nullptr);
 void ensure_partials(jh_context ctx, size_t min_stride);
 void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max, const double *done = nullptr);
 void k_unit_diag(hipStream_t s, const Pattern &P, double *val, double *r, int64_t n_owned);

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
                                                                  const double *__restrict__ x, double *__restrict__ y,
                                                                  double alpha, double beta, const double *__restrict__ dw,
                                                                  int dot_rows, double *__restrict__ part, size_t pstride,
-                                                                 const double *done) {
+                                                                 const double *done, int t_begin) {
   if (done && *done != 0.0) return;
   __shared__ double prod[TILE_NNZ * BS];
   __shared__ int32_t rp[TILE_ROWS + 1];
@@ -214,11 +214,13 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
   double d0 = 0.0, d1 = 0.0;  // fused dot partials of this lane
   // Persistent over tiles: workgroup b belongs to XCD b % 8 and walks that XCD's contiguous chunk of tiles with stride
   // gridDim/8, so a fused dot product needs ONE block reduction and ONE partial per workgroup (<= 2048 partials).
+  // (ntiles tiles starting at tile t_begin: the split SpMV of a rank-local subdomain launches interior and boundary tiles
+  // separately)
   const int chunk = (ntiles + NUM_XCD - 1) / NUM_XCD;
   const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, wgs = gridDim.x / NUM_XCD;
   for (int tl = wg; tl < chunk; tl += wgs) {
-  const int t = xcd * chunk + tl;
-  if (t >= ntiles) break;
+  if (xcd * chunk + tl >= ntiles) break;
+  const int t = t_begin + xcd * chunk + tl;
   if (tl != wg) __syncthreads();  // the previous tile's LDS contents are dead only once every lane is done with them
   const int r0 = tile_row[t], r1 = tile_row[t + 1];
   const int nrows = r1 - r0;
@@ -342,23 +344,30 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
   }
 }
 
-void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta,
-            const SpmvDot *dot, const double *done) {
-  if (P.n == 0) return;
-  int chunk = (P.ntiles + NUM_XCD - 1) / NUM_XCD;
+int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta,
+           const SpmvDot *dot, const double *done, const SpmvRange *rng) {
+  if (P.n == 0) return 0;
+  const int t_begin = rng ? rng->t0 : 0;
+  const int ntl = rng ? rng->t1 - rng->t0 : P.ntiles;
+  const int part_off = rng ? rng->part_off : 0;
+  if (ntl <= 0) {
+    if (dot && rng && rng->reduce && part_off > 0) k_final_reduce(ctx, part_off, dot->mode == 2 ? 2 : 1, dot->slot, false, done);
+    return 0;
+  }
+  int chunk = (ntl + NUM_XCD - 1) / NUM_XCD;
   static const int wg_per_xcd = getenv("JH_SPMV_WGS") ? atoi(getenv("JH_SPMV_WGS")) : 256;  // 32 CUs x 8 workgroups
   const int mode = dot ? dot->mode : 0;
   const int per_xcd = mode ? std::min(chunk, wg_per_xcd) : chunk;  // plain SpMV: one tile per workgroup
   dim3 grid(per_xcd * NUM_XCD), block(TILE_THREADS);
-  if (mode) ensure_partials(ctx, (size_t)grid.x);
+  if (mode) ensure_partials(ctx, (size_t)grid.x + part_off);
   const double *dw = dot ? dot->w : nullptr;
   const int drows = dot ? (int)dot->n_rows : 0;
-  double *part = ctx->partials.p;
+  double *part = ctx->partials.p + part_off;
   const size_t ps = ctx->partial_stride;
   static const bool xwin = getenv("JH_SPMV_NO_WINDOW") == nullptr;
 #define JH_SPMV(BSV, DV)                                                                                                      \
   if (BSV == 1 && xwin) JH_SPMV_X(BSV, DV, true); else JH_SPMV_X(BSV, DV, false)
-#define JH_SPMV_X(BSV, DV, XWV) hipLaunchKernelGGL((spmv_tile_kernel<BSV, DV, (BSV == 1) && XWV>), grid, block, 0, ctx->stream, P.d_tile_row.p, P.ntiles, (int)P.n, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta, dw, drows, part, ps, done)
+#define JH_SPMV_X(BSV, DV, XWV) hipLaunchKernelGGL((spmv_tile_kernel<BSV, DV, (BSV == 1) && XWV>), grid, block, 0, ctx->stream, P.d_tile_row.p, ntl, (int)P.n, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta, dw, drows, part, ps, done, t_begin)
   switch (P.bs * 10 + mode) {
     case 10: JH_SPMV(1, 0); break;
     case 11: JH_SPMV(1, 1); break;
@@ -373,7 +382,9 @@ void k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x
   }
 #undef JH_SPMV
 #undef JH_SPMV_X
-  if (mode) k_final_reduce(ctx, (int)grid.x, mode == 2 ? 2 : 1, dot->slot, false, done);
+  // second stage of the fused dot: over the partials of all launches that make up this product
+  if (mode && (!rng || rng->reduce)) k_final_reduce(ctx, part_off + (int)grid.x, mode == 2 ? 2 : 1, dot->slot, false, done);
+  return (int)grid.x;
 }
 
 // unit_diagonalize!: ghost rows -> -I, r_ghost -> 0 (ext/JutulPartitionedArraysExt/linalg.jl:18-35)

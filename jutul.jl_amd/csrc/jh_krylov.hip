@@ -17,6 +17,8 @@ namespace jh {
 void ilu_apply(jh_ilu M, const double *b, double *x);
 bool ilu_can_fuse_gather(jh_ilu M);
 void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x);
+void halo_exchange_begin(jh_tpfa d, double *v, int bs);
+void halo_exchange_end(jh_tpfa d);
 void ilu_factor(jh_ilu M);
 void comm_allreduce_dev(jh_context ctx, double *p, int n, int op);
 void halo_exchange(jh_tpfa d, double *v, int bs);
@@ -49,7 +51,7 @@ struct jh_krylov_s {
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     if (gh_host) (void)hipHostFree(gh_host);
   }
-  void mark(int kind, hipStream_t st) {  // call before and after the profiled launch
+  void mark(int kind, hipStream_t st) {  // call before and after the profiled launch (kind 2: continuation of a kind-0 launch)
     if (!profiling) return;
     if (prof_stride > 1 && cur_it % prof_stride != 1) return;
     if (ev_used == ev_pool.size()) {
@@ -70,6 +72,7 @@ struct jh_krylov_s {
       float ms = 0;
       if (ev_it[i] > last_it) continue;
       if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) {
+        if (ev_kind[i] == 2) { prof_ms[0] += ms; continue; }  // second launch of a split SpMV: time only
         prof_ms[ev_kind[i]] += ms;
         prof_cnt[ev_kind[i]]++;
       }
@@ -265,6 +268,32 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   const bool fuse = right && ilu_can_fuse_gather(M);
   const int ghost_from = dist ? (int)(nd / P.bs) : 0x7fffffff;
   static const int lag = getenv("JH_SYNC_LOOP") ? 0 : 1;
+  // Rank-local subdomain: the device order is [interior blocks | boundary blocks | ghost blocks].  Opt-in
+  // (JH_HALO_OVERLAP=1): a fused half-iteration "v = A * N^-1(update)" runs as
+  //   compute stream: ILU(0) apply | SpMV(interior tiles) | wait | SpMV(boundary tiles)
+  //   comm stream   :              | pack, send/recv, unpack |
+  // hiding the ghost exchange of the preconditioned vector (consistent!, linalg.jl:46) behind the interior SpMV.
+  // Off by default: on one GPU with a real RCCL self send/recv (tools/overlap_probe.py, the 1.25M-cell share of the 8-GPU
+  // run) the two cross-stream event hops (~8 us each) and the second SpMV launch cost more than the 22 us exchange they
+  // hide (247 vs 214 us per iteration); also splitting the ILU apply doubled its latency-bound time (261 us).
+  static const bool want_overlap = getenv("JH_HALO_OVERLAP") != nullptr;
+  const bool overlap = dist && fuse && want_overlap && P.interior_tiles >= 0;
+  auto fused_half = [&](IluGather &G, double *pv, double *out, const SpmvDot &dot) {
+    K->mark(1, st);
+    ilu_apply_fused(M, G, pv);
+    K->mark(1, st);
+    halo_exchange_begin(disc, pv, P.bs);
+    SpmvRange r1{0, P.interior_tiles, 0, false};
+    K->mark(0, st);
+    const int g1 = k_spmv(ctx, P, K->A->val.p, pv, out, 1.0, 0.0, &dot, done, &r1);
+    K->mark(0, st);
+    halo_exchange_end(disc);
+    SpmvRange r2{P.interior_tiles, P.ntiles, g1, true};
+    K->mark(2, st);
+    k_spmv(ctx, P, K->A->val.p, pv, out, 1.0, 0.0, &dot, done, &r2);
+    K->mark(2, st);
+    comm_allreduce_dev(ctx, sc + dot.slot, dot.mode == 2 ? 2 : 1, 0);
+  };
   double seq_of[2] = {0, 0};
   // pair holding (rho, rr) at the start of iteration k; the next one goes to the other pair
   auto pair_of = [](int64_t k) { return (k & 1) ? (int)S_PAIR0 : (int)S_PAIR1; };
@@ -274,17 +303,26 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     const double *xin = X[(k - 1) & 1];
     double *xout = X[k & 1];
     double *yy = K->p.p;
+    bool v_done = false;
     if (fuse && k > 1) {  // p = r + beta*(p - omega*q) of the previous iteration, then y = N^-1 p
       IluGather G;
       G.mode = 2; G.r = K->r.p; G.q = K->q.p; G.out = K->p.p; G.sc = sc; G.done = done;
       G.rho_slot = pair_of(k - 1); G.rho_next_slot = rs; G.cv_slot = S_CV; G.ts_slot = S_TS; G.n_owned_rows = ghost_from;
-      K->mark(1, st);
-      ilu_apply_fused(M, G, K->y.p);
-      K->mark(1, st);
       yy = K->y.p;
+      if (overlap) {
+        // NB: q is an input of this gather (p-update) and the output of the SpMV, which follows it on the compute stream
+        SpmvDot d1{1, K->c.p, S_CV, rows_dot};
+        fused_half(G, yy, K->q.p, d1);
+        v_done = true;
+      } else {
+        K->mark(1, st);
+        ilu_apply_fused(M, G, K->y.p);
+        K->mark(1, st);
+      }
     } else if (right) { prec(K->p.p, K->y.p); yy = K->y.p; }
     double *vv = K->q.p;
-    if (left) {
+    if (v_done) {
+    } else if (left) {
       spmv(yy, K->q.p, nullptr);
       prec(K->q.p, K->v.p);
       vv = K->v.p;
@@ -294,20 +332,28 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       spmv(yy, K->q.p, &d1);
     }
     double *zz = K->s.p;
+    bool t_done = false;
     if (fuse) {  // s = r - alpha*q fused into z = N^-1 s
       IluGather G;
       G.mode = 1; G.r = K->r.p; G.q = vv; G.out = K->s.p; G.sc = sc; G.done = done;
       G.rho_slot = rs; G.cv_slot = S_CV; G.n_owned_rows = ghost_from;
-      K->mark(1, st);
-      ilu_apply_fused(M, G, K->z.p);
-      K->mark(1, st);
       zz = K->z.p;
+      if (overlap) {
+        SpmvDot d2{2, K->s.p, S_TS, rows_dot};
+        fused_half(G, zz, K->d.p, d2);
+        t_done = true;
+      } else {
+        K->mark(1, st);
+        ilu_apply_fused(M, G, K->z.p);
+        K->mark(1, st);
+      }
     } else {
       hipLaunchKernelGGL(bicg_s_kernel, vgrid(n), dim3(256), 0, st, K->s.p, K->r.p, vv, sc, rs, n);
       if (right) { prec(K->s.p, K->z.p); zz = K->z.p; }
     }
     double *tt = K->d.p;
-    if (left) {
+    if (t_done) {
+    } else if (left) {
       spmv(zz, K->d.p, nullptr);
       prec(K->d.p, K->t.p);
       tt = K->t.p;

@@ -28,11 +28,15 @@ void Pattern::build_tiles() {
     int64_t base = rowptr[r];
     // always take at least one row (a row longer than TILE_NNZ forms its own tile: "long row" path)
     ++r1;
-    while (r1 < n && (r1 - r) < TILE_ROWS && (rowptr[r1 + 1] - base) <= max_nnz) ++r1;
+    // a tile never straddles the interior / boundary limit of a rank-local subdomain (split SpMV, see jh_krylov.hip)
+    const int64_t lim = (interior_rows > r) ? interior_rows : n;
+    while (r1 < lim && (r1 - r) < TILE_ROWS && (rowptr[r1 + 1] - base) <= max_nnz) ++r1;
     tile_row.push_back((int32_t)r1);
+    if (r1 == interior_rows) interior_tiles = (int32_t)tile_row.size() - 1;
     r = r1;
   }
   ntiles = (int32_t)tile_row.size() - 1;
+  if (interior_rows == 0) interior_tiles = 0;
 }
 
 void Pattern::upload() {
@@ -84,7 +88,7 @@ static Adj build_adjacency(int64_t nc, int64_t nf, const int64_t *N) {
 // device ordering: compact blocks grown by BFS; blocks in creation order, cells in growth order
 // --------------------------------------------------------------------------------------------------------------
 static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block_rows, std::vector<int32_t> &perm,
-                         std::vector<int32_t> &block_ptr) {
+                         std::vector<int32_t> &block_ptr, int64_t &interior_rows, int32_t &interior_blocks) {
   // cells >= nc (ghosts of a rank-local subdomain) are never absorbed; they form the last block
   perm.clear();
   perm.reserve(nc_all);
@@ -143,6 +147,33 @@ static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block
       merged.push_back(block_ptr[i]);
   }
   block_ptr.swap(merged);
+  // rank-local subdomain: blocks touching a ghost cell ("boundary" blocks) go behind the interior ones, so that the halo
+  // exchange can run while the interior part of an ILU(0) apply / SpMV is computed.  Block-Jacobi ILU(0) does not depend
+  // on the order of the blocks, and the order inside a block is kept.
+  interior_rows = -1;
+  interior_blocks = -1;
+  if (nc < nc_all) {
+    const size_t nb = block_ptr.size() - 1;
+    std::vector<char> bnd(nb, 0);
+    for (size_t b = 0; b < nb; ++b)
+      for (int32_t i = block_ptr[b]; i < block_ptr[b + 1] && !bnd[b]; ++i) {
+        const int32_t c = perm[i];
+        for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k)
+          if (A.nbr[k] >= nc) { bnd[b] = 1; break; }
+      }
+    std::vector<int32_t> perm2, bp2(1, 0);
+    perm2.reserve(nc_all);
+    for (int pass = 0; pass < 2; ++pass) {
+      for (size_t b = 0; b < nb; ++b)
+        if (bnd[b] == pass) {
+          perm2.insert(perm2.end(), perm.begin() + block_ptr[b], perm.begin() + block_ptr[b + 1]);
+          bp2.push_back((int32_t)perm2.size());
+        }
+      if (pass == 0) { interior_rows = (int64_t)perm2.size(); interior_blocks = (int32_t)bp2.size() - 1; }
+    }
+    perm.swap(perm2);
+    block_ptr.swap(bp2);
+  }
   // ghost cells: their rows become -I (unit_diagonalize!), so any grouping works; keep the blocks LDS-sized
   for (int64_t c = nc; c < nc_all; ++c) {
     perm.push_back((int32_t)c);
@@ -203,7 +234,7 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
       // default: 512-row blocks; below ~2M rows the ILU(0) apply is bound by per-block latency, not bandwidth, and twice
       // as many half-size blocks fill the chip better (1.25M cells: apply 48 -> 40 us at equal iteration counts)
       if (block_rows <= 0) block_rows = nc < 2000000 ? 256 : 512;
-      order_blocks(A, nc, n_owned, block_rows, pat->perm, pat->block_ptr);
+      order_blocks(A, nc, n_owned, block_rows, pat->perm, pat->block_ptr, pat->interior_rows, pat->interior_blocks);
     } else if (reorder != JH_REORDER_NONE) {
       JH_THROW("unknown reorder mode");
     }
@@ -393,6 +424,16 @@ extern "C" int32_t jh_tpfa_get_ordering(jh_tpfa d, int64_t *perm, int64_t *nbloc
       if (block_ptr_cap < nb + 1) JH_THROW("block_ptr buffer too small");
       for (int64_t i = 0; i <= nb; ++i) block_ptr[i] = P.block_ptr[i];
     }
+  });
+}
+
+extern "C" int32_t jh_tpfa_get_split(jh_tpfa d, int64_t *interior_rows, int64_t *interior_blocks, int64_t *interior_tiles) {
+  return guard([&] {
+    if (!d) JH_THROW("null handle");
+    const Pattern &P = *d->pat;
+    if (interior_rows) *interior_rows = P.interior_rows;
+    if (interior_blocks) *interior_blocks = P.interior_blocks;
+    if (interior_tiles) *interior_tiles = P.interior_tiles;
   });
 }
 

@@ -175,6 +175,51 @@ def test_ghost_cells_do_not_break_lds_blocks(ja):
     assert prec.info()["lds_mode"]
 
 
+def test_interior_boundary_split_of_a_subdomain(ja):
+    """Device order of a rank-local subdomain: interior blocks (no ghost neighbour) first, then boundary blocks, then ghosts.
+    Every cell that is sent to a neighbour lies in a boundary block; interior rows reference no ghost column."""
+    from jutul_amd import dd
+    g, T, X0, _ = problem(ja, dims=(24, 20, 16))
+    part = dd.partition_rcb(g["cell_centroids"], 4)
+    ctx = ja.HIPContext(0)
+    disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, 1, T, g["volumes"], X0, block_rows=128)
+    n_owned, n_local = sub["n_owned"], sub["n_local"]
+    rows_i, blocks_i, tiles_i = disc.split()
+    perm, bp = disc.ordering()
+    assert 0 < rows_i < n_owned and 0 < blocks_i < len(bp) - 1 and tiles_i > 0
+    assert bp[blocks_i] == rows_i
+    iperm = np.empty(n_local, dtype=np.int64)
+    iperm[perm - 1] = np.arange(n_local)
+    N = sub["N"] - 1
+    ghost_nbr = np.zeros(n_local, dtype=bool)          # host cells with a ghost neighbour
+    ghost_nbr[N[0][N[1] >= n_owned]] = True
+    ghost_nbr[N[1][N[0] >= n_owned]] = True
+    dev_has_ghost = ghost_nbr[perm - 1]
+    assert not dev_has_ghost[:rows_i].any()
+    # every boundary block really touches a ghost (otherwise it would have been classified interior)
+    owned_blocks = np.searchsorted(bp, n_owned)
+    for b in range(blocks_i, owned_blocks):
+        assert dev_has_ghost[bp[b]:bp[b + 1]].any()
+    for cells in sub["send"]:
+        assert np.all(iperm[np.asarray(cells) - 1] >= rows_i)
+    assert np.all(perm[n_owned:] > n_owned)
+    # a single-process discretisation is not split
+    disc1 = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], g["nc"], reorder="blocks")
+    assert disc1.split() == (-1, -1, -1)
+
+
+def test_overlapped_halo_exchange_path():
+    """The opt-in overlapped ghost exchange (JH_HALO_OVERLAP=1: second stream, split interior/boundary SpMV) must give the
+    same distributed Newton results; the switch is read once per process, hence the subprocess."""
+    import os, subprocess, sys
+    env = dict(os.environ, JH_HALO_OVERLAP="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_distributed.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_distributed_newton_matches_single_rank or test_eight_ranks_many_neighbours"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_eight_ranks_many_neighbours(ja):
     """8 ranks (the node size the bench targets), RCB parts with up to 7 neighbours each: plan symmetry, ghost consistency and
     the distributed right-preconditioned Newton step == single rank."""
