@@ -97,7 +97,7 @@ def main():
         n_owned = nc_g
     else:
         part = dd.partition_rcb(mesh["cell_centroids"], world)
-        sub = dd.local_subdomain(mesh["N"], part, rank + 1)
+        sub = dd.local_subdomain(mesh["N"], part, rank + 1, ghost_order="owner")  # ghosts grouped by owner: direct receives
         uid = [ja.HIPContext.comm_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(uid, src=0)

@@ -5,7 +5,7 @@
 #include "jh_internal.hpp"
 
 namespace jh {
-void halo_exchange(jh_tpfa d, double *v, int bs);
+void halo_exchange(jh_tpfa d, double *v, int bs, bool packed = false);
 }
 using namespace jh;
 

@@ -119,11 +119,12 @@ void halo_pack_launch(hipStream_t s, double *buf, const double *v, const int32_t
 void halo_unpack_launch(hipStream_t s, double *v, const double *buf, const int32_t *idx, int64_t n, int bs);
 
 // consistent!(v): pack owned values -> grouped ncclSend/ncclRecv per neighbour -> unpack into ghost rows, all on stream s
-static void halo_exchange_on(jh_tpfa d, double *v, int bs, hipStream_t s) {
+// packed: the producer of v has already written the send buffer (fused ILU(0) apply)
+static void halo_exchange_on(jh_tpfa d, double *v, int bs, hipStream_t s, bool packed = false) {
   auto &H = d->halo;
   jh_context ctx = d->ctx;
   if (!ctx->comm) JH_THROW("halo exchange without a communicator (jh_comm_init)");
-  if (H.n_send) halo_pack_launch(s, H.d_send_buf.p, v, H.d_send_idx.p, H.n_send, bs);
+  if (H.n_send && !packed) halo_pack_launch(s, H.d_send_buf.p, v, H.d_send_idx.p, H.n_send, bs);
   if (ctx->comm->local) {
     LocalGroup &G = *ctx->comm->local;
     const int me = ctx->comm->rank;
@@ -151,21 +152,23 @@ static void halo_exchange_on(jh_tpfa d, double *v, int bs, hipStream_t s) {
   for (size_t i = 0; i < H.nbr.size(); ++i) {
     int64_t ns = H.send_ptr[i + 1] - H.send_ptr[i], nr = H.recv_ptr[i + 1] - H.recv_ptr[i];
     if (ns) JH_NCCL(R.Send(H.d_send_buf.p + H.send_ptr[i] * bs, (size_t)(ns * bs), ncclFloat64, H.nbr[i], ctx->comm->comm, s));
-    if (nr) JH_NCCL(R.Recv(H.d_recv_buf.p + H.recv_ptr[i] * bs, (size_t)(nr * bs), ncclFloat64, H.nbr[i], ctx->comm->comm, s));
+    // direct: the ghosts owned by this neighbour are consecutive device rows -> receive straight into the vector
+    double *dst = H.direct_recv ? v + (size_t)H.recv_row0[i] * bs : H.d_recv_buf.p + H.recv_ptr[i] * bs;
+    if (nr) JH_NCCL(R.Recv(dst, (size_t)(nr * bs), ncclFloat64, H.nbr[i], ctx->comm->comm, s));
   }
   JH_NCCL(R.GroupEnd());
-  if (H.n_recv) halo_unpack_launch(s, v, H.d_recv_buf.p, H.d_recv_idx.p, H.n_recv, bs);
+  if (H.n_recv && !H.direct_recv) halo_unpack_launch(s, v, H.d_recv_buf.p, H.d_recv_idx.p, H.n_recv, bs);
 }
 
-void halo_exchange(jh_tpfa d, double *v, int bs) {
+void halo_exchange(jh_tpfa d, double *v, int bs, bool packed) {
   if (!d->halo.active) return;
-  halo_exchange_on(d, v, bs, d->ctx->stream);
+  halo_exchange_on(d, v, bs, d->ctx->stream, packed);
 }
 
 // Overlapped form.  begin: everything enqueued on the compute stream so far (in particular the rows that are sent) is
 // what the exchange sees; it runs on the context's communication stream while the compute stream goes on with work
 // that neither writes v's owned boundary rows nor touches its ghost rows.  end: the compute stream waits for the ghosts.
-void halo_exchange_begin(jh_tpfa d, double *v, int bs) {
+void halo_exchange_begin(jh_tpfa d, double *v, int bs, bool packed) {
   if (!d->halo.active) return;
   jh_context ctx = d->ctx;
   if (!ctx->comm_stream) {
@@ -175,7 +178,7 @@ void halo_exchange_begin(jh_tpfa d, double *v, int bs) {
   }
   JH_HIP(hipEventRecord(ctx->ev_halo_ready, ctx->stream));
   JH_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_halo_ready, 0));
-  halo_exchange_on(d, v, bs, ctx->comm_stream);
+  halo_exchange_on(d, v, bs, ctx->comm_stream, packed);
   JH_HIP(hipEventRecord(ctx->ev_halo_done, ctx->comm_stream));
 }
 void halo_exchange_end(jh_tpfa d) {
@@ -290,6 +293,17 @@ extern "C" int32_t jh_halo_create(jh_tpfa d, int64_t n_owned, int32_t n_nbr, con
       if (c < n_owned || c >= d->nc) JH_THROW("recv cell is not a ghost cell");
       ri[i] = P.iperm.empty() ? (int32_t)c : P.iperm[c];
     }
+    // ghosts grouped by owner (dd.local_subdomain(ghost_order="owner")): every neighbour's receive list is a run of
+    // consecutive device rows and the unpack kernel is not needed
+    H.recv_row0.assign(n_nbr, 0);
+    H.direct_recv = true;
+    for (int32_t i = 0; i < n_nbr && H.direct_recv; ++i) {
+      if (H.recv_ptr[i + 1] > H.recv_ptr[i]) H.recv_row0[i] = ri[H.recv_ptr[i]];
+      for (int64_t k = H.recv_ptr[i] + 1; k < H.recv_ptr[i + 1]; ++k)
+        if (ri[k] != ri[k - 1] + 1) { H.direct_recv = false; break; }
+    }
+    H.send_idx_host = si;
+    ++H.epoch;
     hipStream_t s = d->ctx->stream;
     H.d_send_idx.upload(si, s);
     H.d_recv_idx.upload(ri, s);

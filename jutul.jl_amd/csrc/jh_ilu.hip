@@ -50,6 +50,10 @@ struct jh_ilu_s {
   DevBuf<int32_t> d_rowmap, d_blk_ptr, d_flev_off, d_flev_ptr, d_blev_off, d_blev_ptr, d_l_ptr, d_l_col, d_l_map, d_u_ptr,
       d_u_col, d_u_map, d_d_map, d_u_row, d_upos_of;
   DevBuf<double> l_val, u_val, dinv, xg;
+  // halo send rows per execution block (LDS mode, rank-local subdomain): the apply writes them into the send buffer too
+  std::vector<int32_t> send_ptr, send_local, send_slot;
+  DevBuf<int32_t> d_send_ptr, d_send_local, d_send_slot;
+  uint64_t halo_epoch = 0;
   bool factored = false;
 };
 
@@ -125,6 +129,9 @@ struct IluDev {
   const int32_t *rowmap, *blk_ptr, *flev_off, *flev_ptr, *blev_off, *blev_ptr;
   const int32_t *l_ptr, *l_col, *l_map, *u_ptr, *u_col, *u_map, *d_map, *u_row, *upos_of, *l_lev, *u_lev;
   double *l_val, *u_val, *dinv;
+  // fused halo pack (may be null): block b copies local rows send_local[j] to send_buf[send_slot[j]], j in [send_ptr[b], send_ptr[b+1])
+  const int32_t *send_ptr, *send_local, *send_slot;
+  double *send_buf;
 };
 
 // ---- numeric factorisation of one row (ilu0_factor!, ilu0.jl:108-144) -----------------------------------------------
@@ -570,6 +577,8 @@ template <int BS, int GM>
 __global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec,
                                                               IluGather G) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
+  if (GM == 2 && G.pub_rec && blockIdx.x == 0 && threadIdx.x == 0)
+    publish_record(G.sc_rw, G.pub_pair, G.pub_eps, G.pub_rec, G.pub_seq);  // raises the done flag on convergence
   if (GM != 0 && G.done && *G.done != 0.0) return;  // speculative launch after the Krylov solve has converged
   const int b = blockIdx.x;
   const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
@@ -609,6 +618,14 @@ __global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const d
     const int dev = F.rowmap[b0 + t];
 #pragma unroll
     for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[t * BS + e];
+  }
+  if (F.send_ptr) {  // rows that neighbouring ranks hold as ghosts go straight into the halo send buffer (no pack kernel)
+    for (int j = F.send_ptr[b] + (int)threadIdx.x; j < F.send_ptr[b + 1]; j += 64) {
+      const int t = F.send_local[j];
+      const size_t o = (size_t)F.send_slot[j] * BS;
+#pragma unroll
+      for (int e = 0; e < BS; ++e) F.send_buf[o + e] = xs[t * BS + e];
+    }
   }
 }
 
@@ -686,6 +703,7 @@ IluDev dev_view(jh_ilu M) {
   F.d_map = M->d_d_map.p; F.u_row = M->d_u_row.p; F.upos_of = M->d_upos_of.p;
   F.l_lev = M->d_l_lev.p; F.u_lev = M->d_u_lev.p;
   F.l_val = M->l_val.p; F.u_val = M->u_val.p; F.dinv = M->dinv.p;
+  F.send_ptr = nullptr; F.send_local = nullptr; F.send_slot = nullptr; F.send_buf = nullptr;
   return F;
 }
 
@@ -856,8 +874,30 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     M->u_lev.resize(n);
     for (int64_t t = 0; t < n; ++t) M->l_lev[t] = flev[order[t]];
     for (int64_t pos = 0; pos < n; ++pos) M->u_lev[pos] = blev[order[uord[pos]]];
+    // fused halo pack: (block, local row) of every send row of the discretisation's halo plan
+    if (lds && A->disc && A->disc->halo.active && A->disc->halo.n_send > 0) {
+      const auto &H = A->disc->halo;
+      std::vector<std::vector<std::pair<int32_t, int32_t>>> per(nb);
+      std::vector<int32_t> blk_of(n);
+      for (int64_t b = 0; b < nb; ++b)
+        for (int32_t t = M->blk_ptr[b]; t < M->blk_ptr[b + 1]; ++t) blk_of[t] = (int32_t)b;
+      for (int64_t i = 0; i < H.n_send; ++i) {
+        const int32_t t = ilu_of[H.send_idx_host[i]];
+        const int32_t b = blk_of[t];
+        per[b].push_back({t - M->blk_ptr[b], (int32_t)i});
+      }
+      M->send_ptr.assign(nb + 1, 0);
+      for (int64_t b = 0; b < nb; ++b) {
+        M->send_ptr[b + 1] = M->send_ptr[b] + (int32_t)per[b].size();
+        for (auto &pr : per[b]) { M->send_local.push_back(pr.first); M->send_slot.push_back(pr.second); }
+      }
+      M->halo_epoch = H.epoch;
+    }
     // upload
     hipStream_t s = M->ctx->stream;
+    if (!M->send_ptr.empty()) {
+      M->d_send_ptr.upload(M->send_ptr, s); M->d_send_local.upload(M->send_local, s); M->d_send_slot.upload(M->send_slot, s);
+    }
     M->d_l_lev.upload(M->l_lev, s); M->d_u_lev.upload(M->u_lev, s);
     M->d_rowmap.upload(M->rowmap, s); M->d_blk_ptr.upload(M->blk_ptr, s);
     M->d_flev_off.upload(M->flev_off, s); M->d_flev_ptr.upload(M->flev_ptr, s);
@@ -1036,10 +1076,20 @@ bool ilu_can_fuse_gather(jh_ilu M) {
   return M && M->kind == 0 && M->lds_mode && M->threads == 64 && !off;
 }
 // x = M^-1 * (fused vector update), see IluGather / ilu_apply_chunked_kernel
-void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x) {
+// true if ilu_apply_fused(..., pack = true) can fill the halo send buffer of the matrix' discretisation
+bool ilu_can_pack_halo(jh_ilu M) {
+  static const bool off = getenv("JH_NO_FUSED_PACK") != nullptr;
+  return !off && M && !M->send_ptr.empty() && M->A->disc && M->A->disc->halo.active && M->A->disc->halo.epoch == M->halo_epoch;
+}
+void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x, bool pack) {
   if (!M->factored) JH_THROW("ILU(0) applied before jh_ilu0_factor");
   hipStream_t s = M->ctx->stream;
   IluDev F = dev_view(M);
+  if (pack) {
+    if (!ilu_can_pack_halo(M)) JH_THROW("fused halo pack requested without a matching halo plan");
+    F.send_ptr = M->d_send_ptr.p; F.send_local = M->d_send_local.p; F.send_slot = M->d_send_slot.p;
+    F.send_buf = M->A->disc->halo.d_send_buf.p;
+  }
   const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
 #define JH_FUSED(BSV, GMV) hipLaunchKernelGGL((ilu_apply_chunked_kernel<BSV, GMV>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, (const double *)nullptr, x, G)
   switch (M->bs * 10 + G.mode) {

@@ -154,6 +154,10 @@ struct jh_tpfa_s {
     jh::DevBuf<double> d_send_buf, d_recv_buf;
     int64_t n_send = 0, n_recv = 0;
     bool active = false;
+    std::vector<int32_t> send_idx_host; // host copy of d_send_idx (the ILU(0) apply can fill the send buffer itself)
+    uint64_t epoch = 0;                // bumped by every jh_halo_create
+    bool direct_recv = false;          // each neighbour's ghosts are consecutive device rows: no unpack
+    std::vector<int32_t> recv_row0;    // first device row of every neighbour's ghosts (direct_recv)
   } halo;
 };
 
@@ -248,11 +252,27 @@ struct IluGather {
   int rho_slot = 0, rho_next_slot = 0, cv_slot = 0, ts_slot = 0;
   int n_owned_rows = 0x7fffffff;  // rows >= n_owned_rows are ghosts: their preconditioner input is zero (linalg.jl:78-88)
   const double *done = nullptr;   // launch is a no-op when *done != 0
+  // distributed runs: block 0 first publishes the previous iteration's record (publish_record), which needs the
+  // all-reduced scalars and therefore cannot be written by the kernel that produced them
+  double *pub_rec = nullptr, *sc_rw = nullptr;
+  double pub_seq = 0.0, pub_eps = 0.0;
+  int pub_pair = 0;
 };
 }  // namespace jh
 
 #if defined(__HIPCC__)
 namespace jh {
+// One record per Krylov iteration goes to pinned host memory so that the host can follow the solve without a stream
+// synchronisation: [0..8) scalars, [8] converged flag, [15] sequence number (written last, after a system-scope fence).
+__device__ __forceinline__ void publish_record(double *sc, int pair_slot, double eps, double *rec, double seq) {
+  const double rr = sc[pair_slot + 1];
+  const double conv = (sqrt(rr) <= eps) ? 1.0 : 0.0;
+  if (conv != 0.0) sc[S_DONE] = 1.0;  // later launches of this solve (one speculative iteration) become no-ops
+  for (int i = 0; i < 8; ++i) __hip_atomic_store(rec + i, sc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(rec + 8, conv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __hip_atomic_store(rec + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // Second stage of the deterministic two-stage reductions: ONE 1024-thread block sums (or maxes) nparts partials of
 // `count` slots in a fixed order.  The loads of a thread are independent (8 accumulators), so even ~50k partials cost a few
 // microseconds instead of a serial latency chain.  out[k] is written by thread 0.

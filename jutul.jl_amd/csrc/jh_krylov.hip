@@ -16,12 +16,13 @@
 namespace jh {
 void ilu_apply(jh_ilu M, const double *b, double *x);
 bool ilu_can_fuse_gather(jh_ilu M);
-void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x);
-void halo_exchange_begin(jh_tpfa d, double *v, int bs);
+void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x, bool pack = false);
+bool ilu_can_pack_halo(jh_ilu M);
+void halo_exchange_begin(jh_tpfa d, double *v, int bs, bool packed = false);
 void halo_exchange_end(jh_tpfa d);
 void ilu_factor(jh_ilu M);
 void comm_allreduce_dev(jh_context ctx, double *p, int n, int op);
-void halo_exchange(jh_tpfa d, double *v, int bs);
+void halo_exchange(jh_tpfa d, double *v, int bs, bool packed = false);
 }  // namespace jh
 using namespace jh;
 
@@ -94,17 +95,6 @@ __global__ void bicg_s_kernel(double *s, const double *r, const double *v, const
   const double alpha = sc[rho_slot] / sc[S_CV];
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     s[i] = r[i] - alpha * v[i];
-}
-// One record per Krylov iteration goes to pinned host memory so that the host can follow the solve without a stream
-// synchronisation: [0..8) scalars, [8] converged flag, [15] sequence number (written last, after a system-scope fence).
-__device__ __forceinline__ void publish_record(double *sc, int pair_slot, double eps, double *rec, double seq) {
-  const double rr = sc[pair_slot + 1];
-  const double conv = (sqrt(rr) <= eps) ? 1.0 : 0.0;
-  if (conv != 0.0) sc[S_DONE] = 1.0;  // later launches of this solve (one speculative iteration) become no-ops
-  for (int i = 0; i < 8; ++i) __hip_atomic_store(rec + i, sc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(rec + 8, conv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __threadfence_system();
-  __hip_atomic_store(rec + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void bicg_publish_kernel(double *sc, int pair_slot, double eps, double *rec, double seq) {
   if (threadIdx.x == 0 && blockIdx.x == 0) publish_record(sc, pair_slot, eps, rec, seq);
@@ -237,8 +227,8 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     comm_allreduce_dev(ctx, sc + slot, c2 ? 2 : 1, 0);
   };
   const int64_t rows_dot = nd / P.bs;
-  auto spmv = [&](double *in, double *out, const SpmvDot *dot) {
-    if (dist) halo_exchange(disc, in, P.bs);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
+  auto spmv = [&](double *in, double *out, const SpmvDot *dot, bool packed = false) {
+    if (dist) halo_exchange(disc, in, P.bs, packed);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
     K->mark(0, st);
     k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done);
     K->mark(0, st);
@@ -278,11 +268,13 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   // hide (247 vs 214 us per iteration); also splitting the ILU apply doubled its latency-bound time (261 us).
   static const bool want_overlap = getenv("JH_HALO_OVERLAP") != nullptr;
   const bool overlap = dist && fuse && want_overlap && P.interior_tiles >= 0;
+  // the fused ILU(0) apply also fills the halo send buffer with the rows neighbouring ranks hold as ghosts
+  const bool pack = dist && fuse && ilu_can_pack_halo(M);
   auto fused_half = [&](IluGather &G, double *pv, double *out, const SpmvDot &dot) {
     K->mark(1, st);
-    ilu_apply_fused(M, G, pv);
+    ilu_apply_fused(M, G, pv, pack);
     K->mark(1, st);
-    halo_exchange_begin(disc, pv, P.bs);
+    halo_exchange_begin(disc, pv, P.bs, pack);
     SpmvRange r1{0, P.interior_tiles, 0, false};
     K->mark(0, st);
     const int g1 = k_spmv(ctx, P, K->A->val.p, pv, out, 1.0, 0.0, &dot, done, &r1);
@@ -295,6 +287,8 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     comm_allreduce_dev(ctx, sc + dot.slot, dot.mode == 2 ? 2 : 1, 0);
   };
   double seq_of[2] = {0, 0};
+  double *pend_rec = nullptr, pend_seq = 0;  // record of the previous iteration still to be published (distributed runs)
+  int pend_pair = 0;
   // pair holding (rho, rr) at the start of iteration k; the next one goes to the other pair
   auto pair_of = [](int64_t k) { return (k & 1) ? (int)S_PAIR0 : (int)S_PAIR1; };
   auto enqueue = [&](int64_t k) {
@@ -303,11 +297,12 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     const double *xin = X[(k - 1) & 1];
     double *xout = X[k & 1];
     double *yy = K->p.p;
-    bool v_done = false;
+    bool v_done = false, y_packed = false, z_packed = false;
     if (fuse && k > 1) {  // p = r + beta*(p - omega*q) of the previous iteration, then y = N^-1 p
       IluGather G;
       G.mode = 2; G.r = K->r.p; G.q = K->q.p; G.out = K->p.p; G.sc = sc; G.done = done;
       G.rho_slot = pair_of(k - 1); G.rho_next_slot = rs; G.cv_slot = S_CV; G.ts_slot = S_TS; G.n_owned_rows = ghost_from;
+      if (pend_rec) { G.pub_rec = pend_rec; G.pub_seq = pend_seq; G.pub_pair = pend_pair; G.pub_eps = eps; G.sc_rw = sc; pend_rec = nullptr; }
       yy = K->y.p;
       if (overlap) {
         // NB: q is an input of this gather (p-update) and the output of the SpMV, which follows it on the compute stream
@@ -316,8 +311,9 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
         v_done = true;
       } else {
         K->mark(1, st);
-        ilu_apply_fused(M, G, K->y.p);
+        ilu_apply_fused(M, G, K->y.p, pack);
         K->mark(1, st);
+        y_packed = pack;
       }
     } else if (right) { prec(K->p.p, K->y.p); yy = K->y.p; }
     double *vv = K->q.p;
@@ -329,7 +325,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       dot2(K->c.p, vv, nullptr, nullptr, S_CV);
     } else {
       SpmvDot d1{1, K->c.p, S_CV, rows_dot};  // <c, A y> fused into the SpMV epilogue
-      spmv(yy, K->q.p, &d1);
+      spmv(yy, K->q.p, &d1, y_packed);
     }
     double *zz = K->s.p;
     bool t_done = false;
@@ -344,8 +340,9 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
         t_done = true;
       } else {
         K->mark(1, st);
-        ilu_apply_fused(M, G, K->z.p);
+        ilu_apply_fused(M, G, K->z.p, pack);
         K->mark(1, st);
+        z_packed = pack;
       }
     } else {
       hipLaunchKernelGGL(bicg_s_kernel, vgrid(n), dim3(256), 0, st, K->s.p, K->r.p, vv, sc, rs, n);
@@ -360,7 +357,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       dot2(tt, K->s.p, tt, tt, S_TS);
     } else {
       SpmvDot d2{2, K->s.p, S_TS, rows_dot};  // <t,s>, <t,t> fused
-      spmv(zz, K->d.p, &d2);
+      spmv(zz, K->d.p, &d2, z_packed);
     }
     const double seq = (double)(++ctx->pub_seq);
     seq_of[k & 1] = seq;
@@ -373,7 +370,10 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
                        sc, rn, done, eps, ctx->comm ? nullptr : rec, seq);
     if (ctx->comm) {
       comm_allreduce_dev(ctx, sc + rn, 2, 0);
-      hipLaunchKernelGGL(bicg_publish_kernel, dim3(1), dim3(64), 0, st, sc, rn, eps, rec, seq);
+      // the record needs the all-reduced pair: it is published by the first kernel of the next iteration (fused ILU gather)
+      // when there is one, otherwise by a one-thread kernel
+      if (fuse && lag == 1 && k < itmax) { pend_rec = rec; pend_seq = seq; pend_pair = rn; }
+      else hipLaunchKernelGGL(bicg_publish_kernel, dim3(1), dim3(64), 0, st, sc, rn, eps, rec, seq);
     }
     // p-update: deferred into the next iteration's first ILU apply when fused
     if (!fuse) hipLaunchKernelGGL(bicg_p_kernel, vgrid(n), dim3(256), 0, st, K->p.p, K->r.p, vv, sc, rs, rn, n);

@@ -167,10 +167,12 @@ def submap_cells(N, indices, nc=None, buffer=0, excluded=()):
     return dict(cells=cells, faces=np.flatnonzero(face_active) + 1, is_boundary=~inside[cells])
 
 
-def local_subdomain(N, p, rank):
+def local_subdomain(N, p, rank, ghost_order="global"):
     """Rank-local subdomain as PArraySimulator builds it (interface.jl:38-63 with submap_cells buffer = 0,
     dd/subdomains.jl:77-182): cells = [owned (findall order) ..., ghosts (ascending global id) ...]; faces kept iff
-    both cells are local.  `rank` is 1-based.  All returned index arrays are 1-based."""
+    both cells are local.  `rank` is 1-based.  All returned index arrays are 1-based.
+    ghost_order="owner" sorts the ghosts by (owning rank, global id) instead: every neighbour's ghosts are then consecutive
+    local cells and the device library receives them straight into the vectors (no unpack kernel)."""
     N = np.asarray(N, dtype=np.int64)
     p = np.asarray(p, dtype=np.int64)
     nc = p.size
@@ -179,6 +181,10 @@ def local_subdomain(N, p, rank):
     il, ir = mine[l], mine[r]
     owned = np.flatnonzero(mine)
     ghosts = np.unique(np.concatenate([r[il & ~ir], l[ir & ~il]]))
+    if ghost_order == "owner":
+        ghosts = ghosts[np.lexsort((ghosts, p[ghosts]))]
+    elif ghost_order != "global":
+        raise ValueError("ghost_order must be 'global' or 'owner'")
     n_owned = owned.size
     g2l = np.full(nc, -1, dtype=np.int64)
     g2l[owned] = np.arange(n_owned)
@@ -227,12 +233,12 @@ class HostExchange:
 
 
 def setup_rank_problem(ctx, N, part, rank, T, vol, X0, kind="poisson", block_n=1, sources=None, reorder="blocks",
-                       block_rows=512, law_params=None, gdz=None):
+                       block_rows=512, law_params=None, gdz=None, ghost_order="global"):
     """Builds this rank's discretisation + law the way PArraySimulator does per rank (interface.jl:38-63):
     submodel on [owned..., ghosts...], substate, halo plan.  `rank` is 0-based; `sources` = (cells 1-based global,
     values [n, block_n]).  Returns (disc, law, sub)."""
     from . import ConservationLaw, TwoPointPotentialFlowHardCoded
-    sub = local_subdomain(N, part, rank + 1)
+    sub = local_subdomain(N, part, rank + 1, ghost_order=ghost_order)
     cells = sub["cells"] - 1
     disc = TwoPointPotentialFlowHardCoded(ctx, sub["N"], sub["n_local"], block_n=block_n, reorder=reorder,
                                           block_rows=block_rows, n_owned=sub["n_owned"])

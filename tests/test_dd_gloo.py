@@ -173,6 +173,15 @@ def test_partition_and_subdomain_properties(oracle):
             assert np.array_equal(np.flatnonzero(loc[N[0]] & loc[N[1]]) + 1, sub["faces"])
             for s, snd, rcv in zip(sub["neighbors"], sub["send"], sub["recv"]):
                 assert np.all(p[gl[rcv - 1] - 1] == s + 1) and np.all(snd <= sub["n_owned"]) and np.all(rcv > sub["n_owned"])
+            # ghosts grouped by owner: same ghost set, every neighbour's receive list is a run of consecutive local cells
+            sub_o = dd.local_subdomain(N, p, r, ghost_order="owner")
+            assert np.array_equal(np.sort(sub_o["cells"][sub_o["n_owned"]:]), ghosts) and sub_o["n_owned"] == sub["n_owned"]
+            assert np.array_equal(sub_o["neighbors"], sub["neighbors"])
+            nxt = sub_o["n_owned"] + 1
+            for snd_o, snd, rcv in zip(sub_o["send"], sub["send"], sub_o["recv"]):
+                assert np.array_equal(rcv, np.arange(nxt, nxt + rcv.size)) and np.array_equal(snd_o, snd)
+                assert np.all(np.diff(sub_o["cells"][rcv - 1]) > 0)  # ascending global id inside an owner group
+                nxt += rcv.size
         assert owned_total == nc
 
 

@@ -228,7 +228,7 @@ def test_eight_ranks_many_neighbours(ja):
     nc = g["nc"]
     nranks = 8
     part = dd.partition_rcb(g["cell_centroids"], nranks)
-    subs = [dd.local_subdomain(g["N"], part, r + 1) for r in range(nranks)]
+    subs = [dd.local_subdomain(g["N"], part, r + 1, ghost_order="owner") for r in range(nranks)]
     assert max(len(s["neighbors"]) for s in subs) >= 3
     for r, s in enumerate(subs):  # what r sends to q is what q expects from r, in the same global order
         for q, snd in zip(s["neighbors"], s["send"]):
@@ -256,7 +256,8 @@ def test_eight_ranks_many_neighbours(ja):
     def rank_fn(r):
         ctx = ja.HIPContext(0)
         ctx.comm_init_local(group, r)
-        disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, r, T, g["volumes"], X0, sources=src, block_rows=256)
+        disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, r, T, g["volumes"], X0, sources=src, block_rows=256,
+                                               ghost_order="owner")
         ok, its, rep = make_sim(law).solve_ministep(dt)
         X = law.get_state()
         ctx.comm_finalize()

@@ -18,7 +18,7 @@ steps = int(os.environ.get("STEPS", "10"))
 mesh = ja.tet_lattice_mesh(*dims_for_cells(cells)); nc = mesh["nc"]
 T = mesh["T"] / mesh["T"].mean(); U0 = 1.0 + 0.1 * np.random.default_rng(3).random(nc)
 part = dd.partition_rcb(mesh["cell_centroids"], nparts)
-sub = dd.local_subdomain(mesh["N"], part, 1)
+sub = dd.local_subdomain(mesh["N"], part, 1, ghost_order=os.environ.get("GHOST_ORDER", "owner"))
 n_owned, n_local = sub["n_owned"], sub["n_local"]
 ctx = ja.HIPContext(0)
 ctx.comm_init(1, 0, ja.HIPContext.comm_unique_id())
