@@ -218,14 +218,15 @@ def main():
 
 def measured_traffic(kernel, cells, world):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected separately on
-    this same command, FETCH doubled per the gfx950 correction; tools/pmc_summary.py -> profiles/r01_traffic_*.json).
+    this same command, FETCH doubled per the gfx950 correction; tools/collect_profiles.sh + tools/pmc_summary.py ->
+    profiles/r01_d_traffic_*.json).
     PMC counters cannot be read from inside the benchmark, so the number is the committed measurement for the default
     1-GPU 10M-cell workload and None for anything else."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_10M_1gpu.json")
+    path = os.path.join(ROOT, "profiles", "r01_d_traffic_10M_1gpu.json")
     if world != 1 or not os.path.exists(path) or abs(cells - 10_025_988) > 0:
         return None
     names = {"ilu0_apply": ["ilu_apply_chunked_kernel<1, 1>", "ilu_apply_chunked_kernel<1, 2>"],
-             "spmv": ["spmv_tile_kernel<1, 1>", "spmv_tile_kernel<1, 2>"], "assembly": ["assemble_tile_kernel<0>"]}
+             "spmv": ["spmv_tile_kernel<1, 1, true>", "spmv_tile_kernel<1, 2, true>"], "assembly": ["assemble_tile_kernel<0>"]}
     try:
         with open(path) as f:
             d = json.load(f)
