@@ -198,50 +198,54 @@ __global__ void ilu_invert_kernel(double *dinv, int64_t n) {
 // 16-bit block-local metadata) is staged in LDS, factorised level by level there (every hop of the dependent
 // lookup chain l_col -> upos -> u_ptr -> u_col -> u_val costs an LDS access instead of an L2/HBM access), and
 // written back once, coalesced.  Same IKJ arithmetic as factor_row above.
+// dv holds A_ii for rows that are not finished yet and inv(D_ii) for finished ones (every row inverts its pivot when it is
+// done, so the elimination multiplies by the stored inverse instead of dividing once per L entry; same arithmetic:
+// nz_l * inv(A_kk)).
 template <int BS>
 __device__ __forceinline__ void factor_row_lds(int lt, double *lv, double *uv, double *dv, const uint16_t *lc, const uint16_t *uc,
                                                const uint16_t *lp, const uint16_t *up, const uint16_t *upos) {
   constexpr int BB = BS * BS;
   const int ipos = upos[lt];
   const int ls = lp[lt], le = lp[lt + 1];
-  if (ls == le) return;
-  const int us = up[ipos], ue = up[ipos + 1];
   Blk<BS> dii = blk_load<BS>(dv + (size_t)ipos * BB);
-  for (int p = ls; p < le; ++p) {
-    const int k = lc[p];
-    const int kpos = upos[k];
-    const Blk<BS> lik = blk_mul<BS>(blk_load<BS>(lv + (size_t)p * BB), blk_inv<BS>(blk_load<BS>(dv + (size_t)kpos * BB)));
-    blk_store<BS>(lv + (size_t)p * BB, lik);
-    if (!blk_nonzero<BS>(lik)) continue;
-    const int ks = up[kpos], ke = up[kpos + 1];
-    for (int p2 = p + 1; p2 < le; ++p2) {
-      const int j = lc[p2];
+  if (ls != le) {
+    const int us = up[ipos], ue = up[ipos + 1];
+    for (int p = ls; p < le; ++p) {
+      const int k = lc[p];
+      const int kpos = upos[k];
+      const Blk<BS> lik = blk_mul<BS>(blk_load<BS>(lv + (size_t)p * BB), blk_load<BS>(dv + (size_t)kpos * BB));
+      blk_store<BS>(lv + (size_t)p * BB, lik);
+      if (!blk_nonzero<BS>(lik)) continue;
+      const int ks = up[kpos], ke = up[kpos + 1];
+      for (int p2 = p + 1; p2 < le; ++p2) {
+        const int j = lc[p2];
+        for (int q = ks; q < ke; ++q)
+          if (uc[q] == j) {
+            Blk<BS> v = blk_load<BS>(lv + (size_t)p2 * BB);
+            blk_sub<BS>(v, blk_mul<BS>(lik, blk_load<BS>(uv + (size_t)q * BB)));
+            blk_store<BS>(lv + (size_t)p2 * BB, v);
+            break;
+          }
+      }
       for (int q = ks; q < ke; ++q)
-        if (uc[q] == j) {
-          Blk<BS> v = blk_load<BS>(lv + (size_t)p2 * BB);
-          blk_sub<BS>(v, blk_mul<BS>(lik, blk_load<BS>(uv + (size_t)q * BB)));
-          blk_store<BS>(lv + (size_t)p2 * BB, v);
-          break;
-        }
-    }
-    for (int q = ks; q < ke; ++q)
-      if (uc[q] == lt) { blk_sub<BS>(dii, blk_mul<BS>(lik, blk_load<BS>(uv + (size_t)q * BB))); break; }
-    for (int qi = us; qi < ue; ++qi) {
-      const int j = uc[qi];
-      for (int q = ks; q < ke; ++q)
-        if (uc[q] == j) {
-          Blk<BS> v = blk_load<BS>(uv + (size_t)qi * BB);
-          blk_sub<BS>(v, blk_mul<BS>(lik, blk_load<BS>(uv + (size_t)q * BB)));
-          blk_store<BS>(uv + (size_t)qi * BB, v);
-          break;
-        }
+        if (uc[q] == lt) { blk_sub<BS>(dii, blk_mul<BS>(lik, blk_load<BS>(uv + (size_t)q * BB))); break; }
+      for (int qi = us; qi < ue; ++qi) {
+        const int j = uc[qi];
+        for (int q = ks; q < ke; ++q)
+          if (uc[q] == j) {
+            Blk<BS> v = blk_load<BS>(uv + (size_t)qi * BB);
+            blk_sub<BS>(v, blk_mul<BS>(lik, blk_load<BS>(uv + (size_t)q * BB)));
+            blk_store<BS>(uv + (size_t)qi * BB, v);
+            break;
+          }
+      }
     }
   }
-  blk_store<BS>(dv + (size_t)ipos * BB, dii);
+  blk_store<BS>(dv + (size_t)ipos * BB, blk_inv<BS>(dii));
 }
 
 template <int BS>
-__global__ void ilu_factor_lds_kernel(IluDev F, const double *__restrict__ aval, int maxnl, int maxnu, int maxnr) {
+__global__ void ilu_factor_lds_kernel(IluDev F, const double *__restrict__ aval, int maxnl, int maxnu, int maxnr, int maxlev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BB = BS * BS;
   double *lv = reinterpret_cast<double *>(smem);
@@ -252,9 +256,13 @@ __global__ void ilu_factor_lds_kernel(IluDev F, const double *__restrict__ aval,
   uint16_t *lp = uc + maxnu;
   uint16_t *up = lp + (maxnr + 1);
   uint16_t *upos = up + (maxnr + 1);
+  uint16_t *levp = upos + maxnr;  // level starts (block-local rows) + end sentinel: no global load inside the level loop
+  (void)maxlev;
   const int b = blockIdx.x;
   const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
   const int nr = b1 - b0;
+  const int lev0 = F.flev_off[b], nlev = F.flev_off[b + 1] - 1 - lev0;
+  for (int l = threadIdx.x; l <= nlev; l += blockDim.x) levp[l] = (uint16_t)(F.flev_ptr[lev0 + l] - b0);
   const int l0 = F.l_ptr[b0], nl = F.l_ptr[b1] - l0;
   const int u0 = F.u_ptr[b0], nu = F.u_ptr[b1] - u0;
   const int T = blockDim.x, tid = threadIdx.x;
@@ -281,16 +289,14 @@ __global__ void ilu_factor_lds_kernel(IluDev F, const double *__restrict__ aval,
     }
   }
   __syncthreads();
-  const int lev0 = F.flev_off[b], lev1 = F.flev_off[b + 1] - 1;
-  for (int lev = lev0 + 1; lev < lev1; ++lev) {
-    const int s = F.flev_ptr[lev], e = F.flev_ptr[lev + 1];
-    for (int t = s + tid; t < e; t += T) factor_row_lds<BS>(t - b0, lv, uv, dv, lc, uc, lp, up, upos);
+  for (int lev = 0; lev < nlev; ++lev) {  // level 0 rows have no L entries: they only invert their pivot
+    const int s = levp[lev], e = levp[lev + 1];
+    for (int t = s + tid; t < e; t += T) factor_row_lds<BS>(t, lv, uv, dv, lc, uc, lp, up, upos);
     __syncthreads();
   }
   for (int j = tid; j < nl * BB; j += T) F.l_val[(size_t)l0 * BB + j] = lv[j];
   for (int j = tid; j < nu * BB; j += T) F.u_val[(size_t)u0 * BB + j] = uv[j];
-  for (int t = tid; t < nr; t += T)
-    blk_store<BS>(F.dinv + (size_t)(b0 + t) * BB, blk_inv<BS>(blk_load<BS>(dv + (size_t)t * BB)));
+  for (int j = tid; j < nr * BB; j += T) F.dinv[(size_t)b0 * BB + j] = dv[j];  // already inverted
 }
 
 // LDS mode: one workgroup per block, levels separated by __syncthreads()
@@ -862,7 +868,8 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         mxu = std::max<int64_t>(mxu, M->u_ptr[M->blk_ptr[b + 1]] - M->u_ptr[M->blk_ptr[b]]);
       }
       const size_t bbv = (size_t)P.bs * P.bs;
-      size_t bytes = sizeof(double) * bbv * (size_t)(mxl + mxu + maxrows) + sizeof(uint16_t) * (size_t)(mxl + mxu + 3 * maxrows + 2);
+      size_t bytes = sizeof(double) * bbv * (size_t)(mxl + mxu + maxrows) +
+                     sizeof(uint16_t) * (size_t)(mxl + mxu + 3 * maxrows + 2 + maxlev + 2);
       bytes = (bytes + 15) & ~(size_t)15;
       if (mxl < 65536 && mxu < 65536 && maxrows < 65536 && bytes <= LDS_CAP_BYTES && !getenv("JH_ILU_FACTOR_GLOBAL")) {
         M->max_blk_l = (int)mxl;
@@ -983,9 +990,9 @@ void ilu_factor(jh_ilu M) {
     // the bulk load/store phases want many lanes (memory-level parallelism); the level loop only needs a few
     static const int fthreads = getenv("JH_ILU_FACTOR_THREADS") ? atoi(getenv("JH_ILU_FACTOR_THREADS")) : 256;
     switch (M->bs) {
-      case 1: hipLaunchKernelGGL(ilu_factor_lds_kernel<1>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr); break;
-      case 2: hipLaunchKernelGGL(ilu_factor_lds_kernel<2>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr); break;
-      case 3: hipLaunchKernelGGL(ilu_factor_lds_kernel<3>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr); break;
+      case 1: hipLaunchKernelGGL(ilu_factor_lds_kernel<1>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr, (int)M->max_levels); break;
+      case 2: hipLaunchKernelGGL(ilu_factor_lds_kernel<2>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr, (int)M->max_levels); break;
+      case 3: hipLaunchKernelGGL(ilu_factor_lds_kernel<3>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr, (int)M->max_levels); break;
     }
     M->factored = true;
     return;
