@@ -196,9 +196,10 @@ static void wait_published(jh_context ctx, int rec, double seq, double *out) {
 // returns status; x must hold len doubles
 //
 // Host/device protocol: iteration k+1 is enqueued BEFORE the host looks at the outcome of iteration k, so the stream never
-// drains between iterations (the synchronous version idled the GPU ~30 us per iteration, 15% at 1.25M cells per GPU).  The
-// iterate ping-pongs between x and K->xalt, which keeps x_k intact while the speculative iteration k+1 runs; on
-// convergence the device raises sc[S_DONE] and the kernels of the speculative iteration return immediately.
+// drains between iterations and host-side launch cost (RCCL calls on the distributed path) is hidden.  The iterate
+// ping-pongs between x and K->xalt, which keeps x_k intact while the speculative iteration k+1 runs; on convergence the
+// device raises sc[S_DONE] and the kernels of the speculative iteration return immediately.  The host follows the solve
+// through records in pinned memory (wait_published): no stream synchronisation or D2H copy per iteration.
 int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, double rtol, double atol, int64_t itmax,
              int64_t *iters_out, double *hist, int64_t hist_cap) {
   jh_context ctx = K->ctx;
