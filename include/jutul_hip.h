@@ -203,6 +203,10 @@ int32_t jh_bicgstab(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh_vec x, dou
  * rule, status and history conventions as jh_bicgstab. */
 int32_t jh_gmres(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh_vec x, double rtol, double atol, int64_t itmax,
                  int64_t *iters, int32_t *status, double *hist, int64_t hist_cap);
+/* IterativeSolverConfig.min_iterations (linsolve/krylov.jl:120-131, 199-206).  n > 1: like the reference, the solvers
+ * run with atol = rtol = 1e-20 and stop as soon as ||r_k|| <= atol + rtol*||r_0|| holds at an iteration k >= n; that exit
+ * is reported as status 3 ("user-requested exit": Krylov.jl leaves stats.solved false).  n <= 1: plain stopping rule. */
+int32_t jh_krylov_set_min_iterations(jh_krylov K, int64_t min_iterations);
 /* PrecondWrapper-style instrumentation (linsolve/krylov.jl:5-25): accumulated HIP-event time [ms] and launch
  * count of [0] the SpMV and [1] the preconditioner apply inside jh_bicgstab / jh_newton_step.  Reads the
  * totals (ms2/count2 may be NULL), then optionally resets them and enables/disables further profiling.

@@ -488,8 +488,6 @@ class IterativeSolverConfig:
                  nonlinear_relative_tolerance=None, relaxed_relative_tolerance=0.1, true_residual=False,
                  precond_side="right", verbose=False):
         assert precond_side in ("left", "right")
-        if min_iterations > 1:
-            raise NotImplementedError("min_iterations > 1 (callback termination, krylov.jl:120-131) is not on the device path")
         self.relative_tolerance = relative_tolerance
         self.absolute_tolerance = absolute_tolerance
         self.max_iterations = max_iterations
@@ -527,6 +525,7 @@ class GenericKrylov(_Handle):
             self.close()
             check(_L().jh_krylov_create(A.h, C.byref(self.h)))
             self.A = A
+        check(_L().jh_krylov_set_min_iterations(self.h, int(self.config.min_iterations)))
         return self.h
 
     def profile(self, enable=True, reset=True):
@@ -604,8 +603,12 @@ def linear_solve(sys, krylov, atol=None, rtol=None, update_preconditioner=True, 
     t_solve = ctx.timer_stop_ms()
     n = iters.value
     res = hist[: n + 1].copy()
+    # min_iterations > 1: the callback ends the solve ("user-requested exit", status 3) and Krylov.jl's stats.solved stays
+    # false; only running into max_iterations counts as bad then (manual_conv, krylov.jl:120-131, 158-160)
     solved = status.value == 0
-    if not solved and res.size > 1 and res[-1] / res[0] > 1.0:  # krylov.jl:161-166
+    manual = cfg.min_iterations > 1
+    bad = (manual and n == cfg.max_iterations) or (not manual and not solved)
+    if bad and res.size > 1 and res[-1] / res[0] > 1.0:  # krylov.jl:161-166
         raise JutulHIPError(f"Bad linear solve: final residual {res[-1]}, rel. value {res[-1] / res[0]}")
     return dict(ok=solved, iterations=n, residuals=res, status=status.value, prepare=t_prec * 1e-3, time=t_solve * 1e-3)
 

@@ -45,6 +45,7 @@ SIGNATURES = {
     "jh_tpfa_get_positions_layout": [H, C.c_int32, I64P, I64P],
     "jh_tpfa_get_ordering": [H, I64P, I64P, I64P, C.c_int64],
     "jh_tpfa_get_split": [H, I64P, I64P, I64P],
+    "jh_krylov_set_min_iterations": [H, C.c_int64],
     "jh_vec_create": [H, C.POINTER(H)],
     "jh_vec_create_for": [H, C.POINTER(H)],
     "jh_vec_destroy": [H],

@@ -32,6 +32,7 @@ struct jh_krylov_s {
   int64_t len = 0;      // doubles per vector
   int64_t len_dot = 0;  // owned part (dots / norms)
   DevBuf<double> r, p, c, s, q, y, z, d, v, t, xalt;
+  int64_t min_its = 1;  // IterativeSolverConfig.min_iterations (krylov.jl:120-131)
   int64_t cur_it = 0;  // Krylov iteration the launches being enqueued belong to (profiling marks of speculative ones are dropped)
   // GMRES workspace: Krylov basis (grows on demand, Krylov.jl `restart = false`), device/pinned Hessenberg column
   std::vector<std::unique_ptr<DevBuf<double>>> gV;
@@ -249,10 +250,15 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   read_scalars(ctx, S_PAIR0, 2, h2);
   double rho = h2[0];
   double rnorm = std::sqrt(h2[1]);
-  const double eps = atol + rtol * rnorm;
+  // min_iterations > 1 (krylov.jl:120-131, 199-206): the reference hands Krylov.jl atol = rtol = 1e-20 and lets a callback
+  // stop the solve once ||r_k|| <= atol + rtol*||r_0|| AND k >= min_iterations ("user-requested exit": solved stays false)
+  const bool manual = K->min_its > 1;
+  const double eps_user = atol + rtol * rnorm;
+  const double eps_auto = manual ? 1e-20 + 1e-20 * rnorm : eps_user;
+  auto eps_at = [&](int64_t k) { return (manual && k < K->min_its) ? eps_auto : eps_user; };
   if (hist && hist_cap > 0) hist[0] = rnorm;
   int status = 0;
-  bool solved = rnorm <= eps;
+  bool solved = rnorm <= eps_auto;
   if (rho == 0.0 && !solved) status = 2;  // "Breakdown b'c = 0"
   ensure_partials(ctx, 4096);
   // right preconditioning: the s- and p-updates are fused into the gather phase of the ILU(0) apply
@@ -288,7 +294,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     comm_allreduce_dev(ctx, sc + dot.slot, dot.mode == 2 ? 2 : 1, 0);
   };
   double seq_of[2] = {0, 0};
-  double *pend_rec = nullptr, pend_seq = 0;  // record of the previous iteration still to be published (distributed runs)
+  double *pend_rec = nullptr, pend_seq = 0, pend_eps = 0;  // record of the previous iteration still to be published (distributed runs)
   int pend_pair = 0;
   // pair holding (rho, rr) at the start of iteration k; the next one goes to the other pair
   auto pair_of = [](int64_t k) { return (k & 1) ? (int)S_PAIR0 : (int)S_PAIR1; };
@@ -303,7 +309,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       IluGather G;
       G.mode = 2; G.r = K->r.p; G.q = K->q.p; G.out = K->p.p; G.sc = sc; G.done = done;
       G.rho_slot = pair_of(k - 1); G.rho_next_slot = rs; G.cv_slot = S_CV; G.ts_slot = S_TS; G.n_owned_rows = ghost_from;
-      if (pend_rec) { G.pub_rec = pend_rec; G.pub_seq = pend_seq; G.pub_pair = pend_pair; G.pub_eps = eps; G.sc_rw = sc; pend_rec = nullptr; }
+      if (pend_rec) { G.pub_rec = pend_rec; G.pub_seq = pend_seq; G.pub_pair = pend_pair; G.pub_eps = pend_eps; G.sc_rw = sc; pend_rec = nullptr; }
       yy = K->y.p;
       if (overlap) {
         // NB: q is an input of this gather (p-update) and the output of the SpMV, which follows it on the compute stream
@@ -368,13 +374,13 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     hipLaunchKernelGGL(bicg_xr_dots_kernel, g, dim3(256), 0, st, xin, xout, K->r.p, yy, zz, K->s.p, tt, K->c.p, sc, rs, n, nd,
                        ctx->partials.p, ctx->partial_stride, done);
     hipLaunchKernelGGL(bicg_reduce_publish_kernel, dim3(1), dim3(FIN_THREADS), 0, st, ctx->partials.p, ctx->partial_stride, (int)g.x,
-                       sc, rn, done, eps, ctx->comm ? nullptr : rec, seq);
+                       sc, rn, done, eps_at(k), ctx->comm ? nullptr : rec, seq);
     if (ctx->comm) {
       comm_allreduce_dev(ctx, sc + rn, 2, 0);
       // the record needs the all-reduced pair: it is published by the first kernel of the next iteration (fused ILU gather)
       // when there is one, otherwise by a one-thread kernel
-      if (fuse && lag == 1 && k < itmax) { pend_rec = rec; pend_seq = seq; pend_pair = rn; }
-      else hipLaunchKernelGGL(bicg_publish_kernel, dim3(1), dim3(64), 0, st, sc, rn, eps, rec, seq);
+      if (fuse && lag == 1 && k < itmax) { pend_rec = rec; pend_seq = seq; pend_pair = rn; pend_eps = eps_at(k); }
+      else hipLaunchKernelGGL(bicg_publish_kernel, dim3(1), dim3(64), 0, st, sc, rn, eps_at(k), rec, seq);
     }
     // p-update: deferred into the next iteration's first ILU apply when fused
     if (!fuse) hipLaunchKernelGGL(bicg_p_kernel, vgrid(n), dim3(256), 0, st, K->p.p, K->r.p, vv, sc, rs, rn, n);
@@ -392,7 +398,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     solved = h[8] != 0.0;
     if (alpha == 0.0 || alpha != alpha) status = 2;
   }
-  if (solved) status = 0;
+  if (solved) status = (manual && rnorm > eps_auto) ? 3 : 0;
   else if (status == 0 && it >= itmax) status = 1;
   if (it & 1) k_copy(st, x, X[1], n);  // iterate of the last accepted iteration
   if (dist) halo_exchange(disc, x, P.bs);  // consistent!(x) (ext/.../krylov.jl:75)
@@ -454,11 +460,14 @@ int gmres(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, double
   dot_to(w, w, K->gh.p);
   read(1);
   const double beta = std::sqrt(K->gh_host[0]);
-  const double eps = atol + rtol * beta;
+  const bool manual = K->min_its > 1;  // see bicgstab
+  const double eps_user = atol + rtol * beta;
+  const double eps_auto = manual ? 1e-20 + 1e-20 * beta : eps_user;
   if (hist && hist_cap > 0) hist[0] = beta;
   int64_t it = 0;
   int status = 0;
-  bool solved = beta <= eps;
+  bool solved = beta <= eps_auto;
+  double rnorm_last = beta;
   std::vector<double> R, cs, sn, z;  // R packed by columns: column k holds k+1 entries
   std::vector<size_t> colptr(1, 0);
   z.push_back(beta);
@@ -499,7 +508,8 @@ int gmres(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, double
     z[k] = c * z[k];
     const double rnorm = std::fabs(z[k + 1]);
     if (hist && it < hist_cap) hist[it] = rnorm;
-    solved = rnorm <= eps;
+    rnorm_last = rnorm;
+    solved = rnorm <= ((manual && it < K->min_its) ? eps_auto : eps_user);
     if (!solved) {
       if (hbis == 0.0) { status = 2; break; }
       k_axpby(st, basis(k + 1), 1.0 / hbis, w, 0.0, n);
@@ -517,7 +527,7 @@ int gmres(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, double
   for (size_t jj = 0; jj < m; ++jj) k_axpby(st, tmp, y[jj], basis(jj), 1.0, n);
   if (right) prec(tmp, x); else k_copy(st, x, tmp, n);
   if (dist) halo_exchange(disc, x, P.bs);
-  if (solved) status = 0;
+  if (solved) status = (manual && rnorm_last > eps_auto) ? 3 : 0;
   else if (status == 0 && it >= itmax) status = 1;
   *iters_out = it;
   K->collect();
@@ -534,6 +544,13 @@ extern "C" int32_t jh_gmres(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh_ve
     if (b->len != K->len || x->len != K->len) JH_THROW("dimension mismatch in gmres");
     JH_HIP(hipSetDevice(K->ctx->device));
     *status = jh::gmres(K, M, side, b->d.p, x->d.p, rtol, atol, itmax, iters, hist, hist_cap);
+  });
+}
+
+extern "C" int32_t jh_krylov_set_min_iterations(jh_krylov K, int64_t min_iterations) {
+  return guard([&] {
+    if (!K) JH_THROW("null handle");
+    K->min_its = min_iterations < 1 ? 1 : min_iterations;
   });
 }
 

@@ -793,8 +793,6 @@ def test_krylov_tolerance_options(ja, ctx, oracle):
     second, _ = solve(sub=2)  # same ||r||: rtol = max(min(r0*1e-2/r_k, 0.1), 1e-8) = 1e-2
     assert second["iterations"] < first["iterations"]
     assert second["residuals"][-1] <= 1e-12 + 1e-2 * second["residuals"][0] * 1.0001
-    with pytest.raises(NotImplementedError):
-        ja.IterativeSolverConfig(min_iterations=3)
 
 
 # ---- GMRES -----------------------------------------------------------------------------------------------------------------
@@ -853,3 +851,37 @@ def test_no_device_memory_leak_over_handle_lifetimes(ja, ctx, oracle):
     ctx.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20  # < 8 MiB drift (allocator granularity), one cycle allocates > 100 MiB
+
+
+def test_min_iterations_callback_termination(ja):
+    """IterativeSolverConfig.min_iterations (krylov.jl:120-131, 199-206): the solve may stop only at an iteration k >= min_iterations
+    with ||r_k|| <= atol + rtol*||r_0||; the exit is Krylov.jl's "user-requested exit" (stats.solved == false)."""
+    g = ja.tet_lattice_mesh(6, 5, 4)
+    nc = g["nc"]
+    T = g["T"] / g["T"].mean()
+    ctx = ja.HIPContext(0)
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, reorder="blocks", block_rows=64)
+    law = ja.ConservationLaw(disc, "poisson")
+    law.set_face_trans(T); law.set_volumes(g["volumes"])
+    U = 1.0 + 0.1 * np.random.default_rng(1).random(nc)
+    law.set_state(U); law.set_state0(np.zeros(nc))
+    def solve(solver, min_it):
+        lsys = ja.LinearizedSystem(disc)
+        law.update_equation_and_linearized_system(1.0, lsys.jac, lsys.r)
+        ks = ja.GenericKrylov(solver, preconditioner=ja.ILUZeroPreconditioner(partition="blocks"), relative_tolerance=1e-2,
+                              max_iterations=80, min_iterations=min_it)
+        return ja.linear_solve(lsys, ks)
+
+    for solver in ("bicgstab", "gmres"):
+        base = solve(solver, 1)
+        n1 = base["iterations"]
+        assert base["ok"] and base["status"] == 0 and 3 <= n1 <= 60
+        # below the natural count the callback changes nothing but the reported status
+        low = solve(solver, n1 - 1)
+        assert low["iterations"] == n1 and low["status"] == 3 and not low["ok"]
+        np.testing.assert_allclose(low["residuals"], base["residuals"], rtol=1e-12)
+        # above it the solver keeps iterating until min_iterations and the residual keeps falling
+        high = solve(solver, n1 + 6)
+        assert high["iterations"] == n1 + 6 and high["status"] == 3
+        assert high["residuals"][n1 + 6] < base["residuals"][n1]
+        np.testing.assert_allclose(high["residuals"][: n1 + 1], base["residuals"], rtol=1e-9)
