@@ -1,6 +1,7 @@
 """Size-independent properties at BASELINE.json's full sizes (the oracle would take minutes there):
 10M-cell single-phase grid (configs[1]/[4] family) and a 5M-cell two-phase grid (configs[3]): row sums, conservation,
-linearity of the residual, SpMV adjoint identity, ILU-preconditioned solve residual check with the GPU SpMV."""
+linearity of the residual, SpMV adjoint identity, ILU-preconditioned solve residual check with the GPU SpMV; and the
+1M-cell case decomposed over 8 ranks (configs[2]) against the single-rank Newton update."""
 import numpy as np
 import pytest
 
@@ -120,3 +121,60 @@ def test_5M_cells_two_phase_block_properties(ja):
     assert res.dot(res) ** 0.5 <= 2e-8 * sim.lsys.r.dot(sim.lsys.r) ** 0.5
     ok, its, rep = sim.solve_ministep(dt)
     assert ok and its <= 8
+
+
+def test_1M_cells_eight_ranks_match_single_rank(ja):
+    """BASELINE configs[2]: the 1M-cell single-phase case domain-decomposed over 8 ranks (here 8 in-process ranks on one GPU,
+    the DebugPArrayBackend analogue) with ghost halo exchange and block-Jacobi ILU(0) gives the single-rank Newton update."""
+    import threading
+    from bench import dims_for_cells
+    from jutul_amd import dd
+    g = ja.tet_lattice_mesh(*dims_for_cells(1_000_000))
+    nc = g["nc"]
+    assert nc > 990_000
+    T = g["T"] / g["T"].mean()
+    X0 = 1.0 + 0.1 * np.random.default_rng(3).random(nc)
+    dt, nranks = 5.0, 8
+    src = ([1, nc], np.array([[1.0], [-1.0]]))
+
+    def make_sim(law):
+        ks = ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"), relative_tolerance=1e-10,
+                              max_iterations=400, precond_side="right")
+        return ja.Simulator(law, ks, tolerance=1e-8)
+
+    ctx0 = ja.HIPContext(0)
+    disc0 = ja.TwoPointPotentialFlowHardCoded(ctx0, g["N"], nc, reorder="blocks")
+    law0 = ja.ConservationLaw(disc0, "poisson")
+    law0.set_face_trans(T); law0.set_volumes(g["volumes"]); law0.set_state(X0); law0.set_state0(X0)
+    law0.set_sources(src[0], src[1].reshape(-1))
+    ok0, its0, _ = make_sim(law0).solve_ministep(dt)
+    assert ok0
+    X_ref = law0.get_state()
+    part = dd.partition_rcb(g["cell_centroids"], nranks)
+    group = ja.LocalCommGroup(nranks)
+    out, err = [None] * nranks, []
+
+    def rank_fn(r):
+        try:
+            ctx = ja.HIPContext(0)
+            ctx.comm_init_local(group, r)
+            disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, r, T, g["volumes"], X0, sources=src, block_rows=0,
+                                                   ghost_order="owner")
+            assert disc.split()[0] > 0
+            ok, its, rep = make_sim(law).solve_ministep(dt)
+            out[r] = (ok, its, sub, law.get_state())
+            ctx.comm_finalize()
+        except Exception as e:  # a failing rank would leave the others waiting in a collective
+            err.append(e)
+            raise
+
+    th = [threading.Thread(target=rank_fn, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join(600) for t in th]
+    assert not err, err
+    X = np.zeros(nc)
+    for ok, its, sub, Xl in out:
+        assert ok and its == its0
+        X[sub["cells"][: sub["n_owned"]] - 1] = Xl[: sub["n_owned"]]
+        assert np.allclose(Xl[sub["n_owned"]:], X_ref[sub["cells"][sub["n_owned"]:] - 1], rtol=1e-7, atol=1e-9)
+    assert np.abs(X - X_ref).max() <= 1e-7 * np.abs(X_ref).max()
