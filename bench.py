@@ -60,6 +60,7 @@ def main():
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
         del os.environ["NCCL_DEBUG"]
     os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/jutul_hip_rccl_%h_%p.log")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
