@@ -89,6 +89,7 @@ def main():
     U0 = 1.0 + 0.1 * rng.random(nc_g)
     vol = mesh["volumes"]
     ctx = ja.HIPContext(local_rank)
+    mailbox = False
     force_dist = os.environ.get("JH_BENCH_FORCE_DIST") == "1"  # exercise the distributed code path on one rank
     if world == 1 and not force_dist:
         disc = ja.TwoPointPotentialFlowHardCoded(ctx, mesh["N"], nc_g, reorder="blocks", block_rows=args.block_rows)
@@ -103,6 +104,25 @@ def main():
         if world > 1:
             dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(world, rank, uid[0])
+        if world > 1:
+            # scalar all-reduces of the Krylov loop through peer-mapped mailboxes (xGMI stores) instead of ncclAllReduce:
+            # handles all-gathered over the control plane, self-test on every rank, used only if all ranks passed it
+            try:
+                handle = ctx.comm_ipc_export()
+            except Exception:  # noqa: BLE001
+                handle = None
+            handles = [None] * world
+            dist.all_gather_object(handles, handle)  # every rank takes part, whatever happened above
+            ok = False
+            if all(h is not None for h in handles):
+                try:
+                    ok = ctx.comm_ipc_attach(handles)  # time-limited self-test inside
+                except Exception:  # noqa: BLE001
+                    ok = False
+            flag = torch.tensor([1 if ok else 0])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            mailbox = bool(int(flag[0])) and os.environ.get("JH_BENCH_NO_MAILBOX") != "1"
+            ctx.comm_ipc_enable(mailbox)
         cells = sub["cells"] - 1
         n_owned = sub["n_owned"]
         disc = ja.TwoPointPotentialFlowHardCoded(ctx, sub["N"], sub["n_local"], reorder="blocks", block_rows=args.block_rows,
@@ -138,6 +158,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    barrier()  # ranks finish their setup seconds apart
     for _ in range(args.warmup):
         step()
     ks.profile(enable=args.profile_stride, reset=True)  # HIP-event pairs around every n-th iteration's SpMV / ILU launches
@@ -200,6 +221,7 @@ def main():
                                    f"assembly + block-Jacobi ILU(0) factor + BiCGStab(rtol={args.rtol})",
                        "cells": nc_g, "faces": nf_g, "dt": args.dt, "block_rows": args.block_rows or (256 if disc.nc < 2_000_000 else 512),
                        "parallelism": f"dd{world}" if world > 1 else "single", "precond_side": ks.config.precond_side,
+                       "scalar_allreduce": ("mailbox" if mailbox else "rccl") if world > 1 else None,
                        "ilu_blocks": info["nblocks"], "ilu_max_levels": info["max_levels"],
                        "linear_iterations_per_step": round(float(np.mean(lin_its)), 2),
                        "setup_s": round(t_setup, 1)},

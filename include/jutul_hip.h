@@ -242,6 +242,24 @@ int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_vec r, jh_v
 int32_t jh_comm_unique_id(char *id128);
 int32_t jh_comm_init(jh_context ctx, int32_t nranks, int32_t rank, const char *id128);
 int32_t jh_comm_finalize(jh_context ctx);
+/* Mailbox all-reduce for the ranks of ONE node: the Krylov loop's scalar reductions (mpi_scalar_allreduce,
+ * ext/.../utils.jl:232-234; 1-2 doubles, three per BiCGStab iteration) bypass ncclAllReduce and go through peer-mapped
+ * uncached device memory (hipIpc): one single-wavefront kernel per reduction, summation in rank order (identical bits on
+ * every rank).  Protocol: each rank calls jh_comm_ipc_export (64-byte handle of its mailbox), the host all-gathers the
+ * handles (MPI.Allgather / torch.distributed), each rank calls jh_comm_ipc_attach (maps the peers and self-tests 64
+ * reductions with known answers, time-out guarded: *ok = 0 on any failure), the host ANDs the *ok of all ranks and calls
+ * jh_comm_ipc_enable.  Without enable, ncclAllReduce is used.  jh_comm_init_ipc_only creates a communicator without RCCL
+ * (scalar reductions only): for tests with several processes on one GPU. */
+int32_t jh_comm_init_ipc_only(jh_context ctx, int32_t nranks, int32_t rank);
+/* Host-language halo backend: instead of ncclSend/ncclRecv the library stages the packed send buffer to the host and calls
+ * fn(user, send, n_send, recv, n_recv, block_n), which must fill recv (both buffers hold block_n doubles per cell, the
+ * neighbours' segments in the order of jh_halo_create) and return 0 -- e.g. MPI.Isend/Irecv from Julia, or gloo.  Used
+ * with jh_comm_init or jh_comm_init_ipc_only; fn == NULL restores the RCCL exchange. */
+typedef int32_t (*jh_halo_callback)(void *user, const double *send, int64_t n_send, double *recv, int64_t n_recv, int32_t block_n);
+int32_t jh_comm_set_halo_callback(jh_context ctx, jh_halo_callback fn, void *user);
+int32_t jh_comm_ipc_export(jh_context ctx, char *handle64);
+int32_t jh_comm_ipc_attach(jh_context ctx, const char *handles, int32_t *ok);
+int32_t jh_comm_ipc_enable(jh_context ctx, int32_t enable);
 /* In-process multi-rank backend (the analogue of DebugPArrayBackend / JuliaPArrayBackend,
  * src/ext/partitionedarrays_ext.jl:37-39): ranks are host threads of one process exchanging through host memory;
  * same pack/unpack kernels, halo plans and reduction placement as the RCCL path.  For tests on one GPU. */

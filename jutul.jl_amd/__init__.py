@@ -98,6 +98,48 @@ class HIPContext(_Handle):
         check(_L().jh_comm_init_local(self.h, group.h, int(rank)))
         self.comm_size, self.comm_rank = group.nranks, rank
 
+    def comm_init_ipc_only(self, nranks, rank):
+        """Communicator without RCCL: scalar all-reduces through the mailboxes only (several processes on one GPU, tests)."""
+        check(_L().jh_comm_init_ipc_only(self.h, int(nranks), int(rank)))
+        self.comm_size, self.comm_rank = nranks, rank
+
+    def comm_set_halo_callback(self, fn):
+        """Host-language halo backend: fn(send: ndarray, recv: ndarray, block_n) fills recv in place (segments per
+        neighbour in halo-plan order).  None restores the RCCL exchange."""
+        if fn is None:
+            check(_L().jh_comm_set_halo_callback(self.h, None, None))
+            self._halo_cb = None
+            return
+        proto = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_int64, C.c_int32)
+
+        def tramp(_user, send, ns, recv, nr, bs):
+            try:
+                snd = np.ctypeslib.as_array(send, shape=(ns,)) if ns else np.zeros(0)
+                rcv = np.ctypeslib.as_array(recv, shape=(nr,)) if nr else np.zeros(0)
+                fn(snd, rcv, int(bs))
+                return 0
+            except Exception:  # noqa: BLE001  (must not unwind through the C frame)
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._halo_cb = proto(tramp)  # keep the trampoline alive as long as the context uses it
+        check(_L().jh_comm_set_halo_callback(self.h, C.cast(self._halo_cb, C.c_void_p), None))
+
+    def comm_ipc_export(self):
+        """64-byte IPC handle of this rank's mailbox (to be all-gathered by the host)."""
+        buf = C.create_string_buffer(64)
+        check(_L().jh_comm_ipc_export(self.h, buf))
+        return buf.raw
+
+    def comm_ipc_attach(self, handles):
+        """Maps every rank's mailbox (handles: list of 64-byte strings in rank order) and self-tests; True if usable."""
+        ok = C.c_int32(0)
+        check(_L().jh_comm_ipc_attach(self.h, b"".join(handles), C.byref(ok)))
+        return bool(ok.value)
+
+    def comm_ipc_enable(self, enable=True):
+        check(_L().jh_comm_ipc_enable(self.h, 1 if enable else 0))
+
     def comm_finalize(self):
         check(_L().jh_comm_finalize(self.h))
 

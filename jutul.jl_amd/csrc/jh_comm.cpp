@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -81,18 +82,43 @@ struct LocalGroup {
   }
 };
 
+struct Mailbox;  // jh_halo.hip
 struct Comm {
   ncclComm_t comm = nullptr;
   LocalGroup *local = nullptr;
   int nranks = 1, rank = 0;
+  // mailbox all-reduce (jh_comm_ipc_*): every rank's mailbox mapped into this process
+  Mailbox *mail_self = nullptr;
+  std::vector<Mailbox *> mail_peer;  // [nranks], mail_peer[rank] == mail_self
+  DevBuf<Mailbox *> d_mail_peer;
+  uint64_t mail_epoch = 0;
+  bool mail_attached = false, mail_enabled = false;
+  // host-language halo backend (jh_comm_set_halo_callback): the packed send buffer is staged to the host and exchanged there
+  jh_halo_callback halo_cb = nullptr;
+  void *halo_cb_user = nullptr;
+  std::vector<double> cb_send, cb_recv;
+  volatile unsigned *mail_err = nullptr;  // pinned + mapped: != 0 after a timed-out wait
 };
 
 int comm_size(jh_context ctx) { return ctx->comm ? ctx->comm->nranks : 1; }
 int comm_rank(jh_context ctx) { return ctx->comm ? ctx->comm->rank : 0; }
 
+void mailbox_allreduce_launch(hipStream_t s, Mailbox *self, Mailbox *const *peers, int rank, int nranks, uint64_t epoch, double *p,
+                              int n, int op, unsigned *err, uint64_t timeout_ticks);
+size_t mailbox_bytes();
+constexpr int MAIL_MAX_RANKS = 16, MAIL_MAX_VALUES = 8;
+
+// timeout_ticks: 100 MHz ticks, 0 = wait like a collective
+static void mailbox_allreduce(jh_context ctx, double *p, int n, int op, uint64_t timeout_ticks = 0) {
+  Comm &c = *ctx->comm;
+  mailbox_allreduce_launch(ctx->stream, c.mail_self, c.d_mail_peer.p, c.rank, c.nranks, ++c.mail_epoch, p, n, op,
+                           const_cast<unsigned *>(c.mail_err), timeout_ticks);
+}
+
 // in-stream all-reduce of n doubles living in device memory; no-op without a communicator
 void comm_allreduce_dev(jh_context ctx, double *p, int n, int op) {
   if (!ctx->comm || ctx->comm->nranks == 1) return;
+  if (ctx->comm->mail_enabled && n <= MAIL_MAX_VALUES) { mailbox_allreduce(ctx, p, n, op); return; }
   if (ctx->comm->local) {
     LocalGroup &G = *ctx->comm->local;
     const int r = ctx->comm->rank;
@@ -112,6 +138,7 @@ void comm_allreduce_dev(jh_context ctx, double *p, int n, int op) {
     JH_HIP(hipStreamSynchronize(ctx->stream));
     return;
   }
+  if (!ctx->comm->comm) JH_THROW("all-reduce without an RCCL communicator or enabled mailboxes");
   JH_NCCL(rccl().AllReduce(p, p, (size_t)n, ncclFloat64, op == 1 ? ncclMax : ncclSum, ctx->comm->comm, ctx->stream));
 }
 
@@ -147,6 +174,22 @@ static void halo_exchange_on(jh_tpfa d, double *v, int bs, hipStream_t s, bool p
     }
     return;
   }
+  if (ctx->comm->halo_cb) {
+    Comm &c = *ctx->comm;
+    c.cb_send.resize((size_t)H.n_send * bs);
+    c.cb_recv.resize((size_t)H.n_recv * bs);
+    if (H.n_send) JH_HIP(hipMemcpyAsync(c.cb_send.data(), H.d_send_buf.p, c.cb_send.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    JH_HIP(hipStreamSynchronize(s));
+    if (c.halo_cb(c.halo_cb_user, c.cb_send.data(), (int64_t)c.cb_send.size(), c.cb_recv.data(), (int64_t)c.cb_recv.size(), bs) != 0)
+      JH_THROW("halo callback reported an error");
+    if (H.n_recv) {
+      JH_HIP(hipMemcpyAsync(H.d_recv_buf.p, c.cb_recv.data(), c.cb_recv.size() * sizeof(double), hipMemcpyHostToDevice, s));
+      halo_unpack_launch(s, v, H.d_recv_buf.p, H.d_recv_idx.p, H.n_recv, bs);
+      JH_HIP(hipStreamSynchronize(s));  // cb_recv is reused by the next exchange
+    }
+    return;
+  }
+  if (!ctx->comm->comm) JH_THROW("halo exchange needs an RCCL communicator, the in-process backend or a halo callback");
   Rccl &R = rccl();
   JH_NCCL(R.GroupStart());
   for (size_t i = 0; i < H.nbr.size(); ++i) {
@@ -242,12 +285,117 @@ extern "C" int32_t jh_comm_init_local(jh_context ctx, void *group, int32_t rank)
   });
 }
 
+// ---- mailbox all-reduce: the solver's 1-2 scalar reductions over peer-mapped device memory ------------------------------
+extern "C" int32_t jh_comm_init_ipc_only(jh_context ctx, int32_t nranks, int32_t rank) {
+  return guard([&] {
+    if (!ctx) JH_THROW("null context");
+    if (ctx->comm) JH_THROW("communicator already initialised");
+    if (nranks < 1 || rank < 0 || rank >= nranks) JH_THROW("bad rank / size");
+    auto c = std::make_unique<Comm>();
+    c->nranks = nranks;
+    c->rank = rank;
+    ctx->comm = c.release();
+  });
+}
+
+extern "C" int32_t jh_comm_set_halo_callback(jh_context ctx, jh_halo_callback fn, void *user) {
+  return guard([&] {
+    if (!ctx || !ctx->comm) JH_THROW("no communicator");
+    if (ctx->comm->local) JH_THROW("the in-process backend exchanges by itself");
+    ctx->comm->halo_cb = fn;
+    ctx->comm->halo_cb_user = user;
+  });
+}
+
+extern "C" int32_t jh_comm_ipc_export(jh_context ctx, char *handle64) {
+  return guard([&] {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (!ctx || !ctx->comm || !handle64) JH_THROW("jh_comm_ipc_export needs an initialised communicator");
+    Comm &c = *ctx->comm;
+    if (c.local) JH_THROW("the in-process backend has no mailboxes");
+    if (c.nranks > MAIL_MAX_RANKS) JH_THROW("mailbox all-reduce supports at most 16 ranks");
+    JH_HIP(hipSetDevice(ctx->device));
+    if (!c.mail_self) {
+      // uncached (fine-grained) device memory: peer stores over xGMI become visible without cache maintenance
+      JH_HIP(hipExtMallocWithFlags((void **)&c.mail_self, mailbox_bytes(), hipDeviceMallocUncached));
+      JH_HIP(hipMemset(c.mail_self, 0, mailbox_bytes()));
+      JH_HIP(hipHostMalloc((void **)&c.mail_err, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
+      *c.mail_err = 0;
+    }
+    hipIpcMemHandle_t h;
+    JH_HIP(hipIpcGetMemHandle(&h, c.mail_self));
+    std::memcpy(handle64, &h, 64);
+  });
+}
+
+// handles: nranks x 64 bytes in rank order (every rank's jh_comm_ipc_export, gathered by the host).  Maps the peers and runs a
+// self-test: 64 all-reduces (sum and max) whose answers every rank can compute.  *ok = 1 if all of them were right.  The
+// mailboxes are only used after jh_comm_ipc_enable(ctx, 1) -- call it with the AND of every rank's *ok.
+extern "C" int32_t jh_comm_ipc_attach(jh_context ctx, const char *handles, int32_t *ok) {
+  return guard([&] {
+    if (!ctx || !ctx->comm || !handles || !ok) JH_THROW("null argument");
+    Comm &c = *ctx->comm;
+    if (!c.mail_self) JH_THROW("jh_comm_ipc_export first");
+    JH_HIP(hipSetDevice(ctx->device));
+    *ok = 0;
+    c.mail_peer.assign(c.nranks, nullptr);
+    for (int r = 0; r < c.nranks; ++r) {
+      if (r == c.rank) { c.mail_peer[r] = c.mail_self; continue; }
+      hipIpcMemHandle_t h;
+      std::memcpy(&h, handles + (size_t)r * 64, 64);
+      void *ptr = nullptr;
+      if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+        (void)hipGetLastError();
+        return;  // *ok stays 0: the caller falls back to RCCL
+      }
+      c.mail_peer[r] = (Mailbox *)ptr;
+    }
+    c.d_mail_peer.upload(c.mail_peer, ctx->stream);
+    c.mail_attached = true;
+    // self-test on the solver's scalar area (slots 24..31 are free)
+    double *dev = ctx->scalars.p + 24;
+    bool good = true;
+    for (int t = 0; t < 64 && good; ++t) {
+      const int n = 1 + t % MAIL_MAX_VALUES, op = (t / 8) % 2;
+      double mine[MAIL_MAX_VALUES], want[MAIL_MAX_VALUES], got[MAIL_MAX_VALUES];
+      for (int i = 0; i < n; ++i) {
+        auto f = [&](int r) { return (double)((r + 1) * (i + 3) + t) * (((r + t + i) & 1) ? 0.5 : -0.25); };
+        mine[i] = f(c.rank);
+        double acc = f(0);
+        for (int r = 1; r < c.nranks; ++r) acc = op ? std::max(acc, f(r)) : acc + f(r);
+        want[i] = acc;
+      }
+      JH_HIP(hipMemcpyAsync(dev, mine, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+      mailbox_allreduce(ctx, dev, n, op, 500000000ull);  // 5 s
+      JH_HIP(hipMemcpyAsync(got, dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+      JH_HIP(hipStreamSynchronize(ctx->stream));
+      if (*c.mail_err) good = false;
+      for (int i = 0; i < n; ++i) good = good && got[i] == want[i];
+    }
+    if (!good) *c.mail_err = 0;  // the fallback path must stay usable
+    *ok = good ? 1 : 0;
+  });
+}
+
+extern "C" int32_t jh_comm_ipc_enable(jh_context ctx, int32_t enable) {
+  return guard([&] {
+    if (!ctx || !ctx->comm) JH_THROW("no communicator");
+    if (enable && !ctx->comm->mail_attached) JH_THROW("jh_comm_ipc_attach first");
+    ctx->comm->mail_enabled = enable != 0;
+  });
+}
+
 extern "C" int32_t jh_comm_finalize(jh_context ctx) {
   return guard([&] {
     if (!ctx || !ctx->comm) return;
     JH_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->comm_stream) JH_HIP(hipStreamSynchronize(ctx->comm_stream));
     if (ctx->comm->comm) rccl().CommDestroy(ctx->comm->comm);
+    Comm &c = *ctx->comm;
+    for (int r = 0; r < (int)c.mail_peer.size(); ++r)
+      if (r != c.rank && c.mail_peer[r]) (void)hipIpcCloseMemHandle(c.mail_peer[r]);
+    if (c.mail_self) (void)hipFree(c.mail_self);
+    if (c.mail_err) (void)hipHostFree((void *)c.mail_err);
     delete ctx->comm;
     ctx->comm = nullptr;
   });

@@ -1,0 +1,47 @@
+"""Worker of tests/test_gpu_ipc_allreduce.py: one of several PROCESSES that share GPU 0 (launched by torch.distributed.run).
+Sets up the mailbox all-reduce across the processes (handles all-gathered over gloo) and checks a few hundred reductions
+against numpy on the gathered contributions."""
+import os
+import sys
+
+os.environ.pop("NCCL_DEBUG", None)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+import jutul_amd as ja
+
+ctx = ja.HIPContext(0)  # every process on the same device
+ctx.comm_init_ipc_only(world, rank)
+handles = [None] * world
+dist.all_gather_object(handles, ctx.comm_ipc_export())
+ok = ctx.comm_ipc_attach(handles)
+flag = torch.tensor([1 if ok else 0])
+dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+assert int(flag[0]) == 1, "mailbox self-test failed on some rank"
+ctx.comm_ipc_enable(True)
+rng = np.random.default_rng(100 + rank)
+for t in range(300):
+    n = 1 + t % 8
+    op = "max" if t % 3 == 0 else "sum"
+    mine = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4)
+    allv = [None] * world
+    dist.all_gather_object(allv, mine)
+    got = ctx.allreduce(mine, op)
+    acc = allv[0].copy()
+    for r in range(1, world):   # rank order, like the kernel
+        acc = np.maximum(acc, allv[r]) if op == "max" else acc + allv[r]
+    assert np.array_equal(got, acc), (t, op, got, acc)
+# every rank must hold identical bits
+res = [None] * world
+dist.all_gather_object(res, got.tobytes())
+assert all(r == res[0] for r in res)
+dist.barrier()
+ctx.comm_finalize()
+dist.barrier()
+if rank == 0:
+    print("IPC_ALLREDUCE_OK", world, flush=True)
