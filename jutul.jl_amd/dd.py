@@ -232,6 +232,31 @@ class HostExchange:
         return v
 
 
+def packed_exchange(sub):
+    """Halo callback for HIPContext.comm_set_halo_callback over torch.distributed (any backend): exchanges the PACKED send /
+    receive buffers of the device library, whose segments follow the neighbour order of the halo plan."""
+    nsend = [len(c) for c in sub["send"]]
+    nrecv = [len(c) for c in sub["recv"]]
+    nbrs = [int(r) for r in sub["neighbors"]]
+
+    def exchange(send, recv, bs):
+        import torch
+        import torch.distributed as dist
+        reqs, bufs, so, ro = [], [], 0, 0
+        for nb, ns, nr in zip(nbrs, nsend, nrecv):
+            out = torch.from_numpy(send[so * bs:(so + ns) * bs].copy())
+            inp = torch.empty(nr * bs, dtype=torch.float64)
+            reqs += [dist.isend(out, nb), dist.irecv(inp, nb)]
+            bufs.append((ro, nr, inp, out))
+            so += ns
+            ro += nr
+        for q in reqs:
+            q.wait()
+        for ro, nr, inp, _ in bufs:
+            recv[ro * bs:(ro + nr) * bs] = inp.numpy()
+    return exchange
+
+
 def setup_rank_problem(ctx, N, part, rank, T, vol, X0, kind="poisson", block_n=1, sources=None, reorder="blocks",
                        block_rows=512, law_params=None, gdz=None, ghost_order="global"):
     """Builds this rank's discretisation + law the way PArraySimulator does per rank (interface.jl:38-63):

@@ -50,26 +50,7 @@ assert int(ok[0]) == 1
 ctx.comm_ipc_enable(True)
 disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, rank, T, g["volumes"], X0, kind=kind, block_n=nblk, sources=src,
                                        block_rows=128, law_params=par, ghost_order="owner")
-nsend = [len(c) for c in sub["send"]]
-nrecv = [len(c) for c in sub["recv"]]
-
-
-def exchange(send, recv, bs):  # packed buffers: the neighbours' segments in halo-plan order
-    reqs, bufs, so, ro = [], [], 0, 0
-    for nb, ns, nr in zip(sub["neighbors"], nsend, nrecv):
-        out = torch.from_numpy(send[so * bs:(so + ns) * bs].copy())
-        inp = torch.empty(nr * bs, dtype=torch.float64)
-        reqs += [dist.isend(out, int(nb)), dist.irecv(inp, int(nb))]
-        bufs.append((ro, nr, inp, out))
-        so += ns
-        ro += nr
-    for r in reqs:
-        r.wait()
-    for ro, nr, inp, _ in bufs:
-        recv[ro * bs:(ro + nr) * bs] = inp.numpy()
-
-
-ctx.comm_set_halo_callback(exchange)
+ctx.comm_set_halo_callback(dd.packed_exchange(sub))
 okk, its, rep = make_sim(law).solve_ministep(dt)
 assert okk
 Xl = law.get_state().reshape(-1, nblk)

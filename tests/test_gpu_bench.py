@@ -47,3 +47,16 @@ def test_bench_under_torchrun_distributed_path():
             env={"JH_BENCH_FORCE_DIST": "1"})
     check(d, 2, 1)
     assert d["cpu_baseline"] is None
+
+
+def test_bench_two_processes_sharing_the_gpu():
+    """bench.py's N > 1 path (RCB partition, rank-local subdomains, mailbox set-up, barrier + max-over-ranks clock, one JSON line
+    from rank 0) with two processes on the box's single GPU; RCCL cannot place two ranks on one device, so the ghost exchange
+    uses the host-callback backend (JH_BENCH_HALO=host)."""
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", "29542", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--cells", "200000", "--no-cpu"],
+            env={"JH_BENCH_HALO": "host", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    check(d, 2, 1)
+    assert d["n_gpus"] == 2
+    assert d["config"]["parallelism"] == "dd2" and d["config"]["scalar_allreduce"] == "mailbox"
+    assert 5 <= d["config"]["linear_iterations_per_step"] <= 100
