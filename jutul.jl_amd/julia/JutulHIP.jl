@@ -185,4 +185,30 @@ function linear_solve!(sys::HIPLinearizedSystem, krylov::GenericKrylov, context:
     return linear_solve_return(solved, n, (residuals = hist[1:n + 1], solved = solved); prepare = t_prec)
 end
 
+# ---- distributed set-up (seam: the PArraySimulator hooks, src/ext/partitionedarrays_ext.jl:3-33) ---------------------------
+# One process per GPU.  `bcast(bytes, root)` and `allgather(bytes)` are the host's collectives (MPI.Bcast! / MPI.Allgather from
+# the MPI extension); all data-path communication then runs inside the library.
+function setup_distributed!(ctx::HIPContext, nranks::Integer, rank::Integer, bcast, allgather)
+    id = zeros(UInt8, 128)
+    rank == 0 && @jh :jh_comm_unique_id (Ptr{UInt8},) id
+    id = bcast(id, 0)
+    @jh :jh_comm_init (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}) ctx.handle Int32(nranks) Int32(rank) id
+    # scalar all-reduces of the Krylov loop through peer-mapped mailboxes when every rank of the node passes the self-test
+    h = zeros(UInt8, 64)
+    @jh :jh_comm_ipc_export (Ptr{Cvoid}, Ptr{UInt8}) ctx.handle h
+    all = allgather(h)                       # nranks*64 bytes in rank order
+    ok = Ref{Int32}(0)
+    @jh :jh_comm_ipc_attach (Ptr{Cvoid}, Ptr{UInt8}, Ref{Int32}) ctx.handle all ok
+    everyone = minimum(reinterpret(Int32, allgather(collect(reinterpret(UInt8, [ok[]]))))) == 1
+    @jh :jh_comm_ipc_enable (Ptr{Cvoid}, Int32) ctx.handle Int32(everyone)
+    return ctx
+end
+
+# Halo plan of the rank-local model built by distribute_case (ext/JutulPartitionedArraysExt/utils.jl:91-148): cells are
+# [owned..., ghosts...]; per neighbour rank the local owned cells to send and the local ghost cells to receive (1-based).
+function set_halo!(disc::Ptr{Cvoid}, n_owned::Integer, neighbors::Vector{Int32}, send::Vector{Vector{Int64}}, recv::Vector{Vector{Int64}})
+    sp = cumsum([0; length.(send)]); rp = cumsum([0; length.(recv)])
+    @jh :jh_halo_create (Ptr{Cvoid}, Int64, Int32, Ptr{Int32}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}) disc Int64(n_owned) Int32(length(neighbors)) neighbors Int64.(sp) reduce(vcat, send; init = Int64[]) Int64.(rp) reduce(vcat, recv; init = Int64[])
+end
+
 end # module
