@@ -95,7 +95,7 @@ def main():
     U0 = 1.0 + 0.1 * rng.random(nc_g)
     vol = mesh["volumes"]
     ctx = ja.HIPContext(local_rank)
-    mailbox = False
+    mailbox = push = False
     force_dist = os.environ.get("JH_BENCH_FORCE_DIST") == "1"  # exercise the distributed code path on one rank
     if world == 1 and not force_dist:
         disc = ja.TwoPointPotentialFlowHardCoded(ctx, mesh["N"], nc_g, reorder="blocks", block_rows=args.block_rows)
@@ -142,6 +142,10 @@ def main():
         disc.set_halo(n_owned, sub["neighbors"], sub["send"], sub["recv"])
         if host_halo:
             ctx.comm_set_halo_callback(dd.packed_exchange(sub))
+        if world > 1 and mailbox:
+            # ghost exchanges inside the Krylov loop by direct xGMI stores into the neighbours' landing buffers (self-tested,
+            # all ranks or none); state / right-hand-side / solution exchanges stay on RCCL
+            push = dd.setup_push_halo(disc, sub, rank, world, enable=os.environ.get("JH_BENCH_NO_PUSH") != "1")
         T_loc, vol_loc, U_loc = T[sub["faces"] - 1], vol[cells], U0[cells]
         g2l = {int(c): i + 1 for i, c in enumerate(cells[:n_owned]) if c in (0, nc_g - 1)}
         src_cells = [g2l[c] for c in (0, nc_g - 1) if c in g2l]
@@ -236,6 +240,7 @@ def main():
                        "cells": nc_g, "faces": nf_g, "dt": args.dt, "block_rows": args.block_rows or (256 if disc.nc < 2_000_000 else 512),
                        "parallelism": f"dd{world}" if world > 1 else "single", "precond_side": ks.config.precond_side,
                        "scalar_allreduce": ("mailbox" if mailbox else "rccl") if world > 1 else None,
+                       "krylov_halo": ("push" if push else "rccl") if world > 1 else None,
                        "halo": ("host-callback (test mode)" if os.environ.get("JH_BENCH_HALO") == "host" else "rccl") if world > 1 else None,
                        "ilu_blocks": info["nblocks"], "ilu_max_levels": info["max_levels"],
                        "linear_iterations_per_step": round(float(np.mean(lin_its)), 2),

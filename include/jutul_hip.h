@@ -271,6 +271,19 @@ int32_t jh_comm_init_local(jh_context ctx, void *group, int32_t rank);
  * cells to send and the local ghost cells to receive, in matching order on both sides. */
 int32_t jh_halo_create(jh_tpfa d, int64_t n_owned, int32_t n_nbr, const int32_t *nbr_rank, const int64_t *send_ptr,
                        const int64_t *send_cells, const int64_t *recv_ptr, const int64_t *recv_cells);
+/* Push halo for the exchanges INSIDE the Krylov loop (consistent! before every mul!, ext/.../linalg.jl:46), ranks of one
+ * node, needs attached mailboxes: the kernel that produces the vector stores each boundary row straight into the landing
+ * buffers (peer-mapped uncached memory) of the ranks holding it as a ghost; a finish kernel signals, waits for the
+ * neighbours and copies the landed values into the ghost rows.  No collective-library call is left in the loop.  Set-up:
+ * jh_halo_ipc_export (64-byte handle of this rank's landing buffer) -> host gathers, per neighbour i, its handle, the
+ * first cell of this rank's segment in i's receive order (nbr_offset) and i's total receive count (nbr_stride) ->
+ * jh_halo_ipc_attach -> jh_halo_ipc_selftest (one time-limited exchange of a vector whose ghost values the host knows) ->
+ * jh_halo_ipc_enable with the AND over all ranks.  All other exchanges (state, right-hand side, solution) and the fallback
+ * stay on RCCL / the callback backend. */
+int32_t jh_halo_ipc_export(jh_tpfa d, char *handle64);
+int32_t jh_halo_ipc_attach(jh_tpfa d, const char *nbr_handles, const int64_t *nbr_offset, const int64_t *nbr_stride, int32_t *ok);
+int32_t jh_halo_ipc_selftest(jh_tpfa d, jh_vec v, const double *expected_ghosts, int32_t *ok);
+int32_t jh_halo_ipc_enable(jh_tpfa d, int32_t enable);
 /* consistent!(v) (ext/.../linalg.jl:46, krylov.jl:54,75; interface.jl:200): owner values -> ghosts */
 int32_t jh_halo_exchange(jh_tpfa d, jh_vec v);
 int32_t jh_halo_exchange_state(jh_law L);

@@ -234,6 +234,28 @@ class TwoPointPotentialFlowHardCoded(_Handle):
         check(_L().jh_tpfa_get_split(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    # ---- push halo (jh_halo_ipc_*): see dd.setup_push_halo for the collective set-up --------------------------------------
+    def halo_ipc_export(self):
+        buf = C.create_string_buffer(64)
+        check(_L().jh_halo_ipc_export(self.h, buf))
+        return buf.raw
+
+    def halo_ipc_attach(self, nbr_handles, nbr_offset, nbr_stride):
+        ok = C.c_int32(0)
+        off = np.ascontiguousarray(nbr_offset, dtype=np.int64)
+        st = np.ascontiguousarray(nbr_stride, dtype=np.int64)
+        check(_L().jh_halo_ipc_attach(self.h, b"".join(nbr_handles), pi(off), pi(st), C.byref(ok)))
+        return bool(ok.value)
+
+    def halo_ipc_selftest(self, vec, expected_ghosts):
+        ok = C.c_int32(0)
+        e = f64(expected_ghosts).reshape(-1)
+        check(_L().jh_halo_ipc_selftest(self.h, vec.h, pf(e), C.byref(ok)))
+        return bool(ok.value)
+
+    def halo_ipc_enable(self, enable=True):
+        check(_L().jh_halo_ipc_enable(self.h, 1 if enable else 0))
+
     def set_halo(self, n_owned, nbr_ranks, send_lists, recv_lists):
         """Halo plan: per neighbour rank the local owned cells to send / ghost cells to receive (1-based)."""
         nbr = np.ascontiguousarray(nbr_ranks, dtype=np.int32)

@@ -105,6 +105,10 @@ SIGNATURES = {
     "jh_comm_ipc_export": [H, C.c_char_p],
     "jh_comm_ipc_attach": [H, C.c_char_p, C.POINTER(C.c_int32)],
     "jh_comm_ipc_enable": [H, C.c_int32],
+    "jh_halo_ipc_export": [H, C.c_char_p],
+    "jh_halo_ipc_attach": [H, C.c_char_p, I64P, I64P, C.POINTER(C.c_int32)],
+    "jh_halo_ipc_selftest": [H, H, F64P, C.POINTER(C.c_int32)],
+    "jh_halo_ipc_enable": [H, C.c_int32],
     "jh_comm_local_group_create": [C.c_int32, C.POINTER(H)],
     "jh_comm_local_group_destroy": [H],
     "jh_comm_init_local": [H, H, C.c_int32],

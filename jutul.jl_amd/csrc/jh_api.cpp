@@ -5,7 +5,7 @@
 #include "jh_internal.hpp"
 
 namespace jh {
-void halo_exchange(jh_tpfa d, double *v, int bs, bool packed = false);
+void halo_exchange(jh_tpfa d, double *v, int bs, bool packed = false, bool push = false);
 }
 using namespace jh;
 

@@ -142,15 +142,38 @@ void comm_allreduce_dev(jh_context ctx, double *p, int n, int op) {
   JH_NCCL(rccl().AllReduce(p, p, (size_t)n, ncclFloat64, op == 1 ? ncclMax : ncclSum, ctx->comm->comm, ctx->stream));
 }
 
+void halo_push_pack_launch(hipStream_t s, double *const *dst, const double *v, const int32_t *idx, int64_t n, int bs);
+void halo_push_finish_launch(hipStream_t s, Mailbox *self, Mailbox *const *peers, const int32_t *nbr, int n_nbr, int rank, uint64_t epoch,
+                             const double *landing, double *v, const int32_t *recv_idx, int64_t n_recv, int bs, unsigned *err,
+                             uint64_t timeout_ticks);
 void halo_pack_launch(hipStream_t s, double *buf, const double *v, const int32_t *idx, int64_t n, int bs);
 void halo_unpack_launch(hipStream_t s, double *v, const double *buf, const int32_t *idx, int64_t n, int bs);
 
 // consistent!(v): pack owned values -> grouped ncclSend/ncclRecv per neighbour -> unpack into ghost rows, all on stream s
-// packed: the producer of v has already written the send buffer (fused ILU(0) apply)
-static void halo_exchange_on(jh_tpfa d, double *v, int bs, hipStream_t s, bool packed = false) {
+// Push exchange (see jh_halo.hip).  packed: the producer of v has already stored the boundary rows into the neighbours' landing
+// buffers of parity (push_epoch + 1) & 1 (halo_push_targets).
+static void halo_push(jh_tpfa d, double *v, int bs, hipStream_t s, bool packed, uint64_t timeout_ticks = 0) {
+  auto &H = d->halo;
+  Comm &c = *d->ctx->comm;
+  const uint64_t e = ++H.push_epoch;
+  const int par = (int)(e & 1);
+  if (H.n_send && !packed) halo_push_pack_launch(s, H.d_push_dst[par].p, v, H.d_send_idx.p, H.n_send, bs);
+  halo_push_finish_launch(s, c.mail_self, c.d_mail_peer.p, H.d_nbr.p, (int)H.nbr.size(), c.rank, e, H.landing + par * H.landing_stride, v,
+                          H.d_recv_idx.p, H.n_recv, bs, const_cast<unsigned *>(c.mail_err), timeout_ticks);
+}
+// where the producer of the NEXT pushed vector must store send slot k (N doubles each); nullptr when pushing is off
+double *const *halo_push_targets(jh_tpfa d) {
+  auto &H = d->halo;
+  return H.push_enabled ? H.d_push_dst[(H.push_epoch + 1) & 1].p : nullptr;
+}
+
+// packed: the producer of v has already written the send buffer (fused ILU(0) apply); push: inside the Krylov loop, use the
+// push exchange when it is enabled
+static void halo_exchange_on(jh_tpfa d, double *v, int bs, hipStream_t s, bool packed = false, bool push = false) {
   auto &H = d->halo;
   jh_context ctx = d->ctx;
   if (!ctx->comm) JH_THROW("halo exchange without a communicator (jh_comm_init)");
+  if (push && H.push_enabled) { halo_push(d, v, bs, s, packed); return; }
   if (H.n_send && !packed) halo_pack_launch(s, H.d_send_buf.p, v, H.d_send_idx.p, H.n_send, bs);
   if (ctx->comm->local) {
     LocalGroup &G = *ctx->comm->local;
@@ -203,9 +226,9 @@ static void halo_exchange_on(jh_tpfa d, double *v, int bs, hipStream_t s, bool p
   if (H.n_recv && !H.direct_recv) halo_unpack_launch(s, v, H.d_recv_buf.p, H.d_recv_idx.p, H.n_recv, bs);
 }
 
-void halo_exchange(jh_tpfa d, double *v, int bs, bool packed) {
+void halo_exchange(jh_tpfa d, double *v, int bs, bool packed, bool push) {
   if (!d->halo.active) return;
-  halo_exchange_on(d, v, bs, d->ctx->stream, packed);
+  halo_exchange_on(d, v, bs, d->ctx->stream, packed, push);
 }
 
 // Overlapped form.  begin: everything enqueued on the compute stream so far (in particular the rows that are sent) is
@@ -382,6 +405,94 @@ extern "C" int32_t jh_comm_ipc_enable(jh_context ctx, int32_t enable) {
     if (!ctx || !ctx->comm) JH_THROW("no communicator");
     if (enable && !ctx->comm->mail_attached) JH_THROW("jh_comm_ipc_attach first");
     ctx->comm->mail_enabled = enable != 0;
+  });
+}
+
+// ---- push halo set-up ---------------------------------------------------------------------------------------------------
+extern "C" int32_t jh_halo_ipc_export(jh_tpfa d, char *handle64) {
+  return guard([&] {
+    if (!d || !handle64) JH_THROW("null argument");
+    auto &H = d->halo;
+    if (!H.active) JH_THROW("jh_halo_create first");
+    if (!d->ctx->comm || !d->ctx->comm->mail_attached) JH_THROW("the push halo needs attached mailboxes (jh_comm_ipc_attach)");
+    JH_HIP(hipSetDevice(d->ctx->device));
+    if (!H.landing) {
+      H.landing_stride = std::max<int64_t>(1, H.n_recv * d->N);
+      JH_HIP(hipExtMallocWithFlags((void **)&H.landing, sizeof(double) * 2 * H.landing_stride, hipDeviceMallocUncached));
+      JH_HIP(hipMemset(H.landing, 0, sizeof(double) * 2 * H.landing_stride));
+    }
+    hipIpcMemHandle_t h;
+    JH_HIP(hipIpcGetMemHandle(&h, H.landing));
+    std::memcpy(handle64, &h, 64);
+  });
+}
+
+// nbr_handles: n_nbr x 64 bytes, the landing-buffer handles of the neighbours in halo-plan order.  nbr_offset[i]: first cell
+// of MY segment in neighbour i's receive order; nbr_stride[i]: neighbour i's total number of received cells (both gathered
+// by the host from the neighbours' halo plans).
+extern "C" int32_t jh_halo_ipc_attach(jh_tpfa d, const char *nbr_handles, const int64_t *nbr_offset, const int64_t *nbr_stride, int32_t *ok) {
+  return guard([&] {
+    if (!d || !ok) JH_THROW("null argument");
+    auto &H = d->halo;
+    if (!H.landing) JH_THROW("jh_halo_ipc_export first");
+    Comm &c = *d->ctx->comm;
+    JH_HIP(hipSetDevice(d->ctx->device));
+    *ok = 0;
+    const int nn = (int)H.nbr.size();
+    H.peer_landing.assign(nn, nullptr);
+    for (int i = 0; i < nn; ++i) {
+      if (H.nbr[i] == c.rank) { H.peer_landing[i] = H.landing; continue; }  // self exchange (one-rank proxies)
+      hipIpcMemHandle_t h;
+      std::memcpy(&h, nbr_handles + (size_t)i * 64, 64);
+      void *ptr = nullptr;
+      if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return; }
+      H.peer_landing[i] = (double *)ptr;
+    }
+    for (int par = 0; par < 2; ++par) {
+      std::vector<double *> dst((size_t)H.n_send);
+      for (int i = 0; i < nn; ++i) {
+        const int64_t stride = std::max<int64_t>(1, nbr_stride[i] * d->N);
+        for (int64_t k = H.send_ptr[i]; k < H.send_ptr[i + 1]; ++k)
+          dst[k] = H.peer_landing[i] + par * stride + (nbr_offset[i] + (k - H.send_ptr[i])) * d->N;
+      }
+      H.d_push_dst[par].upload(dst, d->ctx->stream);
+    }
+    H.d_nbr.upload(H.nbr, d->ctx->stream);
+    JH_HIP(hipStreamSynchronize(d->ctx->stream));
+    H.push_attached = true;
+    *ok = 1;
+  });
+}
+
+// One time-limited push exchange of v; *ok = 1 if every ghost row of v then equals expected_ghosts (n_recv x N doubles in
+// receive-list order).  Call on all ranks; enable the push halo only if all of them report 1.
+extern "C" int32_t jh_halo_ipc_selftest(jh_tpfa d, jh_vec v, const double *expected_ghosts, int32_t *ok) {
+  return guard([&] {
+    if (!d || !v || !ok) JH_THROW("null argument");
+    auto &H = d->halo;
+    *ok = 0;
+    if (!H.push_attached) return;
+    Comm &c = *d->ctx->comm;
+    hipStream_t s = d->ctx->stream;
+    halo_push(d, v->d.p, v->bs, s, false, 500000000ull);
+    std::vector<double> got((size_t)H.n_recv * v->bs);
+    if (H.n_recv) {
+      halo_pack_launch(s, H.d_recv_buf.p, v->d.p, H.d_recv_idx.p, H.n_recv, v->bs);  // gather the ghost rows
+      JH_HIP(hipMemcpyAsync(got.data(), H.d_recv_buf.p, got.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    JH_HIP(hipStreamSynchronize(s));
+    bool good = *c.mail_err == 0;
+    for (size_t i = 0; i < got.size(); ++i) good = good && got[i] == expected_ghosts[i];
+    if (!good) *c.mail_err = 0;
+    *ok = good ? 1 : 0;
+  });
+}
+
+extern "C" int32_t jh_halo_ipc_enable(jh_tpfa d, int32_t enable) {
+  return guard([&] {
+    if (!d) JH_THROW("null handle");
+    if (enable && !d->halo.push_attached) JH_THROW("jh_halo_ipc_attach first");
+    d->halo.push_enabled = enable != 0;
   });
 }
 

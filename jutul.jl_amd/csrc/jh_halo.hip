@@ -26,6 +26,7 @@ constexpr int MAIL_R = 16, MAIL_V = 8;
 struct Mailbox {
   double val[2][MAIL_R][MAIL_V];
   unsigned long long flag[2][MAIL_R];
+  unsigned long long hflag[2][MAIL_R];  // push halo: epoch of the last exchange whose data rank r has delivered here
 };
 size_t mailbox_bytes() { return sizeof(Mailbox); }
 
@@ -62,6 +63,55 @@ void mailbox_allreduce_launch(hipStream_t s, Mailbox *self, Mailbox *const *peer
                               int n, int op, unsigned *err, uint64_t timeout_ticks) {
   hipLaunchKernelGGL(mailbox_allreduce_kernel, dim3(1), dim3(64), 0, s, self, peers, rank, nranks, (unsigned long long)epoch, p, n, op,
                      err, (unsigned long long)timeout_ticks);
+}
+
+// ---- push halo ------------------------------------------------------------------------------------------------------------
+// Inside the Krylov loop the ghost exchange needs no collective library call either: the producer of the vector (the fused
+// ILU(0) apply, or this pack kernel) stores every boundary row straight into the landing buffers of the ranks that hold it
+// as a ghost (peer-mapped uncached memory, xGMI stores).  The finish kernel, next on the stream (so those stores are
+// released), raises this rank's flag in every neighbour's mailbox, waits for the neighbours' flags in its own, and copies
+// the landed values into the ghost rows.  Landing buffers alternate with the parity of the exchange counter.
+__global__ void halo_push_pack_kernel(double *const *dst, const double *v, const int32_t *idx, int64_t n, int bs) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+    double *d = dst[k];
+    for (int e = 0; e < bs; ++e) __hip_atomic_store(d + e, v[(size_t)idx[k] * bs + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__global__ __launch_bounds__(256) void halo_push_finish_kernel(Mailbox *self, Mailbox *const *peers, const int32_t *nbr, int n_nbr,
+                                                               int rank, unsigned long long epoch, const double *landing, double *v,
+                                                               const int32_t *recv_idx, int64_t n_recv, int bs, unsigned *err,
+                                                               unsigned long long timeout_ticks) {
+  const int par = (int)(epoch & 1ull);
+  if (threadIdx.x < n_nbr) {
+    const int q = nbr[threadIdx.x];
+    if (blockIdx.x == 0)  // my rows for q are in place (previous kernel on this stream): tell q
+      __hip_atomic_store(&peers[q]->hflag[par][rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(&self->hflag[par][q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      if (timeout_ticks && wall_clock64() - t0 > timeout_ticks) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_recv * bs; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i / bs;
+    const int e = (int)(i - k * bs);
+    v[(size_t)recv_idx[k] * bs + e] = __hip_atomic_load(landing + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+void halo_push_pack_launch(hipStream_t s, double *const *dst, const double *v, const int32_t *idx, int64_t n, int bs) {
+  int g = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 1024));
+  hipLaunchKernelGGL(halo_push_pack_kernel, dim3(g), dim3(256), 0, s, dst, v, idx, n, bs);
+}
+void halo_push_finish_launch(hipStream_t s, Mailbox *self, Mailbox *const *peers, const int32_t *nbr, int n_nbr, int rank, uint64_t epoch,
+                             const double *landing, double *v, const int32_t *recv_idx, int64_t n_recv, int bs, unsigned *err,
+                             uint64_t timeout_ticks) {
+  int g = (int)std::max<int64_t>(1, std::min<int64_t>((n_recv * bs + 2047) / 2048, 16));
+  hipLaunchKernelGGL(halo_push_finish_kernel, dim3(g), dim3(256), 0, s, self, peers, nbr, n_nbr, rank, (unsigned long long)epoch,
+                     landing, v, recv_idx, n_recv, bs, err, (unsigned long long)timeout_ticks);
 }
 
 void halo_pack_launch(hipStream_t s, double *buf, const double *v, const int32_t *idx, int64_t n, int bs) {

@@ -23,6 +23,9 @@
 
 #include "jh_internal.hpp"
 
+namespace jh {
+double *const *halo_push_targets(jh_tpfa d);
+}
 using namespace jh;
 
 struct jh_ilu_s {
@@ -132,6 +135,7 @@ struct IluDev {
   // fused halo pack (may be null): block b copies local rows send_local[j] to send_buf[send_slot[j]], j in [send_ptr[b], send_ptr[b+1])
   const int32_t *send_ptr, *send_local, *send_slot;
   double *send_buf;
+  double *const *send_dst;  // push halo: per send slot the address in the neighbour's landing buffer (overrides send_buf)
 };
 
 // ---- numeric factorisation of one row (ilu0_factor!, ilu0.jl:108-144) -----------------------------------------------
@@ -628,9 +632,15 @@ __global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const d
   if (F.send_ptr) {  // rows that neighbouring ranks hold as ghosts go straight into the halo send buffer (no pack kernel)
     for (int j = F.send_ptr[b] + (int)threadIdx.x; j < F.send_ptr[b + 1]; j += 64) {
       const int t = F.send_local[j];
-      const size_t o = (size_t)F.send_slot[j] * BS;
+      if (F.send_dst) {  // xGMI store into the receiving rank's landing buffer
+        double *dp = F.send_dst[F.send_slot[j]];
 #pragma unroll
-      for (int e = 0; e < BS; ++e) F.send_buf[o + e] = xs[t * BS + e];
+        for (int e = 0; e < BS; ++e) __hip_atomic_store(dp + e, xs[t * BS + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        const size_t o = (size_t)F.send_slot[j] * BS;
+#pragma unroll
+        for (int e = 0; e < BS; ++e) F.send_buf[o + e] = xs[t * BS + e];
+      }
     }
   }
 }
@@ -709,7 +719,7 @@ IluDev dev_view(jh_ilu M) {
   F.d_map = M->d_d_map.p; F.u_row = M->d_u_row.p; F.upos_of = M->d_upos_of.p;
   F.l_lev = M->d_l_lev.p; F.u_lev = M->d_u_lev.p;
   F.l_val = M->l_val.p; F.u_val = M->u_val.p; F.dinv = M->dinv.p;
-  F.send_ptr = nullptr; F.send_local = nullptr; F.send_slot = nullptr; F.send_buf = nullptr;
+  F.send_ptr = nullptr; F.send_local = nullptr; F.send_slot = nullptr; F.send_buf = nullptr; F.send_dst = nullptr;
   return F;
 }
 
@@ -1096,6 +1106,7 @@ void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x, bool pack) {
     if (!ilu_can_pack_halo(M)) JH_THROW("fused halo pack requested without a matching halo plan");
     F.send_ptr = M->d_send_ptr.p; F.send_local = M->d_send_local.p; F.send_slot = M->d_send_slot.p;
     F.send_buf = M->A->disc->halo.d_send_buf.p;
+    F.send_dst = halo_push_targets(M->A->disc);  // non-null when the push halo is enabled: the exchange that follows is a push
   }
   const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
 #define JH_FUSED(BSV, GMV) hipLaunchKernelGGL((ilu_apply_chunked_kernel<BSV, GMV>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, (const double *)nullptr, x, G)

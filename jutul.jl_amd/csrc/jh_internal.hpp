@@ -158,6 +158,15 @@ struct jh_tpfa_s {
     uint64_t epoch = 0;                // bumped by every jh_halo_create
     bool direct_recv = false;          // each neighbour's ghosts are consecutive device rows: no unpack
     std::vector<int32_t> recv_row0;    // first device row of every neighbour's ghosts (direct_recv)
+    // "push" exchange over peer-mapped memory (jh_halo_ipc_*): senders store their boundary rows straight into the
+    // receiver's landing buffer (uncached, 2 parities x n_recv x N doubles, receive-list order)
+    double *landing = nullptr;                 // this rank's landing buffer
+    int64_t landing_stride = 0;                // doubles per parity
+    std::vector<double *> peer_landing;        // per neighbour: that rank's landing buffer, mapped here
+    jh::DevBuf<double *> d_push_dst[2];        // per send slot and parity: where the cell's N doubles go
+    jh::DevBuf<int32_t> d_nbr;                 // neighbour ranks on the device
+    uint64_t push_epoch = 0;
+    bool push_attached = false, push_enabled = false;
   } halo;
 };
 

@@ -22,7 +22,7 @@ void halo_exchange_begin(jh_tpfa d, double *v, int bs, bool packed = false);
 void halo_exchange_end(jh_tpfa d);
 void ilu_factor(jh_ilu M);
 void comm_allreduce_dev(jh_context ctx, double *p, int n, int op);
-void halo_exchange(jh_tpfa d, double *v, int bs, bool packed = false);
+void halo_exchange(jh_tpfa d, double *v, int bs, bool packed = false, bool push = false);
 }  // namespace jh
 using namespace jh;
 
@@ -230,7 +230,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   };
   const int64_t rows_dot = nd / P.bs;
   auto spmv = [&](double *in, double *out, const SpmvDot *dot, bool packed = false) {
-    if (dist) halo_exchange(disc, in, P.bs, packed);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
+    if (dist) halo_exchange(disc, in, P.bs, packed, true);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
     K->mark(0, st);
     k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done);
     K->mark(0, st);
@@ -274,7 +274,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   // run) the two cross-stream event hops (~8 us each) and the second SpMV launch cost more than the 22 us exchange they
   // hide (247 vs 214 us per iteration); also splitting the ILU apply doubled its latency-bound time (261 us).
   static const bool want_overlap = getenv("JH_HALO_OVERLAP") != nullptr;
-  const bool overlap = dist && fuse && want_overlap && P.interior_tiles >= 0;
+  const bool overlap = dist && fuse && want_overlap && P.interior_tiles >= 0 && !disc->halo.push_enabled;
   // the fused ILU(0) apply also fills the halo send buffer with the rows neighbouring ranks hold as ghosts
   const bool pack = dist && fuse && ilu_can_pack_halo(M);
   auto fused_half = [&](IluGather &G, double *pv, double *out, const SpmvDot &dot) {

@@ -298,7 +298,14 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
 }
 
 extern "C" int32_t jh_tpfa_destroy(jh_tpfa d) {
-  return guard([&] { delete d; });
+  return guard([&] {
+    if (!d) return;
+    auto &H = d->halo;  // push-halo mappings
+    for (double *p : H.peer_landing)
+      if (p && p != H.landing) (void)hipIpcCloseMemHandle(p);
+    if (H.landing) (void)hipFree(H.landing);
+    delete d;
+  });
 }
 
 extern "C" int32_t jh_tpfa_sizes(jh_tpfa d, int64_t *nc, int64_t *nf, int64_t *nhf, int64_t *nnzb, int32_t *block_n) {

@@ -257,6 +257,56 @@ def packed_exchange(sub):
     return exchange
 
 
+def setup_push_halo(disc, sub, rank, world, enable=True):
+    """Collective set-up of the push halo (jh_halo_ipc_*) over torch.distributed (control plane, any backend): landing-buffer
+    handles and halo plans are all-gathered, every rank maps its neighbours' buffers, one time-limited test exchange of the
+    global cell ids is verified, and the push halo is enabled only if every rank passed.  Needs enabled mailboxes
+    (HIPContext.comm_ipc_*).  Returns True if the Krylov-loop exchanges now use it."""
+    import torch
+    import torch.distributed as dist
+    from . import DeviceVector
+    nbrs = [int(q) for q in sub["neighbors"]]
+    import sys
+    import traceback
+    try:
+        handle = disc.halo_ipc_export()
+    except Exception:  # noqa: BLE001
+        traceback.print_exc(file=sys.stderr)  # not fatal: the exchange stays on the collective library
+        handle = None
+    info = [None] * world
+    dist.all_gather_object(info, (handle, nbrs, [len(c) for c in sub["recv"]]))  # every rank takes part
+    ok = False
+    if all(i[0] is not None for i in info):
+        try:
+            hs, off, stride = [], [], []
+            for q in nbrs:
+                hq, nbr_q, nrecv_q = info[q]
+                j = nbr_q.index(rank)
+                hs.append(hq)
+                off.append(int(sum(nrecv_q[:j])))
+                stride.append(int(sum(nrecv_q)))
+            ok = disc.halo_ipc_attach(hs, off, stride)
+            if ok:  # ghosts must receive their owners' global cell ids
+                N = disc.block_n
+                gid = np.asarray(sub["cells"], dtype=np.float64)
+                val = gid[:, None] + 0.25 * np.arange(N)[None, :]
+                val[sub["n_owned"]:] = -1.0
+                v = DeviceVector(disc)
+                v.upload(val.reshape(-1))
+                expect = np.concatenate([gid[np.asarray(c) - 1] for c in sub["recv"]] + [np.zeros(0)])
+                ok = disc.halo_ipc_selftest(v, (expect[:, None] + 0.25 * np.arange(N)[None, :]).reshape(-1))
+                if not ok:
+                    print(f"[jutul_amd] rank {rank}: push-halo self-test failed, using the collective library", file=sys.stderr)
+        except Exception:  # noqa: BLE001
+            traceback.print_exc(file=sys.stderr)
+            ok = False
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    use = bool(int(flag[0])) and enable
+    disc.halo_ipc_enable(use)
+    return use
+
+
 def setup_rank_problem(ctx, N, part, rank, T, vol, X0, kind="poisson", block_n=1, sources=None, reorder="blocks",
                        block_rows=512, law_params=None, gdz=None, ghost_order="global"):
     """Builds this rank's discretisation + law the way PArraySimulator does per rank (interface.jl:38-63):

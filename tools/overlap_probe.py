@@ -26,6 +26,11 @@ disc = ja.TwoPointPotentialFlowHardCoded(ctx, sub["N"], n_local, reorder="blocks
 send = np.concatenate([np.asarray(c) for c in sub["send"]]); recv = np.concatenate([np.asarray(c) for c in sub["recv"]])
 send = np.resize(send, recv.size)          # self exchange needs equal counts
 disc.set_halo(n_owned, [0], [send], [recv])
+if os.environ.get("PUSH") == "1":  # Krylov-loop exchanges by direct stores into the (own) landing buffer instead of RCCL send/recv
+    assert ctx.comm_ipc_attach([ctx.comm_ipc_export()])
+    ctx.comm_ipc_enable(True)
+    assert disc.halo_ipc_attach([disc.halo_ipc_export()], [0], [recv.size])
+    disc.halo_ipc_enable(True)
 c0 = sub["cells"] - 1
 law = ja.ConservationLaw(disc, "poisson")
 law.set_face_trans(T[sub["faces"] - 1]); law.set_volumes(mesh["volumes"][c0]); law.set_state(U0[c0]); law.set_state0(U0[c0])
@@ -40,6 +45,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 reps = [step() for _ in range(steps)]
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 its = [int(r.linear_iterations) for r in reps]
-print(f"owned {n_owned} ghosts {n_local - n_owned} split {disc.split()} overlap {'on' if os.environ.get('JH_HALO_OVERLAP') else 'off'}: "
+print(f"owned {n_owned} ghosts {n_local - n_owned} split {disc.split()} overlap {'on' if os.environ.get('JH_HALO_OVERLAP') else 'off'} push {os.environ.get('PUSH', '0')}: "
       f"{el / steps * 1e3:.3f} ms/step, {np.mean(its):.1f} its/step, {el / np.sum(its) * 1e6:.1f} us/iteration", flush=True)
 ctx.comm_finalize()
