@@ -82,7 +82,6 @@ struct LocalGroup {
   }
 };
 
-struct Mailbox;  // jh_halo.hip
 struct Comm {
   ncclComm_t comm = nullptr;
   LocalGroup *local = nullptr;
@@ -103,16 +102,25 @@ struct Comm {
 int comm_size(jh_context ctx) { return ctx->comm ? ctx->comm->nranks : 1; }
 int comm_rank(jh_context ctx) { return ctx->comm ? ctx->comm->rank : 0; }
 
-void mailbox_allreduce_launch(hipStream_t s, Mailbox *self, Mailbox *const *peers, int rank, int nranks, uint64_t epoch, double *p,
-                              int n, int op, unsigned *err, uint64_t timeout_ticks);
+void mailbox_allreduce_launch(hipStream_t s, const MailArgs &A, double *p, int n, int op);
 size_t mailbox_bytes();
-constexpr int MAIL_MAX_RANKS = 16, MAIL_MAX_VALUES = 8;
+constexpr int MAIL_MAX_RANKS = MAIL_R, MAIL_MAX_VALUES = MAIL_V;
 
+static MailArgs next_mail_args(jh_context ctx, uint64_t timeout_ticks) {
+  Comm &c = *ctx->comm;
+  MailArgs A;
+  A.self = c.mail_self; A.peers = c.d_mail_peer.p; A.rank = c.rank; A.nranks = c.nranks;
+  A.epoch = ++c.mail_epoch; A.timeout_ticks = timeout_ticks; A.err = const_cast<unsigned *>(c.mail_err);
+  return A;
+}
+bool comm_mail_args(jh_context ctx, int n, MailArgs *out) {
+  if (!ctx->comm || ctx->comm->nranks == 1 || !ctx->comm->mail_enabled || n > MAIL_MAX_VALUES) return false;
+  *out = next_mail_args(ctx, 0);
+  return true;
+}
 // timeout_ticks: 100 MHz ticks, 0 = wait like a collective
 static void mailbox_allreduce(jh_context ctx, double *p, int n, int op, uint64_t timeout_ticks = 0) {
-  Comm &c = *ctx->comm;
-  mailbox_allreduce_launch(ctx->stream, c.mail_self, c.d_mail_peer.p, c.rank, c.nranks, ++c.mail_epoch, p, n, op,
-                           const_cast<unsigned *>(c.mail_err), timeout_ticks);
+  mailbox_allreduce_launch(ctx->stream, next_mail_args(ctx, timeout_ticks), p, n, op);
 }
 
 // in-stream all-reduce of n doubles living in device memory; no-op without a communicator

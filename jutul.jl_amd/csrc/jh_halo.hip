@@ -22,47 +22,11 @@ __global__ void halo_unpack_kernel(double *v, const double *buf, const int32_t *
 // have written into its own, and sums in rank order -- so every rank obtains the same bits.  Two slot sets alternate with
 // the parity of the epoch: a rank can be at most one all-reduce ahead of the slowest one, because it cannot finish epoch
 // e+1 before everybody has contributed to it, i.e. has finished reading epoch e.
-constexpr int MAIL_R = 16, MAIL_V = 8;
-struct Mailbox {
-  double val[2][MAIL_R][MAIL_V];
-  unsigned long long flag[2][MAIL_R];
-  unsigned long long hflag[2][MAIL_R];  // push halo: epoch of the last exchange whose data rank r has delivered here
-};
 size_t mailbox_bytes() { return sizeof(Mailbox); }
 
-__global__ __launch_bounds__(64) void mailbox_allreduce_kernel(Mailbox *self, Mailbox *const *peers, int rank, int nranks,
-                                                               unsigned long long epoch, double *p, int n, int op, unsigned *err,
-                                                               unsigned long long timeout_ticks) {
-  const int lane = threadIdx.x, par = (int)(epoch & 1ull);
-  if (lane < nranks) {
-    Mailbox *dst = peers[lane];
-    for (int i = 0; i < n; ++i) __hip_atomic_store(&dst->val[par][rank][i], p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&dst->flag[par][rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const unsigned long long t0 = wall_clock64();  // constant 100 MHz counter
-    while (__hip_atomic_load(&self->flag[par][lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-      // only the attach-time self-test runs with a time limit (a missing peer is then reported, not waited for); inside a
-      // solve the wait is unbounded like any collective: ranks may legitimately enter it seconds apart
-      if (timeout_ticks && wall_clock64() - t0 > timeout_ticks) {
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-  __syncthreads();
-  if (lane < n) {
-    double acc = __hip_atomic_load(&self->val[par][0][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    for (int r = 1; r < nranks; ++r) {
-      const double v = __hip_atomic_load(&self->val[par][r][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      acc = op == 1 ? ((v > acc || v != v) ? v : acc) : acc + v;
-    }
-    p[lane] = acc;
-  }
-}
-void mailbox_allreduce_launch(hipStream_t s, Mailbox *self, Mailbox *const *peers, int rank, int nranks, uint64_t epoch, double *p,
-                              int n, int op, unsigned *err, uint64_t timeout_ticks) {
-  hipLaunchKernelGGL(mailbox_allreduce_kernel, dim3(1), dim3(64), 0, s, self, peers, rank, nranks, (unsigned long long)epoch, p, n, op,
-                     err, (unsigned long long)timeout_ticks);
+__global__ __launch_bounds__(64) void mailbox_allreduce_kernel(MailArgs A, double *p, int n, int op) { mailbox_allreduce_body(A, p, n, op); }
+void mailbox_allreduce_launch(hipStream_t s, const MailArgs &A, double *p, int n, int op) {
+  hipLaunchKernelGGL(mailbox_allreduce_kernel, dim3(1), dim3(64), 0, s, A, p, n, op);
 }
 
 // ---- push halo ------------------------------------------------------------------------------------------------------------

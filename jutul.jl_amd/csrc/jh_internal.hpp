@@ -78,6 +78,22 @@ struct DevBuf {
 
 struct Comm;  // RCCL state (jh_comm.cpp)
 
+// Mailbox of the node-local scalar all-reduce / push halo (jh_comm_ipc_*, jh_halo_ipc_*; protocol in jh_halo.hip)
+constexpr int MAIL_R = 16, MAIL_V = 8;
+struct Mailbox {
+  double val[2][MAIL_R][MAIL_V];
+  unsigned long long flag[2][MAIL_R];
+  unsigned long long hflag[2][MAIL_R];  // push halo: epoch of the last exchange whose data rank r has delivered here
+};
+// everything a kernel needs to all-reduce a few scalars through the mailboxes; self == nullptr: no all-reduce requested
+struct MailArgs {
+  Mailbox *self = nullptr;
+  Mailbox *const *peers = nullptr;
+  int rank = 0, nranks = 1;
+  unsigned long long epoch = 0, timeout_ticks = 0;  // timeout in 100 MHz ticks, 0 = wait like a collective
+  unsigned *err = nullptr;
+};
+
 }  // namespace jh
 
 // ---- handle structs ------------------------------------------------------------------------------------
@@ -224,6 +240,7 @@ struct SpmvDot {
   const double *w = nullptr;
   int slot = 0;
   int64_t n_rows = 0;
+  bool allreduce = false;  // the result is also summed over the ranks (in the reduction kernel itself when the mailboxes are on)
 };
 constexpr int JH_PUB_LEN = 16;  // doubles per published record: [0..8) scalars, [8] converged flag, [15] sequence number
 constexpr int S_DONE = 20;      // ctx->scalars slot: != 0 once the running Krylov solve has converged (speculative launches exit)
@@ -237,7 +254,11 @@ struct SpmvRange {
 int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta,
            const SpmvDot *dot = nullptr, const double *done = nullptr, const SpmvRange *rng = nullptr);
 void ensure_partials(jh_context ctx, size_t min_stride);
-void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max, const double *done = nullptr);
+void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max, const double *done = nullptr,
+                    const MailArgs *mail = nullptr);
+// jh_comm.cpp: fills *out (and advances the epoch) if n scalars can be all-reduced through the mailboxes right now
+bool comm_mail_args(jh_context ctx, int n, MailArgs *out);
+void comm_allreduce_dev(jh_context ctx, double *p, int n, int op);
 void k_unit_diag(hipStream_t s, const Pattern &P, double *val, double *r, int64_t n_owned);
 void k_scale_system(hipStream_t s, const Pattern &P, double *val, double *r, int kind, double dt);
 
@@ -282,6 +303,40 @@ __device__ __forceinline__ void publish_record(double *sc, int pair_slot, double
   __threadfence_system();
   __hip_atomic_store(rec + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// All-reduce of p[0..n) (n <= MAIL_V, global or LDS memory, in place) over the ranks of the node.  Called by ALL threads of a
+// workgroup of >= 64 threads (threads 0..63 work, everybody joins the barrier); op 0 sum, 1 max (NaN propagating).  Each rank
+// stores its contribution into every rank's mailbox (xGMI peer stores, system-scope release on the epoch flag), waits
+// until all ranks have written into its own, and sums in rank order -- identical bits everywhere.  Two slot sets alternate
+// with the epoch parity: a rank cannot finish epoch e+1 before everybody has finished reading epoch e.
+__device__ __forceinline__ void mailbox_allreduce_body(const MailArgs &A, double *p, int n, int op) {
+  const int lane = threadIdx.x, par = (int)(A.epoch & 1ull);
+  if (lane < A.nranks) {
+    Mailbox *dst = A.peers[lane];
+    for (int i = 0; i < n; ++i) __hip_atomic_store(&dst->val[par][A.rank][i], p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&dst->flag[par][A.rank], A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = wall_clock64();  // constant 100 MHz counter
+    while (__hip_atomic_load(&A.self->flag[par][lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.epoch) {
+      // only the attach-time self-test runs with a time limit (a missing peer is then reported, not waited for); inside a
+      // solve the wait is unbounded like any collective: ranks may legitimately enter it seconds apart
+      if (A.timeout_ticks && wall_clock64() - t0 > A.timeout_ticks) {
+        __hip_atomic_store(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  if (lane < n) {
+    double acc = __hip_atomic_load(&A.self->val[par][0][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int r = 1; r < A.nranks; ++r) {
+      const double v = __hip_atomic_load(&A.self->val[par][r][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      acc = op == 1 ? ((v > acc || v != v) ? v : acc) : acc + v;
+    }
+    p[lane] = acc;
+  }
+  __syncthreads();
+}
+
 // Second stage of the deterministic two-stage reductions: ONE 1024-thread block sums (or maxes) nparts partials of
 // `count` slots in a fixed order.  The loads of a thread are independent (8 accumulators), so even ~50k partials cost a few
 // microseconds instead of a serial latency chain.  out[k] is written by thread 0.

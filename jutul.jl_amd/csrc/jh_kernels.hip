@@ -138,9 +138,10 @@ __global__ __launch_bounds__(256) void absmax_partial_kernel(const double *r, in
 // final stage: see final_reduce_body (jh_internal.hpp)
 template <bool MAX>
 __global__ __launch_bounds__(FIN_THREADS) void final_reduce_kernel(const double *part, size_t stride, int nparts, int count, double *out,
-                                                                   const double *done) {
+                                                                   const double *done, MailArgs mail) {
   if (done && *done != 0.0) return;
   final_reduce_body<MAX>(part, stride, nparts, count, out);
+  if (mail.self) mailbox_allreduce_body(mail, out, count, MAX ? 1 : 0);  // over the ranks, in the same launch
 }
 
 void ensure_partials(jh_context ctx, size_t min_stride) {
@@ -150,11 +151,12 @@ void ensure_partials(jh_context ctx, size_t min_stride) {
     ctx->partials.alloc(ctx->partial_stride * 4);
   }
 }
-void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max, const double *done) {
+void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max, const double *done, const MailArgs *mail) {
+  const MailArgs ma = mail ? *mail : MailArgs();
   if (is_max)
-    hipLaunchKernelGGL(final_reduce_kernel<true>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, nparts, count, ctx->scalars.p + slot, done);
+    hipLaunchKernelGGL(final_reduce_kernel<true>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, nparts, count, ctx->scalars.p + slot, done, ma);
   else
-    hipLaunchKernelGGL(final_reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, nparts, count, ctx->scalars.p + slot, done);
+    hipLaunchKernelGGL(final_reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, nparts, count, ctx->scalars.p + slot, done, ma);
 }
 
 void k_dot2_to(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, double *out) {
@@ -163,7 +165,7 @@ void k_dot2_to(jh_context ctx, const double *a, const double *b, const double *c
   if (g > RED_BLOCKS) g = RED_BLOCKS;
   hipLaunchKernelGGL(dot2_partial_kernel, dim3(g), dim3(256), 0, ctx->stream, a, b, c, d, n, ctx->partials.p, ctx->partial_stride);
   hipLaunchKernelGGL(final_reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, g,
-                     c ? 2 : 1, out, (const double *)nullptr);
+                     c ? 2 : 1, out, (const double *)nullptr, MailArgs());
 }
 void k_dot2(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, int slot) {
   k_dot2_to(ctx, a, b, c, d, n, ctx->scalars.p + slot);
@@ -177,7 +179,7 @@ void k_absmax_strided(jh_context ctx, const double *r, int64_t ncell, int bs, in
   for (int e = 0; e < bs; ++e) {
     hipLaunchKernelGGL(absmax_partial_kernel, dim3(g), dim3(256), 0, ctx->stream, r, ncell, bs, e, ctx->partials.p);
     hipLaunchKernelGGL(final_reduce_kernel<true>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, g, 1,
-                       ctx->scalars.p + slot + e, (const double *)nullptr);
+                       ctx->scalars.p + slot + e, (const double *)nullptr, MailArgs());
   }
 }
 
@@ -350,8 +352,15 @@ int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x,
   const int t_begin = rng ? rng->t0 : 0;
   const int ntl = rng ? rng->t1 - rng->t0 : P.ntiles;
   const int part_off = rng ? rng->part_off : 0;
+  auto reduce = [&](int nparts) {  // second stage; with dot->allreduce also over the ranks (same launch if the mailboxes are on)
+    const int cnt = dot->mode == 2 ? 2 : 1;
+    MailArgs ma;
+    const bool fused = dot->allreduce && comm_mail_args(ctx, cnt, &ma);
+    k_final_reduce(ctx, nparts, cnt, dot->slot, false, done, fused ? &ma : nullptr);
+    if (dot->allreduce && !fused) comm_allreduce_dev(ctx, ctx->scalars.p + dot->slot, cnt, 0);
+  };
   if (ntl <= 0) {
-    if (dot && rng && rng->reduce && part_off > 0) k_final_reduce(ctx, part_off, dot->mode == 2 ? 2 : 1, dot->slot, false, done);
+    if (dot && rng && rng->reduce && part_off > 0) reduce(part_off);
     return 0;
   }
   int chunk = (ntl + NUM_XCD - 1) / NUM_XCD;
@@ -383,7 +392,7 @@ int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x,
 #undef JH_SPMV
 #undef JH_SPMV_X
   // second stage of the fused dot: over the partials of all launches that make up this product
-  if (mode && (!rng || rng->reduce)) k_final_reduce(ctx, part_off + (int)grid.x, mode == 2 ? 2 : 1, dot->slot, false, done);
+  if (mode && (!rng || rng->reduce)) reduce(part_off + (int)grid.x);
   return (int)grid.x;
 }
 

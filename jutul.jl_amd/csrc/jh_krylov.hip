@@ -21,7 +21,6 @@ bool ilu_can_pack_halo(jh_ilu M);
 void halo_exchange_begin(jh_tpfa d, double *v, int bs, bool packed = false);
 void halo_exchange_end(jh_tpfa d);
 void ilu_factor(jh_ilu M);
-void comm_allreduce_dev(jh_context ctx, double *p, int n, int op);
 void halo_exchange(jh_tpfa d, double *v, int bs, bool packed = false, bool push = false);
 }  // namespace jh
 using namespace jh;
@@ -136,9 +135,10 @@ __global__ __launch_bounds__(256) void bicg_xr_dots_kernel(const double *x_in, d
 // publishes the iteration's record (otherwise bicg_publish_kernel does, after the all-reduce)
 __global__ __launch_bounds__(FIN_THREADS) void bicg_reduce_publish_kernel(const double *part, size_t stride, int nparts, double *sc,
                                                                           int out_slot, const double *done, double eps, double *rec,
-                                                                          double seq) {
+                                                                          double seq, MailArgs mail) {
   if (done && *done != 0.0) return;
   final_reduce_body<false>(part, stride, nparts, 2, sc + out_slot);
+  if (mail.self) mailbox_allreduce_body(mail, sc + out_slot, 2, 0);  // over the ranks, in the same launch
   if (rec && threadIdx.x == 0) publish_record(sc, out_slot, eps, rec, seq);
 }
 // p = r + beta*(p - omega*v), beta = (rho'/rho)*(alpha/omega)
@@ -232,9 +232,8 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   auto spmv = [&](double *in, double *out, const SpmvDot *dot, bool packed = false) {
     if (dist) halo_exchange(disc, in, P.bs, packed, true);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
     K->mark(0, st);
-    k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done);
+    k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done);  // dot->allreduce: summed over the ranks in there
     K->mark(0, st);
-    if (dot) comm_allreduce_dev(ctx, sc + dot->slot, dot->mode == 2 ? 2 : 1, 0);
   };
   K->cur_it = 0;
   k_fill(st, x, n, 0.0);
@@ -291,7 +290,6 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     K->mark(2, st);
     k_spmv(ctx, P, K->A->val.p, pv, out, 1.0, 0.0, &dot, done, &r2);
     K->mark(2, st);
-    comm_allreduce_dev(ctx, sc + dot.slot, dot.mode == 2 ? 2 : 1, 0);
   };
   double seq_of[2] = {0, 0};
   double *pend_rec = nullptr, pend_seq = 0, pend_eps = 0;  // record of the previous iteration still to be published (distributed runs)
@@ -313,7 +311,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       yy = K->y.p;
       if (overlap) {
         // NB: q is an input of this gather (p-update) and the output of the SpMV, which follows it on the compute stream
-        SpmvDot d1{1, K->c.p, S_CV, rows_dot};
+        SpmvDot d1{1, K->c.p, S_CV, rows_dot, true};
         fused_half(G, yy, K->q.p, d1);
         v_done = true;
       } else {
@@ -331,7 +329,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       vv = K->v.p;
       dot2(K->c.p, vv, nullptr, nullptr, S_CV);
     } else {
-      SpmvDot d1{1, K->c.p, S_CV, rows_dot};  // <c, A y> fused into the SpMV epilogue
+      SpmvDot d1{1, K->c.p, S_CV, rows_dot, true};  // <c, A y> fused into the SpMV epilogue
       spmv(yy, K->q.p, &d1, y_packed);
     }
     double *zz = K->s.p;
@@ -342,7 +340,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       G.rho_slot = rs; G.cv_slot = S_CV; G.n_owned_rows = ghost_from;
       zz = K->z.p;
       if (overlap) {
-        SpmvDot d2{2, K->s.p, S_TS, rows_dot};
+        SpmvDot d2{2, K->s.p, S_TS, rows_dot, true};
         fused_half(G, zz, K->d.p, d2);
         t_done = true;
       } else {
@@ -363,7 +361,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       tt = K->t.p;
       dot2(tt, K->s.p, tt, tt, S_TS);
     } else {
-      SpmvDot d2{2, K->s.p, S_TS, rows_dot};  // <t,s>, <t,t> fused
+      SpmvDot d2{2, K->s.p, S_TS, rows_dot, true};  // <t,s>, <t,t> fused
       spmv(zz, K->d.p, &d2, z_packed);
     }
     const double seq = (double)(++ctx->pub_seq);
@@ -373,9 +371,11 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     // (rho_next, ||r||^2) -> the other pair; without a communicator the kernel also publishes the record
     hipLaunchKernelGGL(bicg_xr_dots_kernel, g, dim3(256), 0, st, xin, xout, K->r.p, yy, zz, K->s.p, tt, K->c.p, sc, rs, n, nd,
                        ctx->partials.p, ctx->partial_stride, done);
+    MailArgs ma;
+    const bool fused_ar = comm_mail_args(ctx, 2, &ma);  // mailboxes on: all-reduce + publish in the reduction launch itself
     hipLaunchKernelGGL(bicg_reduce_publish_kernel, dim3(1), dim3(FIN_THREADS), 0, st, ctx->partials.p, ctx->partial_stride, (int)g.x,
-                       sc, rn, done, eps_at(k), ctx->comm ? nullptr : rec, seq);
-    if (ctx->comm) {
+                       sc, rn, done, eps_at(k), (ctx->comm && !fused_ar) ? nullptr : rec, seq, fused_ar ? ma : MailArgs());
+    if (ctx->comm && !fused_ar) {
       comm_allreduce_dev(ctx, sc + rn, 2, 0);
       // the record needs the all-reduced pair: it is published by the first kernel of the next iteration (fused ILU gather)
       // when there is one, otherwise by a one-thread kernel
