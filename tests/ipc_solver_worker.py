@@ -49,7 +49,7 @@ dist.all_reduce(ok, op=dist.ReduceOp.MIN)
 assert int(ok[0]) == 1
 ctx.comm_ipc_enable(True)
 disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, rank, T, g["volumes"], X0, kind=kind, block_n=nblk, sources=src,
-                                       block_rows=128, law_params=par, ghost_order="owner")
+                                       block_rows=128, law_params=par, ghost_order=os.environ.get("JH_TEST_GHOST_ORDER", "owner"))
 ctx.comm_set_halo_callback(dd.packed_exchange(sub))
 if os.environ.get("JH_TEST_PUSH", "1") == "1":  # Krylov-loop exchanges by direct stores into the neighbours' landing buffers
     assert dd.setup_push_halo(disc, sub, rank, world)
