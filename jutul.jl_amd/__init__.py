@@ -717,11 +717,15 @@ class Simulator:
                 return True, it, rep
         return False, self.max_it + 1, rep
 
-    def solve_timestep(self, dT):
-        done, t, dt, cuts, its = False, 0.0, dT, 0, 0
+    def solve_timestep(self, dT, dt0=None):
+        """dt0: first ministep to try (a restart continues with the last stored ministep, simulator.jl:700-703)."""
+        done, t, cuts, its = False, 0.0, 0, 0
+        dt = dT if dt0 is None else min(dT, dt0)
+        self.last_ministeps = []
         while not done:
             ok, n, rep = self.solve_ministep(dt)
             its += n
+            self.last_ministeps.append(dict(dt=float(dt), success=bool(ok), iterations=int(n)))
             if ok:
                 t += dt
                 done = t >= dT * (1 - 1e-12)
@@ -734,5 +738,45 @@ class Simulator:
                 dt = dt / 2
         return its
 
-    def simulate(self, timesteps):
-        return [self.solve_timestep(dt) for dt in timesteps]
+    # names of the primary variables in output states (cell index last, the reference's [N, nc] layout)
+    _STATE_NAMES = {"poisson": ("U",), "compressible": ("Pressure",), "twophase": ("Pressure", "Saturations")}
+
+    def get_output_state(self):
+        """get_output_state (simulator/io.jl:62): primary variables by name; the water saturation is stored for two-phase."""
+        X = self.law.get_state().reshape(-1, self.law.N)
+        return {nm: X[:, i].copy() for i, nm in enumerate(self._STATE_NAMES[self.law.kind])}
+
+    def reset_state(self, state):
+        """reset_variables! + reset_previous_state! (simulator.jl:664-669) from an output state."""
+        X = np.stack([np.asarray(state[nm], dtype=np.float64) for nm in self._STATE_NAMES[self.law.kind]], axis=1).reshape(-1)
+        self.law.set_state(X)
+        self.law.set_state0(X)
+
+    def simulate(self, timesteps, output_path=None, restart=None, rank=None, cells_global=None, n_total=None):
+        """simulate! slice (simulator.jl:150-260): report steps with ministep cutting; optional result files per step
+        (io.write_result) and restart (restart=True: after the last stored step; restart=k: from step k, reading k-1).
+        Distributed runs pass rank (0-based), the rank's global cell ids and the global cell count: every rank writes
+        its proc_<rank+1> folder, io.consolidate_distributed_results_on_disk merges them."""
+        from . import io
+        path = output_path
+        if path is not None and rank is not None:
+            path = io.rank_folder(output_path, rank + 1)
+            io.initialize_io(path)
+            io.write_partition(output_path, rank + 1, cells_global, self.disc.n_owned, n_total)
+        io.initialize_io(path)
+        first, dt0 = 1, None
+        # has_restart (simulator.jl:641): nothing / false / the integers 0 and 1 mean "from the first step"; `true` restarts
+        has_restart = not (restart is None or restart is False or (not isinstance(restart, bool) and restart in (0, 1)))
+        if has_restart:
+            state0, dt0, first = io.deserialize_restart(path, restart, len(timesteps))
+            if state0:
+                self.reset_state(state0)
+        out = []
+        for step in range(first, len(timesteps) + 1):
+            its = self.solve_timestep(timesteps[step - 1], dt0)
+            dt0 = None
+            out.append(its)
+            if path is not None:
+                io.write_result(path, self.get_output_state(), dict(ministeps=self.last_ministeps, total_iterations=int(its),
+                                                                    dt=float(timesteps[step - 1])), step)
+        return out

@@ -885,3 +885,66 @@ def test_min_iterations_callback_termination(ja):
         assert high["iterations"] == n1 + 6 and high["status"] == 3
         assert high["residuals"][n1 + 6] < base["residuals"][n1]
         np.testing.assert_allclose(high["residuals"][: n1 + 1], base["residuals"], rtol=1e-9)
+
+
+def test_simulate_output_restart_and_distributed_consolidation(ja, tmp_path):
+    """simulate! with output_path / restart (simulator.jl:150-260, 680-705): a run interrupted after step 2 and restarted gives
+    the states of the uninterrupted run; two in-process ranks write proc_<r> folders that consolidate to the same states."""
+    import threading
+    from jutul_amd import dd, io
+    g = ja.tet_lattice_mesh(7, 6, 5)
+    nc = g["nc"]
+    T = g["T"] / g["T"].mean()
+    X0 = 1.0 + 0.1 * np.random.default_rng(5).random(nc)
+    par = dict(rho0=(1.0, 1.0), compressibility=(5e-2, 5e-2), viscosity=(1.0, 1.0), p_ref=1.0)
+    src = ([1, nc], np.array([[0.5], [-0.5]]))
+    steps = [0.2, 0.4, 0.4, 0.8]
+
+    def make(ctx, disc=None, law=None):
+        if law is None:
+            disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, reorder="blocks", block_rows=64)
+            law = ja.ConservationLaw(disc, "compressible", **par)
+            law.set_face_trans(T); law.set_volumes(g["volumes"]); law.set_state(X0); law.set_state0(X0)
+            law.set_sources(src[0], src[1].reshape(-1))
+        ks = ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"), relative_tolerance=1e-10,
+                              max_iterations=200)
+        return ja.Simulator(law, ks, tolerance=1e-9)
+
+    ctx = ja.HIPContext(0)
+    full = str(tmp_path / "full")
+    its = make(ctx).simulate(steps, output_path=full)
+    assert len(its) == 4 and io.valid_restart_indices(full) == [1, 2, 3, 4]
+    ref = [io.read_restart(full, s)[0]["Pressure"] for s in (1, 2, 3, 4)]
+    assert np.abs(ref[3] - ref[0]).max() > 1e-4  # the state really evolves
+    # interrupted after two steps, then restart=True continues with step 3
+    part = str(tmp_path / "part")
+    make(ctx).simulate(steps[:2], output_path=part)
+    its2 = make(ctx).simulate(steps, output_path=part, restart=True)
+    assert len(its2) == 2
+    for s in (1, 2, 3, 4):
+        np.testing.assert_allclose(io.read_restart(part, s)[0]["Pressure"], ref[s - 1], rtol=1e-9)
+    assert make(ctx).simulate(steps, output_path=part, restart=True) == []  # nothing left to do
+    # two ranks
+    dist_path = str(tmp_path / "dist")
+    part2 = dd.partition_rcb(g["cell_centroids"], 2)
+    group = ja.LocalCommGroup(2)
+    err = []
+
+    def rank_fn(r):
+        try:
+            c = ja.HIPContext(0)
+            c.comm_init_local(group, r)
+            disc, law, sub = dd.setup_rank_problem(c, g["N"], part2, r, T, g["volumes"], X0, kind="compressible", sources=src,
+                                                   block_rows=64, law_params=par)
+            make(c, disc, law).simulate(steps, output_path=dist_path, rank=r, cells_global=sub["cells"], n_total=nc)
+            c.comm_finalize()
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+            raise
+    th = [threading.Thread(target=rank_fn, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    assert not err, err
+    io.consolidate_distributed_results_on_disk(dist_path, 2, [1, 2, 3, 4])
+    for s in (1, 2, 3, 4):
+        np.testing.assert_allclose(io.read_restart(dist_path, s)[0]["Pressure"], ref[s - 1], rtol=1e-7)
