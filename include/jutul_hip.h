@@ -138,8 +138,20 @@ int32_t jh_unit_diagonalize(jh_csr A, jh_vec r, int64_t n_owned);
 #define JH_LAW_POISSON 0      /* VariablePoissonEquation(TimeDependent) (variable_poisson.jl:90-133), N = 1 */
 #define JH_LAW_COMPRESSIBLE 1 /* single-phase slightly compressible, N = 1 (build-defined from flux.jl:335-375) */
 #define JH_LAW_TWOPHASE 2     /* immiscible two-phase (p, S_w), N = 2, SPU upwind (flux.jl:382-405)            */
+#define JH_LAW_CUSTOM 3       /* physics supplied as source at run time (jh_law_create_custom)                 */
 /* params: rho0[2], compressibility[2], viscosity[2], p_ref (7 doubles; NULL = ones/zeros) */
 int32_t jh_law_create(jh_tpfa d, int32_t kind, const double *params, jh_law *out);
+/* Runtime-defined law (the generic-AD path for user equations, equations.jl:578-594, ad/generic.jl:53-96): `source` is HIP
+ * device code defining, for N = block_n of the discretisation (1..3) and the dual type D (value + 2N partials; operators
+ * + - * /, dexp dlog dsqrt dpow, face_average, two_point_potential_drop, upwind of flux.jl:335-405 are provided):
+ *   __device__ void jh_flux(const D *self, const D *other, double T, double gdz, const double *par, D *q);
+ *       q[e] = flux of equation e out of `self` towards `other` across a face with transmissibility T (must be antisymmetric
+ *       in (self, other), conservation.jl:397-415);
+ *   __device__ void jh_mass(const D *x, const double *par, D *M);
+ *       M[e] = conserved quantity per unit volume; the kernel forms vol*(M(x) - M(x0))/dt (conservation.jl:558-568).
+ * It is compiled with hiprtc into the tile assembly kernel; the Jacobian comes from the duals.  params: n_params doubles
+ * readable as par[]. All other jh_law_* / jh_assemble / jh_newton_step calls work on the returned handle. */
+int32_t jh_law_create_custom(jh_tpfa d, const char *source, const double *params, int32_t n_params, jh_law *out);
 int32_t jh_law_destroy(jh_law L);
 #define JH_FACE_TRANS 0 /* T_f [nf]   (compute_face_trans, finite-volume.jl:224-233)  */
 #define JH_FACE_GDZ 1   /* gdz_f [nf] (compute_face_gdz, finite-volume.jl:304-313)    */

@@ -383,12 +383,20 @@ def mul_(y, A, x, alpha=1.0, beta=0.0):
 
 class ConservationLaw(_Handle):
     """ConservationLaw with a TwoPointPotentialFlowHardCoded discretisation and its TPFA storage
-    (core_types.jl:850-856, conservation.jl:101-135).  kind: 'poisson' | 'compressible' | 'twophase'."""
+    (core_types.jl:850-856, conservation.jl:101-135).  kind: 'poisson' | 'compressible' | 'twophase', or 'custom' with
+    `source` = HIP device code for jh_flux / jh_mass written on duals (the generic-AD path for user equations, see
+    jh_law_create_custom in include/jutul_hip.h) and `params` readable there as par[]."""
     _destroy = "jh_law_destroy"
 
-    def __init__(self, disc, kind="poisson", rho0=(1.0, 1.0), compressibility=(0.0, 0.0), viscosity=(1.0, 1.0), p_ref=0.0):
+    def __init__(self, disc, kind="poisson", rho0=(1.0, 1.0), compressibility=(0.0, 0.0), viscosity=(1.0, 1.0), p_ref=0.0,
+                 source=None, params=()):
         super().__init__()
         self.ctx, self.disc, self.kind = disc.ctx, disc, kind
+        if kind == "custom":
+            self.N = disc.block_n
+            par = f64(list(params))
+            check(_L().jh_law_create_custom(disc.h, source.encode(), pf(par) if par.size else None, par.size, C.byref(self.h)))
+            return
         self.N = 2 if kind == "twophase" else 1
         par = f64(list(rho0) + list(compressibility) + list(viscosity) + [p_ref])
         check(_L().jh_law_create(disc.h, LAW[kind], pf(par), C.byref(self.h)))
@@ -741,14 +749,17 @@ class Simulator:
     # names of the primary variables in output states (cell index last, the reference's [N, nc] layout)
     _STATE_NAMES = {"poisson": ("U",), "compressible": ("Pressure",), "twophase": ("Pressure", "Saturations")}
 
+    def _state_names(self):
+        return self._STATE_NAMES.get(self.law.kind) or tuple(f"X{i + 1}" for i in range(self.law.N))
+
     def get_output_state(self):
         """get_output_state (simulator/io.jl:62): primary variables by name; the water saturation is stored for two-phase."""
         X = self.law.get_state().reshape(-1, self.law.N)
-        return {nm: X[:, i].copy() for i, nm in enumerate(self._STATE_NAMES[self.law.kind])}
+        return {nm: X[:, i].copy() for i, nm in enumerate(self._state_names())}
 
     def reset_state(self, state):
         """reset_variables! + reset_previous_state! (simulator.jl:664-669) from an output state."""
-        X = np.stack([np.asarray(state[nm], dtype=np.float64) for nm in self._STATE_NAMES[self.law.kind]], axis=1).reshape(-1)
+        X = np.stack([np.asarray(state[nm], dtype=np.float64) for nm in self._state_names()], axis=1).reshape(-1)
         self.law.set_state(X)
         self.law.set_state0(X)
 

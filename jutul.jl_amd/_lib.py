@@ -71,6 +71,7 @@ SIGNATURES = {
     "jh_scale_system": [H, H, C.c_int32, C.c_double],
     "jh_unit_diagonalize": [H, H, C.c_int64],
     "jh_law_create": [H, C.c_int32, F64P, C.POINTER(H)],
+    "jh_law_create_custom": [H, C.c_char_p, F64P, C.c_int32, C.POINTER(H)],
     "jh_law_destroy": [H],
     "jh_law_set_data": [H, C.c_int32, F64P],
     "jh_law_set_state": [H, F64P],

@@ -293,9 +293,18 @@ void k_set_diag_data(hipStream_t s, double *nzdata, const int32_t *diag, const i
   if (n) hipLaunchKernelGGL(set_diag_kernel, dim3(g), dim3(256), 0, s, nzdata, diag, perm, cell_data, n, use_const, cval);
 }
 
+void custom_launch(jh_law L, double dt, jh_csr A, jh_vec r);  // jh_custom.cpp
+
 void k_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
   const Pattern &P = *A->pat;
   jh_context ctx = L->ctx;
+  if (L->kind == JH_LAW_CUSTOM) {
+    custom_launch(L, dt, A, r);
+    if (L->nsrc)
+      hipLaunchKernelGGL(sources_kernel, dim3((unsigned)((L->nsrc * L->N + 255) / 256)), dim3(256), 0, ctx->stream, r->d.p,
+                         L->src_cell.p, L->src_val.p, L->nsrc, L->N);
+    return;
+  }
   LawPar par;
   par.rho0[0] = L->par[0]; par.rho0[1] = L->par[1];
   par.comp[0] = L->par[2]; par.comp[1] = L->par[3];

@@ -213,6 +213,13 @@ struct jh_law_s {
   int64_t nsrc = 0;
   jh::DevBuf<int32_t> src_cell;
   jh::DevBuf<double> src_val;
+  // JH_LAW_CUSTOM: the assembly kernel compiled at run time from the user's source (jh_custom.cpp)
+  hipModule_t custom_module = nullptr;
+  hipFunction_t custom_kernel = nullptr;
+  jh::DevBuf<double> custom_par;
+  ~jh_law_s() {
+    if (custom_module) (void)hipModuleUnload(custom_module);
+  }
 };
 
 namespace jh {

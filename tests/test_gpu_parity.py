@@ -948,3 +948,95 @@ def test_simulate_output_restart_and_distributed_consolidation(ja, tmp_path):
     io.consolidate_distributed_results_on_disk(dist_path, 2, [1, 2, 3, 4])
     for s in (1, 2, 3, 4):
         np.testing.assert_allclose(io.read_restart(dist_path, s)[0]["Pressure"], ref[s - 1], rtol=1e-7)
+
+
+# ---- runtime-defined laws (SURVEY a-7 / 8f-3) ------------------------------------------------------------------------------------
+COMPRESSIBLE_SRC = r"""
+// par: rho0, c, mu, p_ref -- the built-in single-phase law restated as user code
+__device__ D rho(D p, const double *par) { return par[0] * dexp(par[1] * (p - par[3])); }
+__device__ void jh_flux(const D *self, const D *other, double T, double gdz, const double *par, D *q) {
+  D rs = rho(self[0], par), ro = rho(other[0], par);
+  D dphi = two_point_potential_drop(self[0], other[0], gdz, rs, ro);
+  q[0] = (T / par[2]) * (face_average(rs, ro) * dphi);
+}
+__device__ void jh_mass(const D *x, const double *par, D *M) { M[0] = rho(x[0], par); }
+"""
+
+REACTION_SRC = r"""
+// two coupled species: nonlinear diffusion of u with a v-dependent mobility, linear diffusion of v, cubic storage of u
+__device__ void jh_flux(const D *s, const D *o, double T, double gdz, const double *par, D *q) {
+  D mob = par[0] + face_average(s[1], o[1]) * face_average(s[1], o[1]);
+  q[0] = T * (mob * (s[0] - o[0]));
+  q[1] = (par[1] * T) * (s[1] - o[1]) + gdz * upwind(s[1] - o[1], s[1], o[1]);
+}
+__device__ void jh_mass(const D *x, const double *par, D *M) {
+  M[0] = x[0] + par[2] * (x[0] * x[0] * x[0]);
+  M[1] = dsqrt(x[1]) * x[0];
+}
+"""
+
+
+def test_custom_law_reproduces_the_builtin_compressible_law(ja, oracle):
+    g = ja.tet_lattice_mesh(6, 5, 4)
+    nc = g["nc"]
+    T = g["T"] / g["T"].mean()
+    rng = np.random.default_rng(11)
+    gdz = 0.05 * rng.standard_normal(g["nf"])
+    P, P0 = 1.0 + 0.2 * rng.random(nc), 1.0 + 0.2 * rng.random(nc)
+    ctx = ja.HIPContext(0)
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, reorder="blocks", block_rows=64)
+    out = []
+    for law in (ja.ConservationLaw(disc, "compressible", rho0=(1.3, 1.0), compressibility=(0.07, 0.0), viscosity=(0.9, 1.0), p_ref=1.1),
+                ja.ConservationLaw(disc, "custom", source=COMPRESSIBLE_SRC, params=[1.3, 0.07, 0.9, 1.1])):
+        law.set_face_trans(T); law.set_face_gdz(gdz); law.set_volumes(g["volumes"]); law.set_state(P); law.set_state0(P0)
+        law.set_sources([3], [0.25])
+        lsys = ja.LinearizedSystem(disc)
+        law.update_equation_and_linearized_system(0.7, lsys.jac, lsys.r)
+        out.append((lsys.r.download(), np.array(lsys.jac.nzval)))
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-13, atol=1e-15)
+    # and a full Newton step converges with it
+    law.set_state(P0)
+    ok, its, _ = ja.Simulator(law, ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"),
+                                                    relative_tolerance=1e-10), tolerance=1e-9).solve_ministep(0.7)
+    assert ok and 2 <= its <= 8
+
+
+def test_custom_two_equation_law_jacobian_matches_finite_differences(ja):
+    """A law that is not built in (2 equations per cell): the dual-generated 2x2-block Jacobian == central differences of the
+    residual; conservation of the flux part; compile errors are reported."""
+    g = ja.tet_lattice_mesh(4, 4, 3)
+    nc = g["nc"]
+    T = g["T"] / g["T"].mean()
+    rng = np.random.default_rng(12)
+    gdz = 0.1 * rng.standard_normal(g["nf"])
+    X = np.stack([1.0 + 0.3 * rng.random(nc), 0.5 + 0.4 * rng.random(nc)], axis=1).reshape(-1)
+    X0 = X * (1.0 + 0.05 * rng.standard_normal(X.size))
+    ctx = ja.HIPContext(0)
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, block_n=2, reorder="blocks", block_rows=64)
+    law = ja.ConservationLaw(disc, "custom", source=REACTION_SRC, params=[0.4, 0.7, 0.3])
+    law.set_face_trans(T); law.set_face_gdz(gdz); law.set_volumes(g["volumes"]); law.set_state0(X0)
+    lsys = ja.LinearizedSystem(disc)
+    dt = 0.9
+
+    def residual(x):
+        law.set_state(x)
+        law.update_equation_and_linearized_system(dt, lsys.jac, lsys.r)
+        return lsys.r.download()
+
+    r0 = residual(X)
+    A = lsys.jac  # Jacobian at X
+    y = np.zeros(2 * nc)
+    v = rng.standard_normal(2 * nc)
+    Jv = ja.mul_(ja.DeviceVector(disc), A, ja.DeviceVector(disc, v)).download()
+    h = 1e-6
+    fd = (residual(X + h * v) - residual(X - h * v)) / (2 * h)
+    # the SPU upwind switch of equation 2 is only piecewise smooth: rows next to a switching face may differ
+    bad = np.abs(Jv - fd) > 1e-6 * (1 + np.abs(fd))
+    assert bad.mean() < 0.02, bad.mean()
+    # flux antisymmetry => the flux part of each equation sums to zero: sum(r) == sum(vol*(M - M0))/dt
+    u, w, u0, w0 = X[0::2], X[1::2], X0[0::2], X0[1::2]
+    M1, M10 = u + 0.3 * u ** 3, u0 + 0.3 * u0 ** 3
+    assert np.isclose(r0[0::2].sum(), (g["volumes"] * (M1 - M10)).sum() / dt, rtol=1e-10)
+    with pytest.raises(ja.JutulHIPError, match="does not compile"):
+        ja.ConservationLaw(disc, "custom", source="__device__ void jh_flux() { syntax error }", params=[])
