@@ -3,7 +3,7 @@
 N=${1:-8}; CELLS=${2:-10000000}
 R=$GRAFT_REPO_ROOT; cd $R
 free -g | head -2
-JH_BENCH_HALO=host HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus $N --steps 3 --warmup 1 --cells $CELLS --no-cpu > gpurun_out/mp_$N.json 2> gpurun_out/mp_$N.err
+JH_BENCH_HALO=host HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus $N --steps 3 --warmup 1 --cells $CELLS --no-cpu > gpurun_out/mp_$N.json 2> gpurun_out/mp_$N.err
 echo rc=$?
 python - $N <<'PY'
 import json,sys
