@@ -254,6 +254,8 @@ def main():
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if world > 1:
+        barrier()  # peers poll each other's mailboxes / landing buffers: nobody unmaps while somebody may still run
     if world > 1 or force_dist:
         ctx.comm_finalize()
     if world > 1:

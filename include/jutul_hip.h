@@ -262,6 +262,8 @@ int32_t jh_comm_finalize(jh_context ctx);
  * reductions with known answers, time-out guarded: *ok = 0 on any failure), the host ANDs the *ok of all ranks and calls
  * jh_comm_ipc_enable.  Without enable, ncclAllReduce is used.  jh_comm_init_ipc_only creates a communicator without RCCL
  * (scalar reductions only): for tests with several processes on one GPU. */
+/* Teardown: peers write into and poll each other's mailboxes / landing buffers, so the host must synchronise the ranks
+ * (barrier) after the last solve and before any rank calls jh_comm_finalize / jh_tpfa_destroy. */
 int32_t jh_comm_init_ipc_only(jh_context ctx, int32_t nranks, int32_t rank);
 /* Host-language halo backend: instead of ncclSend/ncclRecv the library stages the packed send buffer to the host and calls
  * fn(user, send, n_send, recv, n_recv, block_n), which must fill recv (both buffers hold block_n doubles per cell, the
