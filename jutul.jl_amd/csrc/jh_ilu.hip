@@ -48,8 +48,11 @@ struct jh_ilu_s {
   std::vector<int32_t> flev_off, flev_ptr; // per block: offsets into flev_ptr; flev_ptr: ilu row starts
   std::vector<int32_t> blev_off, blev_ptr; // backward levels over U-order positions
   std::vector<int32_t> l_ptr, l_col, l_map, u_ptr, u_col, u_map, d_map, u_row, upos_of;
-  std::vector<int32_t> l_lev, u_lev;  // in-block level of every ilu row (fwd order) / U-order position (bwd order)
-  DevBuf<int32_t> d_l_lev, d_u_lev;
+  std::vector<uint16_t> l_lev, u_lev;  // in-block level of every ilu row (fwd order) / U-order position (bwd order)
+  DevBuf<uint16_t> d_l_lev, d_u_lev;
+  // 16-bit copies of the block-local metadata for the chunked apply (LDS mode: < 8192 rows per block)
+  DevBuf<uint16_t> d_l_col16, d_u_col16, d_u_row16, d_rowmap16;
+  bool rowmap_local = false;  // block b's rows are the device rows [blk_ptr[b], blk_ptr[b+1]): rowmap16 = offset in the block
   DevBuf<int32_t> d_rowmap, d_blk_ptr, d_flev_off, d_flev_ptr, d_blev_off, d_blev_ptr, d_l_ptr, d_l_col, d_l_map, d_u_ptr,
       d_u_col, d_u_map, d_d_map, d_u_row, d_upos_of;
   DevBuf<double> l_val, u_val, dinv, xg;
@@ -130,7 +133,8 @@ template <> __device__ __forceinline__ Blk<3> blk_inv<3>(const Blk<3> &A) {
 
 struct IluDev {
   const int32_t *rowmap, *blk_ptr, *flev_off, *flev_ptr, *blev_off, *blev_ptr;
-  const int32_t *l_ptr, *l_col, *l_map, *u_ptr, *u_col, *u_map, *d_map, *u_row, *upos_of, *l_lev, *u_lev;
+  const int32_t *l_ptr, *l_col, *l_map, *u_ptr, *u_col, *u_map, *d_map, *u_row, *upos_of;
+  const uint16_t *l_lev, *u_lev, *l_col16, *u_col16, *u_row16, *rowmap16;
   double *l_val, *u_val, *dinv;
   // fused halo pack (may be null): block b copies local rows send_local[j] to send_buf[send_slot[j]], j in [send_ptr[b], send_ptr[b+1])
   const int32_t *send_ptr, *send_local, *send_slot;
@@ -399,12 +403,13 @@ struct RowPF {
   double dinv[BS * BS];
 };
 
-template <int BS, bool BWD>
+// C16: read the 16-bit copies of the block-local metadata (chunked apply)
+template <int BS, bool BWD, bool C16 = false>
 __device__ __forceinline__ void pf_ptrs(const IluDev &F, RowPF<BS> &R, int idx, int end, int b0) {
   // idx: ilu row (fwd) or U-order position (bwd)
   if (idx < end) {
     if (BWD) {
-      R.lt = F.u_row[idx];
+      R.lt = C16 ? (int)F.u_row16[idx] : F.u_row[idx];
       R.s = F.u_ptr[idx];
       R.e = F.u_ptr[idx + 1];
 #pragma unroll
@@ -419,23 +424,25 @@ __device__ __forceinline__ void pf_ptrs(const IluDev &F, RowPF<BS> &R, int idx, 
     R.s = R.e = 0;
   }
 }
-template <int BS, bool BWD>
+template <int BS, bool BWD, bool C16 = false>
 __device__ __forceinline__ void pf_entries(const IluDev &F, RowPF<BS> &R) {
   const int32_t *cols = BWD ? F.u_col : F.l_col;
+  const uint16_t *cols16 = BWD ? F.u_col16 : F.l_col16;
   const double *vals = BWD ? F.u_val : F.l_val;
 #pragma unroll
   for (int j = 0; j < PFW; ++j) {
     if (R.s + j < R.e) {
-      R.col[j] = cols[R.s + j];
+      R.col[j] = C16 ? (int)cols16[R.s + j] : cols[R.s + j];
 #pragma unroll
       for (int i = 0; i < BS * BS; ++i) R.val[j * BS * BS + i] = vals[(size_t)(R.s + j) * BS * BS + i];
     }
   }
 }
-template <int BS, bool BWD>
+template <int BS, bool BWD, bool C16 = false>
 __device__ __forceinline__ void pf_compute(const IluDev &F, const RowPF<BS> &R, double *xs) {
   if (R.lt < 0) return;
   const int32_t *cols = BWD ? F.u_col : F.l_col;
+  const uint16_t *cols16 = BWD ? F.u_col16 : F.l_col16;
   const double *vals = BWD ? F.u_val : F.l_val;
   double v[BS];
 #pragma unroll
@@ -458,7 +465,7 @@ __device__ __forceinline__ void pf_compute(const IluDev &F, const RowPF<BS> &R, 
     }
   }
   for (int j = R.s + PFW; j < R.e; ++j) {  // slow tail for long rows
-    const int k = cols[j];
+    const int k = C16 ? (int)cols16[j] : cols[j];
 #pragma unroll
     for (int e = 0; e < BS; ++e) {
       double sum = 0.0;
@@ -552,26 +559,26 @@ __global__ void ilu_apply_blocks_pf_kernel(IluDev F, const double *__restrict__ 
 template <int BS, bool BWD>
 __device__ __forceinline__ void chunk_sweep(const IluDev &F, double *xs, int b0, int b1, int skip_level0) {
   const int lane = threadIdx.x;
-  const int32_t *levs = BWD ? F.u_lev : F.l_lev;
+  const uint16_t *levs = BWD ? F.u_lev : F.l_lev;
   RowPF<BS> cur, nxt, nn;
   int lv_cur = -1, lv_nxt = -1, lv_nn = -1;
   int base = b0;
   // prologue
-  pf_ptrs<BS, BWD>(F, cur, base + lane, b1, b0);
+  pf_ptrs<BS, BWD, true>(F, cur, base + lane, b1, b0);
   if (base + lane < b1) lv_cur = levs[base + lane];
-  pf_entries<BS, BWD>(F, cur);
-  pf_ptrs<BS, BWD>(F, nxt, base + 64 + lane, b1, b0);
+  pf_entries<BS, BWD, true>(F, cur);
+  pf_ptrs<BS, BWD, true>(F, nxt, base + 64 + lane, b1, b0);
   if (base + 64 + lane < b1) lv_nxt = levs[base + 64 + lane];
   for (; base < b1; base += 64) {
-    pf_entries<BS, BWD>(F, nxt);
-    pf_ptrs<BS, BWD>(F, nn, base + 128 + lane, b1, b0);
+    pf_entries<BS, BWD, true>(F, nxt);
+    pf_ptrs<BS, BWD, true>(F, nn, base + 128 + lane, b1, b0);
     lv_nn = (base + 128 + lane < b1) ? levs[base + 128 + lane] : -1;
     // levels present in this chunk: rows are sorted by level, so [level of lane 0, level of the last valid lane]
     const int nvalid = min(64, b1 - base);
     const int lv_lo = __shfl(lv_cur, 0, 64);
     const int lv_hi = __shfl(lv_cur, nvalid - 1, 64);
     for (int lv = max(lv_lo, skip_level0); lv <= lv_hi; ++lv) {
-      if (lv_cur == lv) pf_compute<BS, BWD>(F, cur, xs);
+      if (lv_cur == lv) pf_compute<BS, BWD, true>(F, cur, xs);
       __syncthreads();
     }
     cur = nxt; lv_cur = lv_nxt;
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const d
     ca = (rho_next / rho) * (alpha / cb);        // beta
   }
   for (int t = threadIdx.x; t < nr; t += 64) {
-    const int dev = F.rowmap[b0 + t];
+    const int dev = b0 + (int)F.rowmap16[b0 + t];  // the block's rows are the device rows [b0, b1)
 #pragma unroll
     for (int e = 0; e < BS; ++e) {
       const size_t o = (size_t)dev * BS + e;
@@ -625,7 +632,7 @@ __global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const d
   chunk_sweep<BS, false>(F, xs, b0, b1, 1);  // forward: level-0 rows have no L entries
   chunk_sweep<BS, true>(F, xs, b0, b1, 0);   // backward: every row is scaled by its inverted pivot
   for (int t = threadIdx.x; t < nr; t += 64) {
-    const int dev = F.rowmap[b0 + t];
+    const int dev = b0 + (int)F.rowmap16[b0 + t];  // the block's rows are the device rows [b0, b1)
 #pragma unroll
     for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[t * BS + e];
   }
@@ -718,6 +725,7 @@ IluDev dev_view(jh_ilu M) {
   F.u_ptr = M->d_u_ptr.p; F.u_col = M->d_u_col.p; F.u_map = M->d_u_map.p;
   F.d_map = M->d_d_map.p; F.u_row = M->d_u_row.p; F.upos_of = M->d_upos_of.p;
   F.l_lev = M->d_l_lev.p; F.u_lev = M->d_u_lev.p;
+  F.l_col16 = M->d_l_col16.p; F.u_col16 = M->d_u_col16.p; F.u_row16 = M->d_u_row16.p; F.rowmap16 = M->d_rowmap16.p;
   F.l_val = M->l_val.p; F.u_val = M->u_val.p; F.dinv = M->dinv.p;
   F.send_ptr = nullptr; F.send_local = nullptr; F.send_slot = nullptr; F.send_buf = nullptr; F.send_dst = nullptr;
   return F;
@@ -889,8 +897,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     }
     M->l_lev.resize(n);
     M->u_lev.resize(n);
-    for (int64_t t = 0; t < n; ++t) M->l_lev[t] = flev[order[t]];
-    for (int64_t pos = 0; pos < n; ++pos) M->u_lev[pos] = blev[order[uord[pos]]];
+    if (maxlev >= 65536) JH_THROW("more than 65535 dependency levels");
+    for (int64_t t = 0; t < n; ++t) M->l_lev[t] = (uint16_t)flev[order[t]];
+    for (int64_t pos = 0; pos < n; ++pos) M->u_lev[pos] = (uint16_t)blev[order[uord[pos]]];
     // fused halo pack: (block, local row) of every send row of the discretisation's halo plan
     if (lds && A->disc && A->disc->halo.active && A->disc->halo.n_send > 0) {
       const auto &H = A->disc->halo;
@@ -912,6 +921,18 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     }
     // upload
     hipStream_t s = M->ctx->stream;
+    if (lds) {  // 16-bit copies for the chunked apply
+      std::vector<uint16_t> lc(M->l_col.begin(), M->l_col.end()), uc(M->u_col.begin(), M->u_col.end()), ur(M->u_row.begin(), M->u_row.end());
+      std::vector<uint16_t> rm(n);
+      M->rowmap_local = true;
+      for (int64_t b = 0; b < nb; ++b)
+        for (int32_t t = M->blk_ptr[b]; t < M->blk_ptr[b + 1]; ++t) {
+          const int32_t off = M->rowmap[t] - M->blk_ptr[b];
+          if (off < 0 || off >= M->blk_ptr[b + 1] - M->blk_ptr[b]) M->rowmap_local = false;
+          rm[t] = (uint16_t)off;
+        }
+      M->d_l_col16.upload(lc, s); M->d_u_col16.upload(uc, s); M->d_u_row16.upload(ur, s); M->d_rowmap16.upload(rm, s);
+    }
     if (!M->send_ptr.empty()) {
       M->d_send_ptr.upload(M->send_ptr, s); M->d_send_local.upload(M->send_local, s); M->d_send_slot.upload(M->send_slot, s);
     }
@@ -1090,7 +1111,7 @@ void ilu_apply(jh_ilu M, const double *b, double *x) {
 }
 bool ilu_can_fuse_gather(jh_ilu M) {
   static const bool off = getenv("JH_ILU_NO_CHUNK") != nullptr || getenv("JH_NO_FUSE") != nullptr;
-  return M && M->kind == 0 && M->lds_mode && M->threads == 64 && !off;
+  return M && M->kind == 0 && M->lds_mode && M->threads == 64 && M->rowmap_local && !off;
 }
 // x = M^-1 * (fused vector update), see IluGather / ilu_apply_chunked_kernel
 // true if ilu_apply_fused(..., pack = true) can fill the halo send buffer of the matrix' discretisation
