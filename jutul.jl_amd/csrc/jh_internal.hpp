@@ -140,6 +140,9 @@ struct Pattern {
   // tiles
   std::vector<int32_t> tile_row;
   int32_t ntiles = 0;
+  std::vector<int32_t> tile_desc;  // per tile (first row, rows, first entry, entries): one 16-byte load instead of the chain
+                                   // tile_row -> rowptr -> entries at the start of every tile
+  DevBuf<int32_t> d_tile_desc;
   // device copies
   DevBuf<int32_t> d_rowptr, d_col, d_diag, d_perm, d_nz_hslot, d_tile_row;
   void build_tiles();

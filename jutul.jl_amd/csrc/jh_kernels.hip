@@ -224,10 +224,8 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
   if (xcd * chunk + tl >= ntiles) break;
   const int t = t_begin + xcd * chunk + tl;
   if (tl != wg) __syncthreads();  // the previous tile's LDS contents are dead only once every lane is done with them
-  const int r0 = tile_row[t], r1 = tile_row[t + 1];
-  const int nrows = r1 - r0;
-  const int base = rowptr[r0];
-  const int cnt = rowptr[r1] - base;
+  const int4 td = reinterpret_cast<const int4 *>(tile_row)[t];  // tile descriptor (Pattern::tile_desc)
+  const int r0 = td.x, nrows = td.y, base = td.z, cnt = td.w;
   if (nrows == 1 && cnt > TILE_NNZ) {
     // long row: the whole workgroup strides over one row, then block-reduces
     double acc[BS];
@@ -346,6 +344,115 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
   }
 }
 
+
+// Software-pipelined variant of the scalar SpMV with a fused dot (the BiCGStab workhorse): a tile costs a chain of dependent
+// memory latencies (descriptor -> entries -> far x), and with 8 resident workgroups per CU one tile in flight per workgroup
+// leaves the memory system under-subscribed.  Here the first-level loads of tile i+1 (column ids, values, x window, row
+// offsets) are issued before tile i is processed out of registers and LDS.
+struct SpmvTilePre {
+  int r0, nrows, base, cnt;
+  int cidx[TILE_NNZ / TILE_THREADS];
+  double vv[TILE_NNZ / TILE_THREADS];
+  double xa, xb;
+  int rpv;
+};
+template <int DOT>
+__global__ __launch_bounds__(TILE_THREADS) void spmv_pipe_kernel(const int32_t *__restrict__ tile_desc, int ntiles, int ncols,
+                                                                 const int32_t *__restrict__ rowptr,
+                                                                 const int32_t *__restrict__ col,
+                                                                 const double *__restrict__ val,
+                                                                 const double *__restrict__ x, double *__restrict__ y,
+                                                                 double alpha, double beta, const double *__restrict__ dw,
+                                                                 int dot_rows, double *__restrict__ part, size_t pstride,
+                                                                 const double *done, int t_begin) {
+  if (done && *done != 0.0) return;
+  constexpr int KPT = TILE_NNZ / TILE_THREADS;
+  __shared__ double prod[TILE_NNZ];
+  __shared__ int32_t rp[TILE_ROWS + 1];
+  __shared__ double red[8];
+  __shared__ double xw[TILE_ROWS + 2 * SPMV_WIN];
+  const int tid = threadIdx.x;
+  double d0 = 0.0, d1 = 0.0;
+  const int chunk = (ntiles + NUM_XCD - 1) / NUM_XCD;
+  const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, wgs = gridDim.x / NUM_XCD;
+  auto in_range = [&](int tl) { return tl < chunk && xcd * chunk + tl < ntiles; };
+  auto issue = [&](int tl, SpmvTilePre &T) {  // descriptor + first-level loads of tile tl (entries beyond the tile: zeros)
+    const int4 td = reinterpret_cast<const int4 *>(tile_desc)[t_begin + xcd * chunk + tl];
+    T.r0 = td.x; T.nrows = td.y; T.base = td.z; T.cnt = td.w;
+    if (T.nrows == 1 && T.cnt > TILE_NNZ) return;  // long row: handled synchronously
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int k = tid + j * TILE_THREADS;
+      T.cidx[j] = (k < T.cnt) ? col[T.base + k] : 0;
+      T.vv[j] = (k < T.cnt) ? val[T.base + k] : 0.0;
+    }
+    const int w0 = max(0, T.r0 - SPMV_WIN);
+    const int wn = min(ncols, T.r0 + TILE_ROWS + SPMV_WIN) - w0;
+    T.xa = (tid < wn) ? x[w0 + tid] : 0.0;
+    T.xb = (tid + TILE_THREADS < wn) ? x[w0 + tid + TILE_THREADS] : 0.0;
+    T.rpv = (tid < T.nrows) ? rowptr[T.r0 + tid] - T.base : T.cnt;
+  };
+  SpmvTilePre cur, nxt;
+  int tl = wg;
+  bool have = in_range(tl);
+  if (have) issue(tl, cur);
+  while (have) {
+    const int tln = tl + wgs;
+    const bool have_next = in_range(tln);
+    if (have_next) issue(tln, nxt);
+    const int r0 = cur.r0, nrows = cur.nrows, base = cur.base, cnt = cur.cnt;
+    if (nrows == 1 && cnt > TILE_NNZ) {  // long row: the whole workgroup strides over one row, then block-reduces
+      double acc = 0.0;
+      for (int k = tid; k < cnt; k += TILE_THREADS) acc += val[base + k] * x[col[base + k]];
+      const double s = block_reduce<false>(acc, red);
+      if (tid == 0) {
+        const double yv = (beta == 0.0) ? alpha * s : alpha * s + beta * y[r0];
+        y[r0] = yv;
+        if (r0 < dot_rows) { d0 += yv * dw[r0]; if (DOT == 2) d1 += yv * yv; }
+      }
+    } else {
+      const int w0 = max(0, r0 - SPMV_WIN);
+      const int wn = min(ncols, r0 + TILE_ROWS + SPMV_WIN) - w0;
+      rp[tid] = cur.rpv;
+      if (tid == 0) rp[nrows] = cnt;
+      xw[tid] = cur.xa;
+      xw[tid + TILE_THREADS] = cur.xb;
+      __syncthreads();
+      double xg[KPT];
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const unsigned loc = (unsigned)(cur.cidx[j] - w0);
+        xg[j] = (loc < (unsigned)wn) ? xw[loc] : x[cur.cidx[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const int k = tid + j * TILE_THREADS;
+        if (k < cnt) prod[k] = cur.vv[j] * xg[j];
+      }
+      __syncthreads();
+      if (tid < nrows) {
+        double s = 0.0;
+        for (int j = rp[tid]; j < rp[tid + 1]; ++j) s = s + prod[j];
+        const int o = r0 + tid;
+        const double yv = (beta == 0.0) ? alpha * s : alpha * s + beta * y[o];
+        y[o] = yv;
+        if (o < dot_rows) { d0 += yv * dw[o]; if (DOT == 2) d1 += yv * yv; }
+      }
+    }
+    __syncthreads();  // LDS is reused by the next tile
+    cur = nxt;
+    tl = tln;
+    have = have_next;
+  }
+  __syncthreads();
+  const double p0 = block_reduce<false>(d0, red);
+  if (tid == 0) part[blockIdx.x] = p0;
+  if (DOT == 2) {
+    const double p1 = block_reduce<false>(d1, red);
+    if (tid == 0) part[pstride + blockIdx.x] = p1;
+  }
+}
+
 int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta,
            const SpmvDot *dot, const double *done, const SpmvRange *rng) {
   if (P.n == 0) return 0;
@@ -376,11 +483,13 @@ int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x,
   static const bool xwin = getenv("JH_SPMV_NO_WINDOW") == nullptr;
 #define JH_SPMV(BSV, DV)                                                                                                      \
   if (BSV == 1 && xwin) JH_SPMV_X(BSV, DV, true); else JH_SPMV_X(BSV, DV, false)
-#define JH_SPMV_X(BSV, DV, XWV) hipLaunchKernelGGL((spmv_tile_kernel<BSV, DV, (BSV == 1) && XWV>), grid, block, 0, ctx->stream, P.d_tile_row.p, ntl, (int)P.n, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta, dw, drows, part, ps, done, t_begin)
+#define JH_SPMV_X(BSV, DV, XWV) hipLaunchKernelGGL((spmv_tile_kernel<BSV, DV, (BSV == 1) && XWV>), grid, block, 0, ctx->stream, P.d_tile_desc.p, ntl, (int)P.n, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta, dw, drows, part, ps, done, t_begin)
+  static const bool pipe = getenv("JH_SPMV_NO_PIPE") == nullptr;
+#define JH_SPMV_PIPE(DV) hipLaunchKernelGGL((spmv_pipe_kernel<DV>), grid, block, 0, ctx->stream, P.d_tile_desc.p, ntl, (int)P.n, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta, dw, drows, part, ps, done, t_begin)
   switch (P.bs * 10 + mode) {
     case 10: JH_SPMV(1, 0); break;
-    case 11: JH_SPMV(1, 1); break;
-    case 12: JH_SPMV(1, 2); break;
+    case 11: if (xwin && pipe) JH_SPMV_PIPE(1); else JH_SPMV(1, 1); break;
+    case 12: if (xwin && pipe) JH_SPMV_PIPE(2); else JH_SPMV(1, 2); break;
     case 20: JH_SPMV(2, 0); break;
     case 21: JH_SPMV(2, 1); break;
     case 22: JH_SPMV(2, 2); break;
@@ -391,6 +500,7 @@ int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x,
   }
 #undef JH_SPMV
 #undef JH_SPMV_X
+#undef JH_SPMV_PIPE
   // second stage of the fused dot: over the partials of all launches that make up this product
   if (mode && (!rng || rng->reduce)) reduce(part_off + (int)grid.x);
   return (int)grid.x;

@@ -37,6 +37,14 @@ void Pattern::build_tiles() {
   }
   ntiles = (int32_t)tile_row.size() - 1;
   if (interior_rows == 0) interior_tiles = 0;
+  tile_desc.resize((size_t)ntiles * 4);
+  for (int32_t t = 0; t < ntiles; ++t) {
+    const int32_t a = tile_row[t], b = tile_row[t + 1];
+    tile_desc[4 * t + 0] = a;
+    tile_desc[4 * t + 1] = b - a;
+    tile_desc[4 * t + 2] = rowptr[a];
+    tile_desc[4 * t + 3] = rowptr[b] - rowptr[a];
+  }
 }
 
 void Pattern::upload() {
@@ -45,6 +53,7 @@ void Pattern::upload() {
   d_col.upload(col, s);
   d_diag.upload(diag, s);
   d_tile_row.upload(tile_row, s);
+  d_tile_desc.upload(tile_desc, s);
   if (!perm.empty()) d_perm.upload(perm, s);
   if (!nz_hslot.empty()) d_nz_hslot.upload(nz_hslot, s);
   JH_HIP(hipStreamSynchronize(s));
