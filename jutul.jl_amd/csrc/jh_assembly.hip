@@ -105,10 +105,9 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
   __shared__ uint8_t rowof[TNNZ];
   const int t = xcd_tile_a(blockIdx.x, ntiles);
   if (t >= ntiles) return;
-  const int r0 = tile_row[t], r1 = tile_row[t + 1];
-  const int nrows = r1 - r0;
-  const int base = rowptr[r0];
-  const int cnt = rowptr[r1] - base;  // TPFA rows are short: cnt <= TILE_NNZ is guaranteed by the host (checked)
+  const int4 td = reinterpret_cast<const int4 *>(tile_row)[t];  // tile descriptor (Pattern::tile_desc): one load, not a chain
+  const int r0 = td.x, nrows = td.y, r1 = r0 + nrows, base = td.z;
+  const int cnt = td.w;  // TPFA rows are short: cnt <= TILE_NNZ is guaranteed by the host (checked)
   const int tid = threadIdx.x;
   constexpr int KPT = TNNZ / TILE_THREADS;  // entries per lane
   // the (col, T) stream of the lane's entries is requested first: it is in flight while the row table is built
@@ -314,7 +313,7 @@ void k_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
   int chunk = (P.ntiles + NUM_XCD - 1) / NUM_XCD;
   dim3 grid(chunk * NUM_XCD), block(TILE_THREADS);
   const double *g = L->has_gdz ? L->gnz.p : nullptr;
-#define JH_ASM_ARGS P.d_tile_row.p, P.ntiles, P.d_rowptr.p, P.d_col.p, P.d_diag.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row, (int)P.n
+#define JH_ASM_ARGS P.d_tile_desc.p, P.ntiles, P.d_rowptr.p, P.d_col.p, P.d_diag.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row, (int)P.n
   switch (L->kind) {
     case JH_LAW_POISSON: hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_POISSON>, grid, block, 0, ctx->stream, JH_ASM_ARGS); break;
     case JH_LAW_COMPRESSIBLE: hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_COMPRESSIBLE>, grid, block, 0, ctx->stream, JH_ASM_ARGS); break;
