@@ -52,7 +52,7 @@ struct jh_ilu_s {
   DevBuf<uint16_t> d_l_lev, d_u_lev;
   // 16-bit copies of the block-local metadata for the chunked apply (LDS mode: < 8192 rows per block)
   DevBuf<uint16_t> d_l_col16, d_u_col16, d_u_row16, d_rowmap16;
-  bool rowmap_local = false;  // block b's rows are the device rows [blk_ptr[b], blk_ptr[b+1]): rowmap16 = offset in the block
+  bool rowmap_local = false;  // block b's rows are the device rows [blk_ptr[b], blk_ptr[b+1]): rowmap16[device row] = ilu position inside the block
   DevBuf<int32_t> d_rowmap, d_blk_ptr, d_flev_off, d_flev_ptr, d_blev_off, d_blev_ptr, d_l_ptr, d_l_col, d_l_map, d_u_ptr,
       d_u_col, d_u_map, d_d_map, d_u_row, d_upos_of;
   DevBuf<double> l_val, u_val, dinv, xg;
@@ -609,8 +609,11 @@ __global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const d
     cb = G.sc[G.ts_slot + 1] == 0.0 ? 0.0 : G.sc[G.ts_slot] / G.sc[G.ts_slot + 1];  // omega (0/0 guard, see bicg_omega)
     ca = (rho_next / rho) * (alpha / cb);        // beta
   }
+  // the block's rows are the device rows [b0, b1): they are read coalesced in device order and dropped at their ilu position
+  // (rowmap16[dev] = position inside the block), so the vector loads do not wait for the map
   for (int t = threadIdx.x; t < nr; t += 64) {
-    const int dev = b0 + (int)F.rowmap16[b0 + t];  // the block's rows are the device rows [b0, b1)
+    const int dev = b0 + t;
+    const int pos = (int)F.rowmap16[dev];
 #pragma unroll
     for (int e = 0; e < BS; ++e) {
       const size_t o = (size_t)dev * BS + e;
@@ -625,16 +628,18 @@ __global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const d
         v = (dev < G.n_owned_rows) ? G.r[o] + ca * pa : 0.0;
         G.out[o] = v;
       }
-      xs[t * BS + e] = v;
+      xs[pos * BS + e] = v;
     }
   }
   __syncthreads();
   chunk_sweep<BS, false>(F, xs, b0, b1, 1);  // forward: level-0 rows have no L entries
   chunk_sweep<BS, true>(F, xs, b0, b1, 0);   // backward: every row is scaled by its inverted pivot
+  __syncthreads();
   for (int t = threadIdx.x; t < nr; t += 64) {
-    const int dev = b0 + (int)F.rowmap16[b0 + t];  // the block's rows are the device rows [b0, b1)
+    const int dev = b0 + t;
+    const int pos = (int)F.rowmap16[dev];
 #pragma unroll
-    for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[t * BS + e];
+    for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[pos * BS + e];
   }
   if (F.send_ptr) {  // rows that neighbouring ranks hold as ghosts go straight into the halo send buffer (no pack kernel)
     for (int j = F.send_ptr[b] + (int)threadIdx.x; j < F.send_ptr[b + 1]; j += 64) {
@@ -927,9 +932,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       M->rowmap_local = true;
       for (int64_t b = 0; b < nb; ++b)
         for (int32_t t = M->blk_ptr[b]; t < M->blk_ptr[b + 1]; ++t) {
-          const int32_t off = M->rowmap[t] - M->blk_ptr[b];
-          if (off < 0 || off >= M->blk_ptr[b + 1] - M->blk_ptr[b]) M->rowmap_local = false;
-          rm[t] = (uint16_t)off;
+          const int32_t off = M->rowmap[t] - M->blk_ptr[b];  // device row of ilu row t, relative to the block
+          if (off < 0 || off >= M->blk_ptr[b + 1] - M->blk_ptr[b]) { M->rowmap_local = false; continue; }
+          rm[M->rowmap[t]] = (uint16_t)(t - M->blk_ptr[b]);  // device row -> position inside the block
         }
       M->d_l_col16.upload(lc, s); M->d_u_col16.upload(uc, s); M->d_u_row16.upload(ur, s); M->d_rowmap16.upload(rm, s);
     }
