@@ -85,6 +85,26 @@ template <int NP> __device__ __forceinline__ Dual<NP> density(const LawPar &P, i
   return P.rho0[ph] * dexp(P.comp[ph] * (p - dconst<NP>(P.p_ref)));  // rho0*exp(c*(p-p0))
 }
 
+// flux of the scalar laws across one half-face with its derivatives w.r.t. the self / other primary variable (shared by the
+// tile kernel and its pipelined variant)
+template <int KIND>
+__device__ __forceinline__ void flux_scalar(double Us, double Uo, double T, double gz, const LawPar &par, double &q, double &dself,
+                                            double &dother) {
+  if (KIND == JH_LAW_POISSON) {  // q = -K[face]*(U_other - U_self)  (variable_poisson.jl:99,124)
+    q = -(T * (Uo - Us));
+    dself = T;
+    dother = -T;
+  } else {
+    Dual<2> ps = dvar<2>(Us, 0), po = dvar<2>(Uo, 1);
+    Dual<2> rs = density(par, 0, ps), ro = density(par, 0, po);
+    Dual<2> ravg = 0.5 * (rs + ro);             // face_average (flux.jl:372-375)
+    Dual<2> dphi = (ps - po) + gz * ravg;       // two_point_potential_drop (flux.jl:335-338)
+    Dual<2> f = (T / par.mu[0]) * (ravg * dphi);
+    q = f.v;
+    dself = f.d[0];
+    dother = f.d[1];
+  }
+}
 // ---- the kernel -------------------------------------------------------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
@@ -152,24 +172,13 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
       isdiag[kk] = true;
       continue;
     }
-    if (KIND == JH_LAW_POISSON) {
-      // q = -K[face]*(U_other - U_self)  (variable_poisson.jl:99,124); dq/dU_self = K, dq/dU_other = -K
-      const double Us = xs[own + lr];
-      const double Uo = inl ? xs[cw] : X[c];
-      qv[k] = -(T * (Uo - Us));
-      dsv[k] = T;
-      off[kk][0] = -T;
-    } else if (KIND == JH_LAW_COMPRESSIBLE) {
+    if (KIND != JH_LAW_TWOPHASE) {
       const double gz = gnz ? gnz[base + k] : 0.0;
-      Dual<2> ps = dvar<2>(xs[own + lr], 0);
-      Dual<2> po = dvar<2>(inl ? xs[cw] : X[c], 1);
-      Dual<2> rs = density(par, 0, ps), ro = density(par, 0, po);
-      Dual<2> ravg = 0.5 * (rs + ro);             // face_average (flux.jl:372-375)
-      Dual<2> dphi = (ps - po) + gz * ravg;       // two_point_potential_drop (flux.jl:335-338)
-      Dual<2> q = (T / par.mu[0]) * (ravg * dphi);
-      qv[k] = q.v;
-      dsv[k] = q.d[0];
-      off[kk][0] = q.d[1];
+      double q, ds, dother_;
+      flux_scalar<KIND>(xs[own + lr], inl ? xs[cw] : X[c], T, gz, par, q, ds, dother_);
+      qv[k] = q;
+      dsv[k] = ds;
+      off[kk][0] = dother_;
     } else {
       const double gz = gnz ? gnz[base + k] : 0.0;
       Dual<4> ps = dvar<4>(xs[(own + lr) * 2], 0), ss_w = dvar<4>(xs[(own + lr) * 2 + 1], 1);
@@ -259,6 +268,137 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
   }
 }
 
+
+// ---- software-pipelined, persistent variant for the scalar laws -------------------------------------------------------------
+// Same arithmetic and tile structure as assemble_tile_kernel; a tile is a chain of dependent latencies (descriptor ->
+// (col, T) / row data -> neighbour gather), so a workgroup walks its tiles (XCD-contiguous chunks like the SpMV) and issues
+// the first-level loads of its next tile before it computes the current one.  The diagonal slot's Tnz value IS the row's
+// accumulation coefficient and its position IS diag[row]: the entry lane that owns the slot hands both to the row lane
+// through LDS, so the row phase needs no dependent global load (and the diag array is not read at all).
+struct AsmPre {
+  int r0, nrows, base, cnt;
+  int cidx[TILE_NNZ / TILE_THREADS];
+  double Tk[TILE_NNZ / TILE_THREADS], gz[TILE_NNZ / TILE_THREADS];
+  double xrow, x0;
+  int rpv;
+};
+template <int KIND>
+__global__ __launch_bounds__(TILE_THREADS) void assemble_pipe_kernel(
+    const int32_t *__restrict__ tile_desc, int ntiles, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const double *__restrict__ Tnz, const double *__restrict__ gnz, const double *__restrict__ X, const double *__restrict__ X0,
+    double *__restrict__ nz, double *__restrict__ r, double dt, LawPar par, int reg_row) {
+  constexpr int KPT = TILE_NNZ / TILE_THREADS;
+  __shared__ double qv[TILE_NNZ];
+  __shared__ double dsv[TILE_NNZ];
+  __shared__ double xs[TILE_ROWS];
+  __shared__ double volrow[TILE_ROWS];
+  __shared__ int32_t rp[TILE_ROWS + 1];
+  __shared__ uint16_t diagk[TILE_ROWS];
+  __shared__ uint8_t rowof[TILE_NNZ];
+  const int tid = threadIdx.x;
+  const int chunk = (ntiles + NUM_XCD - 1) / NUM_XCD;
+  const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, wgs = gridDim.x / NUM_XCD;
+  auto in_range = [&](int tl) { return tl < chunk && xcd * chunk + tl < ntiles; };
+  auto issue = [&](int tl, AsmPre &P) {
+    const int4 td = reinterpret_cast<const int4 *>(tile_desc)[xcd * chunk + tl];
+    P.r0 = td.x; P.nrows = td.y; P.base = td.z; P.cnt = td.w;
+#pragma unroll
+    for (int kk = 0; kk < KPT; ++kk) {
+      const int k = tid + kk * TILE_THREADS;
+      P.cidx[kk] = (k < P.cnt) ? col[P.base + k] : 0;
+      P.Tk[kk] = (k < P.cnt) ? Tnz[P.base + k] : 0.0;
+      P.gz[kk] = (gnz && k < P.cnt) ? gnz[P.base + k] : 0.0;
+    }
+    const bool rowlane = tid < P.nrows;
+    P.xrow = rowlane ? X[P.r0 + tid] : 0.0;
+    P.x0 = rowlane ? X0[P.r0 + tid] : 0.0;
+    P.rpv = rowlane ? rowptr[P.r0 + tid] - P.base : P.cnt;
+  };
+  AsmPre cur, nxt;
+  int tl = wg;
+  bool have = in_range(tl);
+  if (have) issue(tl, cur);
+  while (have) {
+    const int tln = tl + wgs;
+    const bool have_next = in_range(tln);
+    if (have_next) issue(tln, nxt);
+    const int r0 = cur.r0, nrows = cur.nrows, r1 = r0 + nrows, base = cur.base, cnt = cur.cnt;
+    rp[tid] = cur.rpv;
+    if (tid == 0) rp[nrows] = cnt;
+    xs[tid] = cur.xrow;
+    __syncthreads();
+    if (tid < nrows)
+      for (int j = rp[tid]; j < rp[tid + 1]; ++j) rowof[j] = (uint8_t)tid;
+    __syncthreads();
+    // phase 1: one lane per CSR entry; off-diagonals stay in registers until the coalesced store of phase 3
+    double off[KPT];
+    bool isdiag[KPT];
+#pragma unroll
+    for (int kk = 0; kk < KPT; ++kk) {
+      const int k = tid + kk * TILE_THREADS;
+      isdiag[kk] = false;
+      off[kk] = 0.0;
+      if (k >= cnt) continue;
+      const int lr = rowof[k];
+      const int c = cur.cidx[kk];
+      if (c == r0 + lr) {  // diagonal slot: no flux; hand the accumulation coefficient and the slot to the row lane
+        qv[k] = 0.0;
+        dsv[k] = 0.0;
+        volrow[lr] = cur.Tk[kk];
+        diagk[lr] = (uint16_t)k;
+        isdiag[kk] = true;
+        continue;
+      }
+      const double Uo = (c >= r0 && c < r1) ? xs[c - r0] : X[c];
+      double q, ds, dother_;
+      flux_scalar<KIND>(xs[lr], Uo, cur.Tk[kk], cur.gz[kk], par, q, ds, dother_);
+      qv[k] = q;
+      dsv[k] = ds;
+      off[kk] = dother_;
+    }
+    __syncthreads();
+    // phase 2: one lane per row
+    if (tid < nrows) {
+      const int row = r0 + tid;
+      const double vol = volrow[tid], U = xs[tid];
+      double ar, ap;
+      if (KIND == JH_LAW_POISSON) {
+        if (dt > 0.0) {
+          ar = (vol * U - vol * cur.x0) / dt;
+          ap = vol / dt;
+        } else {  // stationary variant with the 1e-10*U regulariser on host cell 1 (variable_poisson.jl:101-104)
+          ar = (row == reg_row) ? 1e-10 * U : 0.0;
+          ap = (row == reg_row) ? 1e-10 : 0.0;
+        }
+      } else {
+        Dual<2> p = dvar<2>(U, 0);
+        Dual<2> M = vol * density(par, 0, p);
+        const double M0 = vol * density(par, 0, dconst<2>(cur.x0)).v;
+        Dual<2> a = ddiv(M - dconst<2>(M0), dt);
+        ar = a.v;
+        ap = a.d[0];
+      }
+      for (int j = rp[tid]; j < rp[tid + 1]; ++j) {
+        ar = ar + qv[j];
+        ap = ap + dsv[j];
+      }
+      r[row] = ar;
+      dsv[diagk[tid]] = ap;  // park the diagonal in its LDS slot for the coalesced store
+    }
+    __syncthreads();
+    // phase 3: every lane stores its entries; nzval lines leave the CU complete
+#pragma unroll
+    for (int kk = 0; kk < KPT; ++kk) {
+      const int k = tid + kk * TILE_THREADS;
+      if (k < cnt) nz[base + k] = isdiag[kk] ? dsv[k] : off[kk];
+    }
+    __syncthreads();  // LDS is reused by the next tile
+    cur = nxt;
+    tl = tln;
+    have = have_next;
+  }
+}
+
 __global__ void sources_kernel(double *r, const int32_t *cell, const double *val, int64_t n, int N) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n * N) return;
@@ -314,13 +454,24 @@ void k_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
   dim3 grid(chunk * NUM_XCD), block(TILE_THREADS);
   const double *g = L->has_gdz ? L->gnz.p : nullptr;
 #define JH_ASM_ARGS P.d_tile_desc.p, P.ntiles, P.d_rowptr.p, P.d_col.p, P.d_diag.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row, (int)P.n
+  static const bool pipe = getenv("JH_ASM_NO_PIPE") == nullptr;
+  // persistent grid of the pipelined scalar kernels: 8 workgroups per CU like the SpMV
+  dim3 pgrid((unsigned)(std::min(chunk, 256) * NUM_XCD));
+#define JH_ASM_PIPE_ARGS P.d_tile_desc.p, P.ntiles, P.d_rowptr.p, P.d_col.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row
   switch (L->kind) {
-    case JH_LAW_POISSON: hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_POISSON>, grid, block, 0, ctx->stream, JH_ASM_ARGS); break;
-    case JH_LAW_COMPRESSIBLE: hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_COMPRESSIBLE>, grid, block, 0, ctx->stream, JH_ASM_ARGS); break;
+    case JH_LAW_POISSON:
+      if (pipe) hipLaunchKernelGGL(assemble_pipe_kernel<JH_LAW_POISSON>, pgrid, block, 0, ctx->stream, JH_ASM_PIPE_ARGS);
+      else hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_POISSON>, grid, block, 0, ctx->stream, JH_ASM_ARGS);
+      break;
+    case JH_LAW_COMPRESSIBLE:
+      if (pipe) hipLaunchKernelGGL(assemble_pipe_kernel<JH_LAW_COMPRESSIBLE>, pgrid, block, 0, ctx->stream, JH_ASM_PIPE_ARGS);
+      else hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_COMPRESSIBLE>, grid, block, 0, ctx->stream, JH_ASM_ARGS);
+      break;
     case JH_LAW_TWOPHASE: hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_TWOPHASE>, grid, block, 0, ctx->stream, JH_ASM_ARGS); break;
     default: JH_THROW("unknown law kind");
   }
 #undef JH_ASM_ARGS
+#undef JH_ASM_PIPE_ARGS
   if (L->nsrc)
     hipLaunchKernelGGL(sources_kernel, dim3((unsigned)((L->nsrc * L->N + 255) / 256)), dim3(256), 0, ctx->stream, r->d.p,
                        L->src_cell.p, L->src_val.p, L->nsrc, L->N);
