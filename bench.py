@@ -272,7 +272,7 @@ def measured_traffic(kernel, cells, world):
     if world != 1 or not os.path.exists(path) or abs(cells - 10_025_988) > 0:
         return None
     names = {"ilu0_apply": ["ilu_apply_chunked_kernel<1, 1>", "ilu_apply_chunked_kernel<1, 2>"],
-             "spmv": ["spmv_pipe_kernel<1>", "spmv_pipe_kernel<2>"], "assembly": ["assemble_tile_kernel<0>"]}
+             "spmv": ["spmv_pipe_kernel<1>", "spmv_pipe_kernel<2>"], "assembly": ["assemble_pipe_kernel<0>"]}
     try:
         with open(path) as f:
             d = json.load(f)

@@ -3,7 +3,7 @@ usage: pmc_summary.py out.json FETCH=dir1/x_counter_collection.csv WRITE=dir2/x_
 import csv, collections, json, re, sys
 
 KNOWN = ["ilu_apply_chunked_kernel", "ilu_apply_blocks_pf_kernel", "ilu_apply_blocks_kernel", "ilu_factor_lds_kernel",
-         "spmv_pipe_kernel", "spmv_tile_kernel", "assemble_tile_kernel", "bicg_xr_dots_kernel", "bicg_reduce_publish_kernel", "bicg_p_kernel",
+         "spmv_pipe_kernel", "spmv_tile_kernel", "assemble_pipe_kernel", "assemble_tile_kernel", "bicg_xr_dots_kernel", "bicg_reduce_publish_kernel", "bicg_p_kernel",
          "bicg_s_kernel", "dot2_partial_kernel", "final_reduce_kernel"]
 
 
