@@ -209,6 +209,11 @@ end
 function set_halo!(disc::Ptr{Cvoid}, n_owned::Integer, neighbors::Vector{Int32}, send::Vector{Vector{Int64}}, recv::Vector{Vector{Int64}})
     sp = cumsum([0; length.(send)]); rp = cumsum([0; length.(recv)])
     @jh :jh_halo_create (Ptr{Cvoid}, Int64, Int32, Ptr{Int32}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}) disc Int64(n_owned) Int32(length(neighbors)) neighbors Int64.(sp) reduce(vcat, send; init = Int64[]) Int64.(rp) reduce(vcat, recv; init = Int64[])
+    # Optional (ranks of one node, mailboxes enabled): the push halo for the exchanges inside the Krylov loop.  All-gather
+    # (jh_halo_ipc_export handle, neighbors, length.(recv)) of every rank; per neighbour q pass its handle, the offset of this
+    # rank's segment in q's receive order and q's total receive count to jh_halo_ipc_attach; verify with jh_halo_ipc_selftest
+    # (a vector holding global cell ids); jh_halo_ipc_enable with the AND over all ranks.  The ctypes twin of this sequence is
+    # jutul.jl_amd/dd.py:setup_push_halo.
 end
 
 end # module
