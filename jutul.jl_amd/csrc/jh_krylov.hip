@@ -152,6 +152,30 @@ __global__ void bicg_p_kernel(double *p, const double *r, const double *v, const
     p[i] = r[i] + beta * pa;
   }
 }
+// start of a solve on one rank without left preconditioning: x = 0, r = p = c = b, partial sums of rho = <c,r> = ||r||^2 = <b,b>
+__global__ __launch_bounds__(256) void bicg_init_kernel(double *x, double *r, double *p, double *c, const double *b, int64_t n, double *part,
+                                                        size_t stride) {
+  __shared__ double sm[4];
+  double d = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = b[i];
+    x[i] = 0.0;
+    r[i] = v;
+    p[i] = v;
+    c[i] = v;
+    d += v * v;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+  if (lane == 0) sm[w] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double s4 = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    part[blockIdx.x] = s4;           // <c, r>
+    part[stride + blockIdx.x] = s4;  // <r, r>
+  }
+}
 inline dim3 vgrid(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 2048))); }
 }  // namespace
 
@@ -236,15 +260,23 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     K->mark(0, st);
   };
   K->cur_it = 0;
-  k_fill(st, x, n, 0.0);
-  k_copy(st, K->c.p, b_in, n);  // scratch copy of b (the ghost zeroing of the preconditioner must not touch b)
-  if (dist) halo_exchange(disc, K->c.p, P.bs);  // consistent!(b) (ext/.../krylov.jl:54)
-  if (left) prec(K->c.p, K->r.p); else k_copy(st, K->r.p, K->c.p, n);  // r0 = M^-1 b
-  k_copy(st, K->p.p, K->r.p, n);
-  k_copy(st, K->c.p, K->r.p, n);  // c = r0
-  // rho = <c,r>, ||r||^2 -> pair 0
-  k_dot2(ctx, K->c.p, K->r.p, K->r.p, K->r.p, nd, S_PAIR0);
-  comm_allreduce_dev(ctx, sc + S_PAIR0, 2, 0);
+  ensure_partials(ctx, 4096);
+  if (!dist && !left) {
+    // x = 0, r = p = c = b and the partial sums of <b,b> in one pass over b (instead of a fill, four copies and a dot)
+    dim3 g = vgrid(n);
+    hipLaunchKernelGGL(bicg_init_kernel, g, dim3(256), 0, st, x, K->r.p, K->p.p, K->c.p, b_in, n, ctx->partials.p, ctx->partial_stride);
+    k_final_reduce(ctx, (int)g.x, 2, S_PAIR0, false);
+  } else {
+    k_fill(st, x, n, 0.0);
+    k_copy(st, K->c.p, b_in, n);  // scratch copy of b (the ghost zeroing of the preconditioner must not touch b)
+    if (dist) halo_exchange(disc, K->c.p, P.bs);  // consistent!(b) (ext/.../krylov.jl:54)
+    if (left) prec(K->c.p, K->r.p); else k_copy(st, K->r.p, K->c.p, n);  // r0 = M^-1 b
+    k_copy(st, K->p.p, K->r.p, n);
+    k_copy(st, K->c.p, K->r.p, n);  // c = r0
+    // rho = <c,r>, ||r||^2 -> pair 0
+    k_dot2(ctx, K->c.p, K->r.p, K->r.p, K->r.p, nd, S_PAIR0);
+    comm_allreduce_dev(ctx, sc + S_PAIR0, 2, 0);
+  }
   double h2[2];
   read_scalars(ctx, S_PAIR0, 2, h2);
   double rho = h2[0];
@@ -259,7 +291,6 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   int status = 0;
   bool solved = rnorm <= eps_auto;
   if (rho == 0.0 && !solved) status = 2;  // "Breakdown b'c = 0"
-  ensure_partials(ctx, 4096);
   // right preconditioning: the s- and p-updates are fused into the gather phase of the ILU(0) apply
   const bool fuse = right && ilu_can_fuse_gather(M);
   const int ghost_from = dist ? (int)(nd / P.bs) : 0x7fffffff;
