@@ -50,8 +50,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     # the same side for every N keeps the scaling series one algorithm; Jutul's IterativeSolverConfig default is :right
     # (linsolve/utils.jl:25), its MPI extension hard-codes M = prec, i.e. left (ext/.../krylov.jl:60): --precond-side left
-    ap.add_argument("--profile-stride", type=int, default=8,
-                    help="time the SpMV / preconditioner launches of every n-th Krylov iteration inside the timed region")
+    ap.add_argument("--profile-stride", type=int, default=0,
+                    help="time the SpMV / preconditioner launches of every n-th Krylov iteration inside the timed region "
+                         "(0 = 8 on one GPU, 32 with several: an event pair costs ~4.5 us of stream time)")
     ap.add_argument("--precond-side", default="right", choices=["left", "right"])
     args = ap.parse_args()
     # The contract is ONE JSON line on stdout.  Libraries write there too (gloo: "[Gloo] Rank 0 is connected to ...", RCCL
@@ -179,7 +180,7 @@ def main():
     barrier()  # ranks finish their setup seconds apart
     for _ in range(args.warmup):
         step()
-    ks.profile(enable=args.profile_stride, reset=True)  # HIP-event pairs around every n-th iteration's SpMV / ILU launches
+    ks.profile(enable=args.profile_stride or (8 if world == 1 else 32), reset=True)  # HIP-event pairs around every n-th iteration's SpMV / ILU launches
     barrier()
     t0 = time.perf_counter()
     reps = [step() for _ in range(args.steps)]
