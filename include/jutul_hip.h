@@ -257,7 +257,7 @@ int32_t jh_comm_finalize(jh_context ctx);
 /* Mailbox all-reduce for the ranks of ONE node: the Krylov loop's scalar reductions (mpi_scalar_allreduce,
  * ext/.../utils.jl:232-234; 1-2 doubles, three per BiCGStab iteration) bypass ncclAllReduce and go through peer-mapped
  * uncached device memory (hipIpc): one single-wavefront kernel per reduction, summation in rank order (identical bits on
- * every rank).  Protocol: each rank calls jh_comm_ipc_export (64-byte handle of its mailbox), the host all-gathers the
+ * every rank); two slot sets alternate with the parity of a device-resident count of EXECUTED reductions.  Protocol: each rank calls jh_comm_ipc_export (64-byte handle of its mailbox), the host all-gathers the
  * handles (MPI.Allgather / torch.distributed), each rank calls jh_comm_ipc_attach (maps the peers and self-tests 64
  * reductions with known answers, time-out guarded: *ok = 0 on any failure), the host ANDs the *ok of all ranks and calls
  * jh_comm_ipc_enable.  Without enable, ncclAllReduce is used.  jh_comm_init_ipc_only creates a communicator without RCCL
@@ -265,6 +265,18 @@ int32_t jh_comm_finalize(jh_context ctx);
 /* Teardown: peers write into and poll each other's mailboxes / landing buffers, so the host must synchronise the ranks
  * (barrier) after the last solve and before any rank calls jh_comm_finalize / jh_tpfa_destroy. */
 int32_t jh_comm_init_ipc_only(jh_context ctx, int32_t nranks, int32_t rank);
+/* What carries this rank's data right now, for the host to report and check (simulate_parray builds all ranks itself,
+ * ext/JutulPartitionedArraysExt/interface.jl:2-97; a host that launched N processes verifies that N ranks run).
+ * out8: [0] ranks of the communicator (1 without one), [1] this rank, [2] ranks RCCL counts in its communicator
+ * (ncclCommCount; 0 = no RCCL communicator), [3] 1 = scalar all-reduces through the mailboxes, [4] 1 = ghost exchanges through
+ * the host callback, [5] 1 = in-process backend, [6] waits that timed out so far, [7] time limit of a wait in seconds.
+ * Waits inside the mailbox all-reduce / push halo are time-limited (JH_COMM_TIMEOUT_S, default 30; 0 = unbounded): when a
+ * peer never arrives, the running solve fails with a jh_last_error message naming this rank, the missing peer and the
+ * epoch, instead of hanging every rank of the node. */
+int32_t jh_comm_info(jh_context ctx, int64_t *out8);
+/* out6: [0] 1 = the ghost exchanges of the Krylov loop are push halos, [1] 1 = receives land directly in the ghost rows,
+ * [2] cells sent, [3] cells received, [4] neighbour ranks, [5] owned cells */
+int32_t jh_halo_info(jh_tpfa d, int64_t *out6);
 /* Host-language halo backend: instead of ncclSend/ncclRecv the library stages the packed send buffer to the host and calls
  * fn(user, send, n_send, recv, n_recv, block_n), which must fill recv (both buffers hold block_n doubles per cell, the
  * neighbours' segments in the order of jh_halo_create) and return 0 -- e.g. MPI.Isend/Irecv from Julia, or gloo.  Used

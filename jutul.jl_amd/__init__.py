@@ -143,6 +143,13 @@ class HIPContext(_Handle):
     def comm_finalize(self):
         check(_L().jh_comm_finalize(self.h))
 
+    def comm_info(self):
+        """What carries this rank's data: dict(nranks, rank, rccl_ranks, mailbox, host_callback, local, timeouts, timeout_s)."""
+        o = np.zeros(8, dtype=np.int64)
+        check(_L().jh_comm_info(self.h, pi(o)))
+        return dict(nranks=int(o[0]), rank=int(o[1]), rccl_ranks=int(o[2]), mailbox=bool(o[3]), host_callback=bool(o[4]),
+                    local=bool(o[5]), timeouts=int(o[6]), timeout_s=int(o[7]))
+
     def allreduce(self, values, op="sum"):
         v = f64(np.atleast_1d(values)).copy()
         check(_L().jh_allreduce(self.h, pf(v), v.size, 1 if op == "max" else 0))
@@ -255,6 +262,11 @@ class TwoPointPotentialFlowHardCoded(_Handle):
 
     def halo_ipc_enable(self, enable=True):
         check(_L().jh_halo_ipc_enable(self.h, 1 if enable else 0))
+
+    def halo_info(self):
+        o = np.zeros(6, dtype=np.int64)
+        check(_L().jh_halo_info(self.h, pi(o)))
+        return dict(push=bool(o[0]), direct_recv=bool(o[1]), n_send=int(o[2]), n_recv=int(o[3]), n_nbr=int(o[4]), n_owned=int(o[5]))
 
     def set_halo(self, n_owned, nbr_ranks, send_lists, recv_lists):
         """Halo plan: per neighbour rank the local owned cells to send / ghost cells to receive (1-based)."""
@@ -697,8 +709,49 @@ class Simulator:
         self.tol = tolerance
         self.max_it, self.min_it, self.max_cuts = max_nonlinear_iterations, min_nonlinear_iterations, max_timestep_cuts
 
+    def _needs_general_path(self):
+        """jh_newton_step is the fast path for the reference's defaults (BiCGStab, no scaling, base tolerances).  Every other
+        GenericKrylov / IterativeSolverConfig option linear_solve! honours (krylov.jl:71-182) goes through linear_solve()."""
+        ks, cfg = self.linear_solver, self.linear_solver.config
+        return (ks.solver != "bicgstab" or ks.scaling != "none" or cfg.true_residual
+                or cfg.nonlinear_relative_tolerance is not None)
+
+    def _perform_step_general(self, dt, iteration, solve=True):
+        """perform_step! (simulator.jl:392-455) from the separate entry points: same sequence as jh_newton_step with the
+        linear solve done by linear_solve() (GMRES, :diagonal / :dt scaling, true_residual, Newton-history relaxed tolerance)."""
+        law, sys_, ctx = self.law, self.lsys, self.disc.ctx
+        dist = ctx.comm_size > 1 and self.disc.n_owned < self.disc.nc
+        rep = NewtonReport()
+        ctx.timer_start()
+        if dist:
+            law.synchronize_ghosts()  # parray_synchronize_primary_variables (interface.jl:189-220)
+        law.update_equation_and_linearized_system(dt, sys_.jac, sys_.r)
+        if dist:
+            check(_L().jh_unit_diagonalize(sys_.jac.h, sys_.r.h, self.disc.n_owned))  # post_update_linearized_system!
+        rep.assembly_ms = ctx.timer_stop_ms()
+        err = law.convergence_criterion(sys_.r, self.disc.n_owned)
+        if ctx.comm_size > 1:
+            err = ctx.allreduce(err, "max")
+        for e in range(min(2, law.N)):
+            rep.error[e] = err[e]
+        rep.converged = 1 if all(e < self.tol for e in err) else 0
+        force = -1 if not solve else (1 if iteration <= self.min_it else 0)
+        if force < 0 or (rep.converged and force == 0):
+            return rep
+        out = linear_solve(sys_, self.linear_solver, dt=dt, subiteration=iteration)
+        rep.precond_ms, rep.linear_solve_ms = out["prepare"] * 1e3, out["time"] * 1e3
+        rep.linear_iterations, rep.linear_status = out["iterations"], out["status"]
+        rep.lin_res0, rep.lin_res = out["residuals"][0], out["residuals"][-1]
+        ctx.timer_start()
+        law.update_primary_variables(sys_.dx)
+        rep.update_ms = ctx.timer_stop_ms()
+        return rep
+
     def perform_step(self, dt, iteration, solve=True):
-        """One Newton iteration through the fused C entry point jh_newton_step."""
+        """One Newton iteration: through the fused C entry point jh_newton_step for the default solver options, through the
+        separate entry points otherwise (no option is silently dropped)."""
+        if self._needs_general_path():
+            return self._perform_step_general(dt, iteration, solve)
         ks = self.linear_solver
         prec = ks.preconditioner
         if prec is not None and prec.A is not self.lsys.jac:

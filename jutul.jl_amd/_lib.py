@@ -103,6 +103,8 @@ SIGNATURES = {
     "jh_comm_finalize": [H],
     "jh_comm_init_ipc_only": [H, C.c_int32, C.c_int32],
     "jh_comm_set_halo_callback": [H, C.c_void_p, C.c_void_p],
+    "jh_comm_info": [H, I64P],
+    "jh_halo_info": [H, I64P],
     "jh_comm_ipc_export": [H, C.c_char_p],
     "jh_comm_ipc_attach": [H, C.c_char_p, C.POINTER(C.c_int32)],
     "jh_comm_ipc_enable": [H, C.c_int32],

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -23,6 +24,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -46,6 +48,7 @@ static Rccl &rccl() {
   JH_SYM(GetUniqueId, "ncclGetUniqueId");
   JH_SYM(CommInitRank, "ncclCommInitRank");
   JH_SYM(CommDestroy, "ncclCommDestroy");
+  JH_SYM(CommCount, "ncclCommCount");
   JH_SYM(AllReduce, "ncclAllReduce");
   JH_SYM(Send, "ncclSend");
   JH_SYM(Recv, "ncclRecv");
@@ -90,13 +93,15 @@ struct Comm {
   Mailbox *mail_self = nullptr;
   std::vector<Mailbox *> mail_peer;  // [nranks], mail_peer[rank] == mail_self
   DevBuf<Mailbox *> d_mail_peer;
-  uint64_t mail_epoch = 0;
+  DevBuf<unsigned long long> mail_ctr;  // [0] all-reduces this rank has executed (the epoch lives on the device, see MailArgs)
+  uint64_t wait_ticks = 3000000000ull;  // time limit of the in-solve waits in 100 MHz ticks (JH_COMM_TIMEOUT_S, default 30 s)
   bool mail_attached = false, mail_enabled = false;
   // host-language halo backend (jh_comm_set_halo_callback): the packed send buffer is staged to the host and exchanged there
   jh_halo_callback halo_cb = nullptr;
   void *halo_cb_user = nullptr;
   std::vector<double> cb_send, cb_recv;
-  volatile unsigned *mail_err = nullptr;  // pinned + mapped: != 0 after a timed-out wait
+  volatile MailErr *mail_err = nullptr;  // pinned + mapped: code != 0 after a timed-out wait
+  int rccl_ranks = 0;                    // ncclCommCount of the RCCL communicator (0: none)
 };
 
 int comm_size(jh_context ctx) { return ctx->comm ? ctx->comm->nranks : 1; }
@@ -110,23 +115,37 @@ static MailArgs next_mail_args(jh_context ctx, uint64_t timeout_ticks) {
   Comm &c = *ctx->comm;
   MailArgs A;
   A.self = c.mail_self; A.peers = c.d_mail_peer.p; A.rank = c.rank; A.nranks = c.nranks;
-  A.epoch = ++c.mail_epoch; A.timeout_ticks = timeout_ticks; A.err = const_cast<unsigned *>(c.mail_err);
+  A.ctr = c.mail_ctr.p; A.timeout_ticks = timeout_ticks; A.err = const_cast<MailErr *>(c.mail_err);
   return A;
 }
 bool comm_mail_args(jh_context ctx, int n, MailArgs *out) {
   if (!ctx->comm || ctx->comm->nranks == 1 || !ctx->comm->mail_enabled || n > MAIL_MAX_VALUES) return false;
-  *out = next_mail_args(ctx, 0);
+  *out = next_mail_args(ctx, ctx->comm->wait_ticks);
   return true;
 }
 // timeout_ticks: 100 MHz ticks, 0 = wait like a collective
-static void mailbox_allreduce(jh_context ctx, double *p, int n, int op, uint64_t timeout_ticks = 0) {
+static void mailbox_allreduce(jh_context ctx, double *p, int n, int op, uint64_t timeout_ticks) {
   mailbox_allreduce_launch(ctx->stream, next_mail_args(ctx, timeout_ticks), p, n, op);
 }
+// A wait inside a mailbox all-reduce / push halo ran out of time on this rank: fail the running call with the culprit's
+// name instead of returning numbers computed from a missing contribution.  Sticky: the communicator is unusable afterwards.
+void comm_check_errors(jh_context ctx) {
+  if (!ctx->comm || !ctx->comm->mail_err) return;
+  const volatile MailErr *e = ctx->comm->mail_err;
+  if (e->code == 0) return;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  JH_THROW("rank " + std::to_string(ctx->comm->rank) + " of " + std::to_string(ctx->comm->nranks) + ": " +
+           (e->code == 1 ? "mailbox all-reduce" : "push halo exchange") + " timed out after " +
+           std::to_string(ctx->comm->wait_ticks / 100000000ull) + " s waiting for rank " + std::to_string(e->peer) + " (epoch " +
+           std::to_string(e->epoch) + ", " + std::to_string(e->count) + " timed-out waits so far); the peer process died, hung or "
+           "runs a different sequence of collectives.  Set JH_BENCH_NO_MAILBOX=1 / JH_BENCH_NO_PUSH=1 to fall back to RCCL.");
+}
+int comm_timeouts(jh_context ctx) { return (ctx->comm && ctx->comm->mail_err) ? (int)ctx->comm->mail_err->count : 0; }
 
 // in-stream all-reduce of n doubles living in device memory; no-op without a communicator
 void comm_allreduce_dev(jh_context ctx, double *p, int n, int op) {
   if (!ctx->comm || ctx->comm->nranks == 1) return;
-  if (ctx->comm->mail_enabled && n <= MAIL_MAX_VALUES) { mailbox_allreduce(ctx, p, n, op); return; }
+  if (ctx->comm->mail_enabled && n <= MAIL_MAX_VALUES) { mailbox_allreduce(ctx, p, n, op, ctx->comm->wait_ticks); return; }
   if (ctx->comm->local) {
     LocalGroup &G = *ctx->comm->local;
     const int r = ctx->comm->rank;
@@ -152,7 +171,7 @@ void comm_allreduce_dev(jh_context ctx, double *p, int n, int op) {
 
 void halo_push_pack_launch(hipStream_t s, double *const *dst, const double *v, const int32_t *idx, int64_t n, int bs);
 void halo_push_finish_launch(hipStream_t s, Mailbox *self, Mailbox *const *peers, const int32_t *nbr, int n_nbr, int rank, uint64_t epoch,
-                             const double *landing, double *v, const int32_t *recv_idx, int64_t n_recv, int bs, unsigned *err,
+                             const double *landing, double *v, const int32_t *recv_idx, int64_t n_recv, int bs, MailErr *err,
                              uint64_t timeout_ticks);
 void halo_pack_launch(hipStream_t s, double *buf, const double *v, const int32_t *idx, int64_t n, int bs);
 void halo_unpack_launch(hipStream_t s, double *v, const double *buf, const int32_t *idx, int64_t n, int bs);
@@ -160,14 +179,15 @@ void halo_unpack_launch(hipStream_t s, double *v, const double *buf, const int32
 // consistent!(v): pack owned values -> grouped ncclSend/ncclRecv per neighbour -> unpack into ghost rows, all on stream s
 // Push exchange (see jh_halo.hip).  packed: the producer of v has already stored the boundary rows into the neighbours' landing
 // buffers of parity (push_epoch + 1) & 1 (halo_push_targets).
-static void halo_push(jh_tpfa d, double *v, int bs, hipStream_t s, bool packed, uint64_t timeout_ticks = 0) {
+static void halo_push(jh_tpfa d, double *v, int bs, hipStream_t s, bool packed, uint64_t timeout_ticks = ~0ull) {
   auto &H = d->halo;
   Comm &c = *d->ctx->comm;
+  if (timeout_ticks == ~0ull) timeout_ticks = c.wait_ticks;
   const uint64_t e = ++H.push_epoch;
   const int par = (int)(e & 1);
   if (H.n_send && !packed) halo_push_pack_launch(s, H.d_push_dst[par].p, v, H.d_send_idx.p, H.n_send, bs);
   halo_push_finish_launch(s, c.mail_self, c.d_mail_peer.p, H.d_nbr.p, (int)H.nbr.size(), c.rank, e, H.landing + par * H.landing_stride, v,
-                          H.d_recv_idx.p, H.n_recv, bs, const_cast<unsigned *>(c.mail_err), timeout_ticks);
+                          H.d_recv_idx.p, H.n_recv, bs, const_cast<MailErr *>(c.mail_err), timeout_ticks);
 }
 // where the producer of the NEXT pushed vector must store send slot k (N doubles each); nullptr when pushing is off
 double *const *halo_push_targets(jh_tpfa d) {
@@ -285,6 +305,10 @@ extern "C" int32_t jh_comm_init(jh_context ctx, int32_t nranks, int32_t rank, co
     ncclUniqueId id;
     std::memcpy(&id, id128, 128);
     JH_NCCL(rccl().CommInitRank(&c->comm, nranks, id, rank));
+    int cnt = 0;
+    JH_NCCL(rccl().CommCount(c->comm, &cnt));
+    if (cnt != nranks) JH_THROW("RCCL communicator has " + std::to_string(cnt) + " ranks, " + std::to_string(nranks) + " were requested");
+    c->rccl_ranks = cnt;
     ctx->comm = c.release();
   });
 }
@@ -313,6 +337,39 @@ extern "C" int32_t jh_comm_init_local(jh_context ctx, void *group, int32_t rank)
     c->nranks = G->n;
     c->rank = rank;
     ctx->comm = c.release();
+  });
+}
+
+// a failed set-up self-test must leave the fallback (RCCL) path usable: forget the recorded time-out
+static void clear_mail_error(Comm &c) {
+  std::memset((void *)c.mail_err, 0, sizeof(MailErr));
+  const unsigned long long zero = 0;
+  (void)hipMemcpy(&c.mail_self->abort, &zero, sizeof(zero), hipMemcpyHostToDevice);
+}
+
+// What actually carries the data of this rank -- for the host to report and to check (bench.py fails loudly when the ranks it
+// asked for are not the ranks that run).  out8: [0] ranks of the communicator, [1] this rank, [2] ranks RCCL counts in its
+// communicator (ncclCommCount; 0 = no RCCL communicator), [3] 1 = scalar all-reduces through the mailboxes, [4] 1 = ghost
+// exchanges through the host callback, [5] 1 = in-process backend, [6] timed-out waits so far, [7] wait limit in seconds.
+extern "C" int32_t jh_comm_info(jh_context ctx, int64_t *out8) {
+  return guard([&] {
+    if (!ctx || !out8) JH_THROW("null argument");
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    out8[0] = 1;
+    if (!ctx->comm) return;
+    Comm &c = *ctx->comm;
+    out8[0] = c.nranks; out8[1] = c.rank; out8[2] = c.rccl_ranks; out8[3] = c.mail_enabled ? 1 : 0;
+    out8[4] = c.halo_cb ? 1 : 0; out8[5] = c.local ? 1 : 0; out8[6] = comm_timeouts(ctx); out8[7] = (int64_t)(c.wait_ticks / 100000000ull);
+  });
+}
+// [0] 1 = the Krylov-loop ghost exchange is the push halo, [1] 1 = receives land directly in the ghost rows, [2] cells sent,
+// [3] cells received, [4] neighbour ranks, [5] owned cells
+extern "C" int32_t jh_halo_info(jh_tpfa d, int64_t *out6) {
+  return guard([&] {
+    if (!d || !out6) JH_THROW("null argument");
+    const auto &H = d->halo;
+    out6[0] = H.push_enabled ? 1 : 0; out6[1] = H.direct_recv ? 1 : 0; out6[2] = H.n_send; out6[3] = H.n_recv;
+    out6[4] = (int64_t)H.nbr.size(); out6[5] = H.active ? H.n_owned : d->nc;
   });
 }
 
@@ -350,8 +407,11 @@ extern "C" int32_t jh_comm_ipc_export(jh_context ctx, char *handle64) {
       // uncached (fine-grained) device memory: peer stores over xGMI become visible without cache maintenance
       JH_HIP(hipExtMallocWithFlags((void **)&c.mail_self, mailbox_bytes(), hipDeviceMallocUncached));
       JH_HIP(hipMemset(c.mail_self, 0, mailbox_bytes()));
-      JH_HIP(hipHostMalloc((void **)&c.mail_err, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
-      *c.mail_err = 0;
+      JH_HIP(hipHostMalloc((void **)&c.mail_err, sizeof(MailErr), hipHostMallocMapped | hipHostMallocCoherent));
+      std::memset((void *)c.mail_err, 0, sizeof(MailErr));
+      c.mail_ctr.alloc(1);
+      JH_HIP(hipMemset(c.mail_ctr.p, 0, sizeof(unsigned long long)));
+      if (const char *e = getenv("JH_COMM_TIMEOUT_S")) c.wait_ticks = (uint64_t)(std::max(0.0, atof(e)) * 1e8);  // 0 = unbounded
     }
     hipIpcMemHandle_t h;
     JH_HIP(hipIpcGetMemHandle(&h, c.mail_self));
@@ -400,10 +460,10 @@ extern "C" int32_t jh_comm_ipc_attach(jh_context ctx, const char *handles, int32
       mailbox_allreduce(ctx, dev, n, op, 500000000ull);  // 5 s
       JH_HIP(hipMemcpyAsync(got, dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
       JH_HIP(hipStreamSynchronize(ctx->stream));
-      if (*c.mail_err) good = false;
+      if (c.mail_err->code) good = false;
       for (int i = 0; i < n; ++i) good = good && got[i] == want[i];
     }
-    if (!good) *c.mail_err = 0;  // the fallback path must stay usable
+    if (!good) clear_mail_error(c);  // the fallback path must stay usable
     *ok = good ? 1 : 0;
   });
 }
@@ -489,9 +549,9 @@ extern "C" int32_t jh_halo_ipc_selftest(jh_tpfa d, jh_vec v, const double *expec
       JH_HIP(hipMemcpyAsync(got.data(), H.d_recv_buf.p, got.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     }
     JH_HIP(hipStreamSynchronize(s));
-    bool good = *c.mail_err == 0;
+    bool good = c.mail_err->code == 0;
     for (size_t i = 0; i < got.size(); ++i) good = good && got[i] == expected_ghosts[i];
-    if (!good) *c.mail_err = 0;
+    if (!good) clear_mail_error(c);
     *ok = good ? 1 : 0;
   });
 }
@@ -531,6 +591,7 @@ extern "C" int32_t jh_allreduce(jh_context ctx, double *values, int32_t n, int32
     comm_allreduce_dev(ctx, dev, n, op);
     JH_HIP(hipMemcpyAsync(values, dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
     JH_HIP(hipStreamSynchronize(ctx->stream));
+    comm_check_errors(ctx);
   });
 }
 
@@ -554,11 +615,15 @@ extern "C" int32_t jh_halo_create(jh_tpfa d, int64_t n_owned, int32_t n_nbr, con
       int64_t c = send_cells[i] - 1;
       if (c < 0 || c >= n_owned) JH_THROW("send cell is not an owned cell");
       si[i] = P.iperm.empty() ? (int32_t)c : P.iperm[c];
+      // dots, norms and unit_diagonalize! take the owned cells to be the device rows [0, n_owned): true only if the
+      // discretisation was created with the same n_owned (jh_tpfa_create keeps the ghosts as the last device rows)
+      if (si[i] >= n_owned) JH_THROW("halo plan and discretisation disagree on n_owned: an owned cell is stored behind the owned device rows (pass the same n_owned to jh_tpfa_create)");
     }
     for (int64_t i = 0; i < H.n_recv; ++i) {
       int64_t c = recv_cells[i] - 1;
       if (c < n_owned || c >= d->nc) JH_THROW("recv cell is not a ghost cell");
       ri[i] = P.iperm.empty() ? (int32_t)c : P.iperm[c];
+      if (ri[i] < n_owned) JH_THROW("halo plan and discretisation disagree on n_owned: a ghost cell is stored among the owned device rows (pass the same n_owned to jh_tpfa_create)");
     }
     // ghosts grouped by owner (dd.local_subdomain(ghost_order="owner")): every neighbour's receive list is a run of
     // consecutive device rows and the unpack kernel is not needed

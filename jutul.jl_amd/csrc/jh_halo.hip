@@ -43,21 +43,14 @@ __global__ void halo_push_pack_kernel(double *const *dst, const double *v, const
 }
 __global__ __launch_bounds__(256) void halo_push_finish_kernel(Mailbox *self, Mailbox *const *peers, const int32_t *nbr, int n_nbr,
                                                                int rank, unsigned long long epoch, const double *landing, double *v,
-                                                               const int32_t *recv_idx, int64_t n_recv, int bs, unsigned *err,
+                                                               const int32_t *recv_idx, int64_t n_recv, int bs, MailErr *err,
                                                                unsigned long long timeout_ticks) {
   const int par = (int)(epoch & 1ull);
   if (threadIdx.x < n_nbr) {
     const int q = nbr[threadIdx.x];
     if (blockIdx.x == 0)  // my rows for q are in place (previous kernel on this stream): tell q
       __hip_atomic_store(&peers[q]->hflag[par][rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(&self->hflag[par][q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-      if (timeout_ticks && wall_clock64() - t0 > timeout_ticks) {
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
+    if (!mailbox_wait(&self->hflag[par][q], epoch, timeout_ticks, self) && blockIdx.x == 0) mailbox_wait_failed(self, err, 2ull, q, epoch);
   }
   __syncthreads();
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_recv * bs; i += (int64_t)gridDim.x * blockDim.x) {
@@ -71,7 +64,7 @@ void halo_push_pack_launch(hipStream_t s, double *const *dst, const double *v, c
   hipLaunchKernelGGL(halo_push_pack_kernel, dim3(g), dim3(256), 0, s, dst, v, idx, n, bs);
 }
 void halo_push_finish_launch(hipStream_t s, Mailbox *self, Mailbox *const *peers, const int32_t *nbr, int n_nbr, int rank, uint64_t epoch,
-                             const double *landing, double *v, const int32_t *recv_idx, int64_t n_recv, int bs, unsigned *err,
+                             const double *landing, double *v, const int32_t *recv_idx, int64_t n_recv, int bs, MailErr *err,
                              uint64_t timeout_ticks) {
   int g = (int)std::max<int64_t>(1, std::min<int64_t>((n_recv * bs + 2047) / 2048, 16));
   hipLaunchKernelGGL(halo_push_finish_kernel, dim3(g), dim3(256), 0, s, self, peers, nbr, n_nbr, rank, (unsigned long long)epoch,

@@ -748,6 +748,8 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     if (!A || !out) JH_THROW("null argument");
     const Pattern &P = *A->pat;
     const int64_t n = P.n;
+    for (int64_t i = 0; i < n; ++i)
+      if (P.diag[i] < 0) JH_THROW("Diagonal must be present in sparsity pattern.");
     auto M = std::make_unique<jh_ilu_s>();
     M->ctx = A->ctx; M->A = A; M->pat = A->pat; M->bs = P.bs; M->n = n;
     JH_HIP(hipSetDevice(M->ctx->device));

@@ -84,14 +84,24 @@ struct Mailbox {
   double val[2][MAIL_R][MAIL_V];
   unsigned long long flag[2][MAIL_R];
   unsigned long long hflag[2][MAIL_R];  // push halo: epoch of the last exchange whose data rank r has delivered here
+  unsigned long long abort;             // != 0 once a wait of THIS rank has timed out: its later waits give up at once
+};
+// What a timed-out wait leaves behind for the host (pinned, host-coherent memory): code 1 = scalar all-reduce, 2 = push halo;
+// peer = the rank whose flag never arrived; epoch = the exchange that was waited for.  code is written last.
+struct MailErr {
+  unsigned long long code, peer, epoch, count;
 };
 // everything a kernel needs to all-reduce a few scalars through the mailboxes; self == nullptr: no all-reduce requested
 struct MailArgs {
   Mailbox *self = nullptr;
   Mailbox *const *peers = nullptr;
   int rank = 0, nranks = 1;
-  unsigned long long epoch = 0, timeout_ticks = 0;  // timeout in 100 MHz ticks, 0 = wait like a collective
-  unsigned *err = nullptr;
+  // Epoch = 1 + the number of all-reduces this rank has EXECUTED, kept on the device: a launch that returns early on the
+  // solver's done flag consumes no epoch, so consecutive executed all-reduces always alternate slot parity (a host-side
+  // counter would skip the epochs of the speculative iteration and reuse the parity of the last executed one).
+  unsigned long long *ctr = nullptr;
+  unsigned long long timeout_ticks = 0;  // 100 MHz ticks, 0 = wait like a collective
+  MailErr *err = nullptr;
 };
 
 }  // namespace jh
@@ -318,22 +328,42 @@ __device__ __forceinline__ void publish_record(double *sc, int pair_slot, double
 // stores its contribution into every rank's mailbox (xGMI peer stores, system-scope release on the epoch flag), waits
 // until all ranks have written into its own, and sums in rank order -- identical bits everywhere.  Two slot sets alternate
 // with the epoch parity: a rank cannot finish epoch e+1 before everybody has finished reading epoch e.
+// A wait that ran out of time: tell the host who was missing (it turns that into a jh_last_error failure, comm_check_errors)
+// and make every later wait of this rank give up at once, so that the kernels already enqueued drain instead of each
+// sitting out its own time limit.
+__device__ __forceinline__ void mailbox_wait_failed(Mailbox *self, MailErr *err, unsigned long long code, int peer, unsigned long long epoch) {
+  if (__hip_atomic_load(&self->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {  // keep the first culprit
+    __hip_atomic_store(&err->peer, (unsigned long long)peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&err->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&err->code, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __hip_atomic_fetch_add(&err->count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&self->abort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// spin until *flag >= epoch; false when the time limit ran out (or an earlier wait of this rank already had)
+__device__ __forceinline__ bool mailbox_wait(const unsigned long long *flag, unsigned long long epoch, unsigned long long timeout_ticks,
+                                             Mailbox *self) {
+  const unsigned long long t0 = wall_clock64();  // constant 100 MHz counter
+  unsigned spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+    if (timeout_ticks) {
+      if (wall_clock64() - t0 > timeout_ticks) return false;
+      if ((++spins & 63u) == 0 && __hip_atomic_load(&self->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return true;
+}
 __device__ __forceinline__ void mailbox_allreduce_body(const MailArgs &A, double *p, int n, int op) {
-  const int lane = threadIdx.x, par = (int)(A.epoch & 1ull);
+  const unsigned long long epoch = *A.ctr + 1ull;  // read by every thread before thread 0 advances it at the end
+  const int lane = threadIdx.x, par = (int)(epoch & 1ull);
   if (lane < A.nranks) {
     Mailbox *dst = A.peers[lane];
     for (int i = 0; i < n; ++i) __hip_atomic_store(&dst->val[par][A.rank][i], p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&dst->flag[par][A.rank], A.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const unsigned long long t0 = wall_clock64();  // constant 100 MHz counter
-    while (__hip_atomic_load(&A.self->flag[par][lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.epoch) {
-      // only the attach-time self-test runs with a time limit (a missing peer is then reported, not waited for); inside a
-      // solve the wait is unbounded like any collective: ranks may legitimately enter it seconds apart
-      if (A.timeout_ticks && wall_clock64() - t0 > A.timeout_ticks) {
-        __hip_atomic_store(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
+    __hip_atomic_store(&dst->flag[par][A.rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // Inside a solve the limit is generous (seconds: ranks may legitimately enter a reduction far apart); a rank that never
+    // arrives is reported through A.err instead of hanging every rank of the node until the job is killed.
+    if (!mailbox_wait(&A.self->flag[par][lane], epoch, A.timeout_ticks, A.self)) mailbox_wait_failed(A.self, A.err, 1ull, lane, epoch);
   }
   __syncthreads();
   if (lane < n) {
@@ -345,6 +375,7 @@ __device__ __forceinline__ void mailbox_allreduce_body(const MailArgs &A, double
     p[lane] = acc;
   }
   __syncthreads();
+  if (threadIdx.x == 0) *A.ctr = epoch;
 }
 
 // Second stage of the deterministic two-stage reductions: ONE 1024-thread block sums (or maxes) nparts partials of

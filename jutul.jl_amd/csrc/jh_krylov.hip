@@ -22,6 +22,8 @@ void halo_exchange_begin(jh_tpfa d, double *v, int bs, bool packed = false);
 void halo_exchange_end(jh_tpfa d);
 void ilu_factor(jh_ilu M);
 void halo_exchange(jh_tpfa d, double *v, int bs, bool packed = false, bool push = false);
+void comm_check_errors(jh_context ctx);
+int comm_size(jh_context ctx);
 }  // namespace jh
 using namespace jh;
 
@@ -205,6 +207,7 @@ static void wait_published(jh_context ctx, int rec, double seq, double *out) {
   for (uint64_t spin = 1;; ++spin) {
     if (r[15] == seq) break;
     if ((spin & 0x3fff) == 0) {  // the stream must still be busy, otherwise the record was lost (kernel fault)
+      comm_check_errors(ctx);    // a peer that never arrived in a mailbox all-reduce / push halo (time-limited waits)
       hipError_t q = hipStreamQuery(ctx->stream);
       if (q == hipSuccess) {
         if (r[15] == seq) break;
@@ -261,7 +264,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   };
   K->cur_it = 0;
   ensure_partials(ctx, 4096);
-  if (!dist && !left) {
+  if (!dist && !left && comm_size(ctx) == 1) {  // (several ranks without a halo plan still all-reduce every dot)
     // x = 0, r = p = c = b and the partial sums of <b,b> in one pass over b (instead of a fill, four copies and a dot)
     dim3 g = vgrid(n);
     hipLaunchKernelGGL(bicg_init_kernel, g, dim3(256), 0, st, x, K->r.p, K->p.p, K->c.p, b_in, n, ctx->partials.p, ctx->partial_stride);
@@ -436,6 +439,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   *iters_out = it;
   K->collect(it);
   JH_HIP(hipGetLastError());
+  comm_check_errors(ctx);
   return status;
 }
 

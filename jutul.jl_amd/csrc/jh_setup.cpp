@@ -222,9 +222,9 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
     if (nc < 1 || nf < 0) JH_THROW("bad sizes");
     // device indices are 32-bit (4-byte column ids are a third of the SpMV's index+value stream): one GPU holds the
     // pattern of up to 2^31 - 1 scalar non-zeros (~400M cells on a tet grid), beyond that the grid must be partitioned
+    if (block_n < 1 || block_n > 3) JH_THROW("block_n must be 1..3");
     if (nc + 2 * nf > (int64_t)INT32_MAX / ((int64_t)block_n * block_n))
       JH_THROW("discretisation too large for 32-bit device indices: partition it across more ranks");
-    if (block_n < 1 || block_n > 3) JH_THROW("block_n must be 1..3");
     if (nc > 2000000000LL || 2 * nf + nc > 2000000000LL) JH_THROW("problem too large for 32-bit device indices");
     JH_HIP(hipSetDevice(ctx->device));
     auto d = std::make_unique<jh_tpfa_s>();

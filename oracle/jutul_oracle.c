@@ -624,46 +624,54 @@ static int blk_nonzero(int N, const double *A) {
  * (par_ilu0.jl) one such object per block with a sorted `active` row set. */
 typedef struct {
   I64 n; int bs;
+  /* strict-L / strict-U CSR over the ACTIVE rows only: row pointers are indexed by the local index a (active[a] = global
+   * row), 1-based entry positions; columns stay global.  (The reference stores n + 1 row pointers per block and scans all
+   * n rows with `insorted`, ilu0.jl:13-54; same entries, but a set-up of O(rows of the block) instead of O(n) per block.) */
   I64 *l_rowptr, *l_col, *l_map; double *l_val;
   I64 *u_rowptr, *u_col, *u_map; double *u_val;
   I64 nact; I64 *active; /* sorted global rows; all rows when nact == n */
   I64 *d_map; double *d_val; /* per active row */
-  I64 *act_index;            /* global row -> local index in active (0 if not active), for D lookups */
+  const I64 *loc;            /* shared by all blocks: global row -> local index + 1 inside its own block */
+  const I64 *owner;          /* shared: global row -> block id + 1 */
+  I64 id;                    /* this block's id + 1 */
 } jo_ilu;
+#define JO_ACTIVE(F, row) ((F)->owner[(row) - 1] == (F)->id)
 
 /* fixed_block (ilu0.jl:13-54): keep entries with keep(col,row,lower) && col in active, rows in active */
 static void fixed_block(const jo_ilu *F, const I64 *rowptr, const I64 *colidx, int lower, I64 **o_rowptr,
                         I64 **o_col, I64 **o_map) {
-  I64 n = F->n;
-  I64 *rp = (I64 *)malloc((size_t)(n + 1) * sizeof(I64));
+  I64 na = F->nact;
+  I64 *rp = (I64 *)malloc((size_t)(na + 1) * sizeof(I64));
   rp[0] = 1;
-  for (I64 row = 1; row <= n; ++row) {
+  for (I64 a = 0; a < na; ++a) {
+    const I64 row = F->active[a];
     I64 ctr = 0;
-    if (F->act_index[row - 1])
-      for (I64 i = rowptr[row - 1]; i <= rowptr[row] - 1; ++i) {
-        I64 col = colidx[i - 1];
-        int keep = lower ? (col < row) : (col > row);
-        if (keep && F->act_index[col - 1]) ++ctr;
-      }
-    rp[row] = rp[row - 1] + ctr;
+    for (I64 i = rowptr[row - 1]; i <= rowptr[row] - 1; ++i) {
+      I64 col = colidx[i - 1];
+      int keep = lower ? (col < row) : (col > row);
+      if (keep && JO_ACTIVE(F, col)) ++ctr;
+    }
+    rp[a + 1] = rp[a] + ctr;
   }
-  I64 m = rp[n] - 1;
+  I64 m = rp[na] - 1;
   I64 *cols = (I64 *)malloc((size_t)(m > 0 ? m : 1) * sizeof(I64));
   I64 *map = (I64 *)malloc((size_t)(m > 0 ? m : 1) * sizeof(I64));
   I64 idx = 0;
-  for (I64 row = 1; row <= n; ++row)
-    if (F->act_index[row - 1])
-      for (I64 i = rowptr[row - 1]; i <= rowptr[row] - 1; ++i) {
-        I64 col = colidx[i - 1];
-        int keep = lower ? (col < row) : (col > row);
-        if (keep && F->act_index[col - 1]) { map[idx] = i; cols[idx] = col; ++idx; }
-      }
+  for (I64 a = 0; a < na; ++a) {
+    const I64 row = F->active[a];
+    for (I64 i = rowptr[row - 1]; i <= rowptr[row] - 1; ++i) {
+      I64 col = colidx[i - 1];
+      int keep = lower ? (col < row) : (col > row);
+      if (keep && JO_ACTIVE(F, col)) { map[idx] = i; cols[idx] = col; ++idx; }
+    }
+  }
   *o_rowptr = rp; *o_col = cols; *o_map = map;
 }
 
 /* U[k, j] lookup: getindex (mat.jl:11) on the U CSR, 0 when not stored; returns pointer or NULL */
 static const double *u_lookup(const jo_ilu *F, I64 k, I64 j) {
-  I64 lo = F->u_rowptr[k - 1], hi = F->u_rowptr[k] - 1;
+  const I64 ka = F->loc[k - 1] - 1; /* k is an active row of this block (it is the column of a kept L entry) */
+  I64 lo = F->u_rowptr[ka], hi = F->u_rowptr[ka + 1] - 1;
   while (lo <= hi) { /* SparseMatrixCSC getindex = binary search over the sorted column */
     I64 mid = (lo + hi) / 2;
     I64 c = F->u_col[mid - 1];
@@ -676,18 +684,18 @@ static const double *u_lookup(const jo_ilu *F, I64 k, I64 j) {
 /* ilu0_factor! (ilu0.jl:108-144) incl. update_values! through the maps (ilu0.jl:83-98,223-231) */
 static void ilu_refactor(jo_ilu *F, const double *nz) {
   int N = F->bs, NN = N * N;
-  I64 nl = F->l_rowptr[F->n] - 1, nu = F->u_rowptr[F->n] - 1;
+  I64 nl = F->l_rowptr[F->nact] - 1, nu = F->u_rowptr[F->nact] - 1;
   for (I64 i = 0; i < nl; ++i) memcpy(F->l_val + i * NN, nz + (F->l_map[i] - 1) * NN, sizeof(double) * NN);
   for (I64 i = 0; i < nu; ++i) memcpy(F->u_val + i * NN, nz + (F->u_map[i] - 1) * NN, sizeof(double) * NN);
   for (I64 i = 0; i < F->nact; ++i) memcpy(F->d_val + i * NN, nz + (F->d_map[i] - 1) * NN, sizeof(double) * NN);
   double tmp[9], Aik[9], inv[9];
   for (I64 a = 0; a < F->nact; ++a) {
     I64 i = F->active[a];
-    I64 ls = F->l_rowptr[i - 1], le = F->l_rowptr[i] - 1;
-    I64 us = F->u_rowptr[i - 1], ue = F->u_rowptr[i] - 1;
+    I64 ls = F->l_rowptr[a], le = F->l_rowptr[a + 1] - 1;
+    I64 us = F->u_rowptr[a], ue = F->u_rowptr[a + 1] - 1;
     for (I64 l_i = ls; l_i <= le; ++l_i) {
       I64 k = F->l_col[l_i - 1];
-      const double *Dk = F->d_val + (size_t)(F->act_index[k - 1] - 1) * NN;
+      const double *Dk = F->d_val + (size_t)(F->loc[k - 1] - 1) * NN;
       if (N == 1) {
         double A_ik = F->l_val[l_i - 1] * (1.0 / Dk[0]); /* nz_l[l_i]*inv(A_kk) :121 */
         F->l_val[l_i - 1] = A_ik;
@@ -728,20 +736,20 @@ static void ilu_refactor(jo_ilu *F, const double *nz) {
   }
 }
 
-static jo_ilu *ilu_setup(I64 n, int bs, const I64 *rowptr, const I64 *colidx, const I64 *active, I64 nact) {
+static jo_ilu *ilu_setup(I64 n, int bs, const I64 *rowptr, const I64 *colidx, const I64 *active, I64 nact, const I64 *loc,
+                         const I64 *owner, I64 id) {
   jo_ilu *F = (jo_ilu *)calloc(1, sizeof(jo_ilu));
-  F->n = n; F->bs = bs; F->nact = nact;
-  F->active = (I64 *)malloc((size_t)nact * sizeof(I64));
-  F->act_index = (I64 *)calloc((size_t)n, sizeof(I64));
-  for (I64 a = 0; a < nact; ++a) { F->active[a] = active ? active[a] : a + 1; F->act_index[F->active[a] - 1] = a + 1; }
+  F->n = n; F->bs = bs; F->nact = nact; F->loc = loc; F->owner = owner; F->id = id;
+  F->active = (I64 *)malloc((size_t)(nact > 0 ? nact : 1) * sizeof(I64));
+  for (I64 a = 0; a < nact; ++a) F->active[a] = active ? active[a] : a + 1;
   fixed_block(F, rowptr, colidx, 1, &F->l_rowptr, &F->l_col, &F->l_map);
   fixed_block(F, rowptr, colidx, 0, &F->u_rowptr, &F->u_col, &F->u_map);
   int NN = bs * bs;
-  I64 nl = F->l_rowptr[n] - 1, nu = F->u_rowptr[n] - 1;
+  I64 nl = F->l_rowptr[nact] - 1, nu = F->u_rowptr[nact] - 1;
   F->l_val = (double *)calloc((size_t)(nl > 0 ? nl : 1) * NN, sizeof(double));
   F->u_val = (double *)calloc((size_t)(nu > 0 ? nu : 1) * NN, sizeof(double));
-  F->d_val = (double *)calloc((size_t)nact * NN, sizeof(double));
-  F->d_map = (I64 *)calloc((size_t)nact, sizeof(I64));
+  F->d_val = (double *)calloc((size_t)(nact > 0 ? nact : 1) * NN, sizeof(double));
+  F->d_map = (I64 *)calloc((size_t)(nact > 0 ? nact : 1), sizeof(I64));
   /* diagonal_block (ilu0.jl:56-81): diagonal must be stored and precede all upper entries */
   for (I64 a = 0; a < nact; ++a) {
     I64 row = F->active[a];
@@ -754,21 +762,24 @@ static void ilu_free_one(jo_ilu *F) {
   if (!F) return;
   free(F->l_rowptr); free(F->l_col); free(F->l_map); free(F->l_val);
   free(F->u_rowptr); free(F->u_col); free(F->u_map); free(F->u_val);
-  free(F->active); free(F->d_map); free(F->d_val); free(F->act_index); free(F);
+  free(F->active); free(F->d_map); free(F->d_val); free(F);
 }
 
 /* ParallelILUFactorCSR (par_ilu0.jl:2-90): nblocks == 1 with partition == NULL is the serial ilu0_csr(A). */
-typedef struct { I64 nblocks; jo_ilu **f; I64 n; int bs; } jo_ilu_par;
+typedef struct { I64 nblocks; jo_ilu **f; I64 n; int bs; I64 *loc, *owner; } jo_ilu_par;
 
 /* ilu0_csr(A) (ilu0.jl:213-221) / ilu0_csr(A, partition) (par_ilu0.jl:47-55); partition values 1..nparts */
 jo_ilu_par *jo_ilu0_csr(I64 n, int bs, const I64 *rowptr, const I64 *colidx, const double *nz,
                         const I64 *partition) {
   jo_ilu_par *P = (jo_ilu_par *)calloc(1, sizeof(jo_ilu_par));
   P->n = n; P->bs = bs;
+  P->loc = (I64 *)calloc((size_t)(n > 0 ? n : 1), sizeof(I64));
+  P->owner = (I64 *)calloc((size_t)(n > 0 ? n : 1), sizeof(I64));
   if (!partition) {
     P->nblocks = 1;
     P->f = (jo_ilu **)calloc(1, sizeof(jo_ilu *));
-    P->f[0] = ilu_setup(n, bs, rowptr, colidx, NULL, n);
+    for (I64 i = 0; i < n; ++i) { P->loc[i] = i + 1; P->owner[i] = 1; }
+    P->f[0] = ilu_setup(n, bs, rowptr, colidx, NULL, n, P->loc, P->owner, 1);
     for (I64 a = 0; a < n; ++a) if (!P->f[0]->d_map[a]) { return NULL; }
     ilu_refactor(P->f[0], nz);
     return P;
@@ -782,8 +793,9 @@ jo_ilu_par *jo_ilu0_csr(I64 n, int bs, const I64 *rowptr, const I64 *colidx, con
   I64 **lists = (I64 **)calloc((size_t)np, sizeof(I64 *));
   for (I64 b = 0; b < np; ++b) lists[b] = (I64 *)malloc((size_t)(cnt[b + 1] > 0 ? cnt[b + 1] : 1) * sizeof(I64));
   I64 *cur = (I64 *)calloc((size_t)np, sizeof(I64));
-  for (I64 i = 0; i < n; ++i) { I64 b = partition[i] - 1; lists[b][cur[b]++] = i + 1; } /* findall(isequal(b), p) */
-  for (I64 b = 0; b < np; ++b) P->f[b] = ilu_setup(n, bs, rowptr, colidx, lists[b], cnt[b + 1]);
+  for (I64 i = 0; i < n; ++i) { I64 b = partition[i] - 1; lists[b][cur[b]++] = i + 1; P->loc[i] = cur[b]; P->owner[i] = b + 1; } /* findall(isequal(b), p) */
+#pragma omp parallel for schedule(dynamic, 1)
+  for (I64 b = 0; b < np; ++b) P->f[b] = ilu_setup(n, bs, rowptr, colidx, lists[b], cnt[b + 1], P->loc, P->owner, b + 1);
 #pragma omp parallel for schedule(dynamic, 1)
   for (I64 b = 0; b < np; ++b) ilu_refactor(P->f[b], nz);
   for (I64 b = 0; b < np; ++b) free(lists[b]);
@@ -805,12 +817,12 @@ static void ilu_solve_one(const jo_ilu *F, double *x, const double *b) {
     I64 row = F->active[a];
     if (N == 1) {
       double v = b[row - 1];
-      for (I64 j = F->l_rowptr[row - 1]; j <= F->l_rowptr[row] - 1; ++j) v -= F->l_val[j - 1] * x[F->l_col[j - 1] - 1];
+      for (I64 j = F->l_rowptr[a]; j <= F->l_rowptr[a + 1] - 1; ++j) v -= F->l_val[j - 1] * x[F->l_col[j - 1] - 1];
       x[row - 1] = v;
     } else {
       double v[3];
       for (int e = 0; e < N; ++e) v[e] = b[(row - 1) * N + e];
-      for (I64 j = F->l_rowptr[row - 1]; j <= F->l_rowptr[row] - 1; ++j) {
+      for (I64 j = F->l_rowptr[a]; j <= F->l_rowptr[a + 1] - 1; ++j) {
         const double *A = F->l_val + (size_t)(j - 1) * NN;
         const double *xk = x + (size_t)(F->l_col[j - 1] - 1) * N;
         for (int e = 0; e < N; ++e) { double s = 0; for (int d = 0; d < N; ++d) s += A[d * N + e] * xk[d]; v[e] -= s; }
@@ -822,12 +834,12 @@ static void ilu_solve_one(const jo_ilu *F, double *x, const double *b) {
     I64 row = F->active[a];
     if (N == 1) {
       double v = x[row - 1];
-      for (I64 j = F->u_rowptr[row - 1]; j <= F->u_rowptr[row] - 1; ++j) v -= F->u_val[j - 1] * x[F->u_col[j - 1] - 1];
+      for (I64 j = F->u_rowptr[a]; j <= F->u_rowptr[a + 1] - 1; ++j) v -= F->u_val[j - 1] * x[F->u_col[j - 1] - 1];
       x[row - 1] = F->d_val[a] * v;
     } else {
       double v[3], o[3];
       for (int e = 0; e < N; ++e) v[e] = x[(row - 1) * N + e];
-      for (I64 j = F->u_rowptr[row - 1]; j <= F->u_rowptr[row] - 1; ++j) {
+      for (I64 j = F->u_rowptr[a]; j <= F->u_rowptr[a + 1] - 1; ++j) {
         const double *A = F->u_val + (size_t)(j - 1) * NN;
         const double *xk = x + (size_t)(F->u_col[j - 1] - 1) * N;
         for (int e = 0; e < N; ++e) { double s = 0; for (int d = 0; d < N; ++d) s += A[d * N + e] * xk[d]; v[e] -= s; }
@@ -849,7 +861,7 @@ int jo_ilu0_apply(const jo_ilu_par *P, double *x, const double *b) {
 void jo_ilu0_free(jo_ilu_par *P) {
   if (!P) return;
   for (I64 b = 0; b < P->nblocks; ++b) ilu_free_one(P->f[b]);
-  free(P->f); free(P);
+  free(P->f); free(P->loc); free(P->owner); free(P);
 }
 
 /* Export factor values scattered back to A's pattern (for parity tests): lu[k] holds L (multipliers)
@@ -858,7 +870,7 @@ int jo_ilu0_export(const jo_ilu_par *P, double *lu) {
   int NN = P->bs * P->bs;
   for (I64 b = 0; b < P->nblocks; ++b) {
     const jo_ilu *F = P->f[b];
-    I64 nl = F->l_rowptr[F->n] - 1, nu = F->u_rowptr[F->n] - 1;
+    I64 nl = F->l_rowptr[F->nact] - 1, nu = F->u_rowptr[F->nact] - 1;
     for (I64 i = 0; i < nl; ++i) memcpy(lu + (F->l_map[i] - 1) * NN, F->l_val + i * NN, sizeof(double) * NN);
     for (I64 i = 0; i < nu; ++i) memcpy(lu + (F->u_map[i] - 1) * NN, F->u_val + i * NN, sizeof(double) * NN);
     for (I64 i = 0; i < F->nact; ++i) memcpy(lu + (F->d_map[i] - 1) * NN, F->d_val + i * NN, sizeof(double) * NN);

@@ -41,6 +41,26 @@ res = [None] * world
 dist.all_gather_object(res, got.tobytes())
 assert all(r == res[0] for r in res)
 dist.barrier()
+if os.environ.get("JH_TEST_TIMEOUT") == "1":
+    # the last rank never enters the next reduction: every other rank must get an error naming it instead of hanging
+    # (JH_COMM_TIMEOUT_S bounds the in-kernel wait)
+    import time
+    if rank == world - 1:
+        time.sleep(float(os.environ["JH_COMM_TIMEOUT_S"]) + 3.0)
+    else:
+        t0 = time.time()
+        try:
+            ctx.allreduce(np.ones(2), "sum")
+            raise AssertionError("the all-reduce returned although a rank was missing")
+        except ja.JutulHIPError as e:
+            msg = str(e)
+            assert "timed out" in msg and f"waiting for rank {world - 1}" in msg and f"rank {rank} of {world}" in msg, msg
+        assert time.time() - t0 < float(os.environ["JH_COMM_TIMEOUT_S"]) + 2.5
+        assert ctx.comm_info()["timeouts"] >= 1
+    dist.barrier()
+    if rank == 0:
+        print("IPC_TIMEOUT_OK", world, flush=True)
+    os._exit(0)  # the communicator is unusable after a time-out: no orderly teardown
 ctx.comm_finalize()
 dist.barrier()
 if rank == 0:

@@ -30,7 +30,8 @@ def check(d, steps, warmup):
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["value"] > 0 and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert set(r["kernels"]) == {"assembly", "spmv", "ilu0_apply"}
+    assert set(r["kernels"]) == {"assembly", "spmv", "ilu0_apply", "ilu0_factor"}
+    assert "traffic" in r and "traffic_note" in r
 
 
 def test_bench_single_process_with_cpu_baseline():
@@ -39,6 +40,9 @@ def test_bench_single_process_with_cpu_baseline():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "single"
+    # same work on both legs: the CPU leg advances the state through the same warm-up + step sequence
+    assert abs(c["linear_iterations_per_step"] - d["config"]["linear_iterations_per_step"]) <= 6
+    assert c["linear_iterations_first_steps"][0] <= c["linear_iterations_first_steps"][-1]
 
 
 def test_bench_under_torchrun_distributed_path():
@@ -60,3 +64,63 @@ def test_bench_two_processes_sharing_the_gpu():
     assert d["n_gpus"] == 2
     assert d["config"]["parallelism"] == "dd2" and d["config"]["scalar_allreduce"] == "mailbox"
     assert 5 <= d["config"]["linear_iterations_per_step"] <= 100
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: bench.py starts the two ranks itself (simulate_parray builds all ranks
+    itself, ext/JutulPartitionedArraysExt/interface.jl:2-97), rank 0 prints the one line, n_gpus == 2.  On a box with fewer
+    devices than ranks the ghost exchange falls back to the host callback (reported in config), on an 8-GPU node the same
+    command runs one rank per GPU over RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "JH_BENCH_HALO")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--cells", "200000", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    check(d, 2, 1)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["launcher"] == "self" and c["parallelism"] == "dd2"
+    assert c["comm_timeouts"] == 0 and c["scalar_allreduce"] in ("mailbox", "rccl") and c["krylov_halo"] in ("push", "rccl", "host-callback")
+    import torch
+    if torch.cuda.device_count() >= 2:
+        assert c["devices_used"] == 2 and c["rccl_ranks"] == 2 and c["halo"] == "rccl"
+    else:
+        assert c["devices_used"] == 1 and c["halo"].startswith("host-callback")
+
+
+def test_bench_fails_loudly_when_ranks_do_not_match_gpus():
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29543", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--cells", "50000", "--no-cpu"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "FATAL" in p.stderr and "--gpus 2" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_bench_two_phase_law():
+    """configs[3] in the measured bench: --law twophase (2x2 blocks), block byte formulas of SURVEY 8(d)."""
+    d = run([sys.executable, "bench.py", "--law", "twophase", "--cells", "200000", "--steps", "3", "--warmup", "1", "--no-cpu"])
+    check(d, 3, 1)
+    c = d["config"]
+    assert c["law"] == "twophase" and c["block_n"] == 2
+    k = d["roofline"]["kernels"]
+    nc, nf = c["cells"], c["faces"]
+    assert k["assembly"]["algorithmic_bytes"] == (24 * 2 + 4 + 8 * 2 + 8 * 4) * nc + (4 + 8 + 8 * 4) * 2 * nf
+    assert k["spmv"]["algorithmic_bytes"] == (8 * 4 + 4) * (nc + 2 * nf) + (4 + 16 * 2) * nc + 8 * 2 * nc
+
+
+def test_bench_rccl_fallback_paths_two_devices():
+    """JH_BENCH_NO_MAILBOX=1 JH_BENCH_NO_PUSH=1 with real RCCL between two devices: the result must match the mailbox / push
+    run and the 1-rank run (state norm) -- only runs where two devices are visible."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    base = [sys.executable, "bench.py", "--cells", "200000", "--steps", "3", "--warmup", "1", "--no-cpu"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "JH_BENCH_HALO")}
+    one = run(base, env=env)
+    fast = run(base + ["--gpus", "2"], env=env)
+    slow = run(base + ["--gpus", "2"], env=dict(env, JH_BENCH_NO_MAILBOX="1", JH_BENCH_NO_PUSH="1"))
+    assert slow["config"]["scalar_allreduce"] == "rccl" and slow["config"]["krylov_halo"] == "rccl"
+    for d in (fast, slow):
+        assert d["config"]["rccl_ranks"] == 2 and d["config"]["comm_timeouts"] == 0
+        assert abs(d["config"]["state_norm"] - one["config"]["state_norm"]) <= 1e-5 * one["config"]["state_norm"]
