@@ -127,6 +127,11 @@ int32_t jh_vec_upload_layout(jh_vec v, int32_t layout, const double *host);
 int32_t jh_vec_download_layout(jh_vec v, int32_t layout, double *host);
 /* mul!(y, A, x, alpha, beta) (StaticCSR/mat.jl:24-39; block: linsolve/block_cpu.jl:1-17) */
 int32_t jh_spmv(jh_csr A, jh_vec x, jh_vec y, double alpha, double beta);
+/* The same product through the layout the Krylov loop multiplies with: a jagged-slice copy of the values (64-row slices, rows
+ * sorted by length, entries stored diagonal by diagonal; refreshed at the start of every jh_bicgstab / jh_newton_step solve).
+ * Same accumulation order, hence the same bits as jh_spmv.  Scalar matrices with at most 8 entries per row; error otherwise.
+ * Exposed so that the parity tests can check the layout on its own. */
+int32_t jh_spmv_jagged(jh_csr A, jh_vec x, jh_vec y, double alpha, double beta);
 /* krylov_scale_system! / apply_scaling_to_linearized_system! (linsolve/krylov.jl:194, default.jl:325-385):
  * kind 0 :none, 1 :diagonal (J <- diag(1/|A_ii[j,j]|) J, r likewise), 2 :dt (J <- dt J, r <- dt r).  In place. */
 int32_t jh_scale_system(jh_csr A, jh_vec r, int32_t kind, double dt);

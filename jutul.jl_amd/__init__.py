@@ -387,9 +387,9 @@ class StaticSparsityMatrixCSR(_Handle):
         return DeviceVector(self.disc if self.disc is not None else self, values)
 
 
-def mul_(y, A, x, alpha=1.0, beta=0.0):
-    """mul!(y, A, x, alpha, beta) (StaticCSR/mat.jl:24-39)."""
-    check(_L().jh_spmv(A.h, x.h, y.h, float(alpha), float(beta)))
+def mul_(y, A, x, alpha=1.0, beta=0.0, jagged=False):
+    """mul!(y, A, x, alpha, beta) (StaticCSR/mat.jl:24-39).  jagged=True: through the jagged-slice layout of the Krylov loop."""
+    check((_L().jh_spmv_jagged if jagged else _L().jh_spmv)(A.h, x.h, y.h, float(alpha), float(beta)))
     return y
 
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     "jh_vec_upload_layout": [H, C.c_int32, F64P],
     "jh_vec_download_layout": [H, C.c_int32, F64P],
     "jh_spmv": [H, H, H, C.c_double, C.c_double],
+    "jh_spmv_jagged": [H, H, H, C.c_double, C.c_double],
     "jh_scale_system": [H, H, C.c_int32, C.c_double],
     "jh_unit_diagonalize": [H, H, C.c_int64],
     "jh_law_create": [H, C.c_int32, F64P, C.POINTER(H)],

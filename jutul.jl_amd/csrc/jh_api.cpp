@@ -1,5 +1,6 @@
 // C-ABI glue: contexts, vectors, matrices, laws.  See include/jutul_hip.h for the reference seams.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "jh_internal.hpp"
@@ -286,6 +287,20 @@ extern "C" int32_t jh_spmv(jh_csr A, jh_vec x, jh_vec y, double alpha, double be
     if (x == y) JH_THROW("x and y must not alias");
     JH_HIP(hipSetDevice(A->ctx->device));
     k_spmv(A->ctx, *A->pat, A->val.p, x->d.p, y->d.p, alpha, beta);
+    JH_HIP(hipGetLastError());
+  });
+}
+extern "C" int32_t jh_spmv_jagged(jh_csr A, jh_vec x, jh_vec y, double alpha, double beta) {
+  return guard([&] {
+    if (!A || !x || !y) JH_THROW("null argument");
+    int64_t len = A->pat->n * A->pat->bs;
+    if (x->len != len || y->len != len) JH_THROW("DimensionMismatch (mat.jl:27-28)");
+    if (x == y) JH_THROW("x and y must not alias");
+    JH_HIP(hipSetDevice(A->ctx->device));
+    const bool keep = getenv("JH_JDS_KEEP") != nullptr;  // tools/spmv_probe.py: time the product without the refresh
+    if (!(keep && A->jval_fresh) && !sell_refresh(A)) JH_THROW("matrix has no jagged-slice form (block size > 1 or more than 8 entries in a row)");
+    k_spmv_sell(A, x->d.p, y->d.p, alpha, beta, nullptr, nullptr);
+    if (!keep) A->jval_fresh = false;
     JH_HIP(hipGetLastError());
   });
 }

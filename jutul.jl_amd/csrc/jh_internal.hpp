@@ -155,8 +155,22 @@ struct Pattern {
   DevBuf<int32_t> d_tile_desc;
   // device copies
   DevBuf<int32_t> d_rowptr, d_col, d_diag, d_perm, d_nz_hslot, d_tile_row;
+  // Jagged-slice form of the pattern for the SpMV of the Krylov loop (jh_sell.hip): rows in slices of 64 (one wavefront), inside
+  // a slice sorted by length, entries stored diagonal by diagonal -> every lane streams its row with fully coalesced loads,
+  // accumulates left->right in registers (the reference's order, mat.jl:41-61) and needs neither row pointers, LDS nor barriers.
+  struct Jagged {
+    bool built = false, usable = false;  // usable: bs == 1 and at most JDS_KMAX entries per row
+    int32_t nslices = 0, kmax = 0;
+    int64_t nent = 0;
+    DevBuf<int32_t> d_base;  // [nslices + 1] first entry of every slice
+    DevBuf<uint8_t> d_cnt;   // [nslices * 16] byte j: rows of the slice with more than j entries
+    DevBuf<uint8_t> d_perm;  // [nslices * 64] lane -> row offset inside the slice
+    DevBuf<int32_t> d_col;   // [nent] column ids, jagged order
+    DevBuf<int32_t> d_src;   // [nent] CSR slot each jagged entry is copied from
+  } jag;
   void build_tiles();
   void upload();
+  void build_jagged();  // lazily, on the first Krylov solve
 };
 
 }  // namespace jh
@@ -212,6 +226,8 @@ struct jh_csr_s {
   std::shared_ptr<jh::Pattern> pat;
   jh_tpfa disc = nullptr;  // non-owning, may be null
   jh::DevBuf<double> val;  // nnzb * bs * bs, device slot order, each block column-major
+  jh::DevBuf<double> jval; // the same values in jagged-slice order: refreshed at the start of every Krylov solve (jh_sell.hip)
+  bool jval_fresh = false; // only between sell_refresh() and the end of that solve
 };
 
 struct jh_law_s {
@@ -273,6 +289,11 @@ struct SpmvRange {
 };
 int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta,
            const SpmvDot *dot = nullptr, const double *done = nullptr, const SpmvRange *rng = nullptr);
+// jh_sell.hip: jagged-slice SpMV with the same fused-dot contract; A->jval must be fresh (sell_refresh)
+constexpr int JDS_KMAX = 8;
+bool sell_refresh(jh_csr A);  // false: the matrix has no jagged form (block size > 1 or long rows) -> CSR tile kernels
+int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done);
+void spmv_dot_reduce(jh_context ctx, const SpmvDot *dot, int nparts, const double *done);
 void ensure_partials(jh_context ctx, size_t min_stride);
 void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max, const double *done = nullptr,
                     const MailArgs *mail = nullptr);

@@ -453,19 +453,22 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_pipe_kernel(const int32_t *
   }
 }
 
+// second stage of a fused SpMV dot; with dot->allreduce also over the ranks (same launch if the mailboxes are on)
+void spmv_dot_reduce(jh_context ctx, const SpmvDot *dot, int nparts, const double *done) {
+  const int cnt = dot->mode == 2 ? 2 : 1;
+  MailArgs ma;
+  const bool fused = dot->allreduce && comm_mail_args(ctx, cnt, &ma);
+  k_final_reduce(ctx, nparts, cnt, dot->slot, false, done, fused ? &ma : nullptr);
+  if (dot->allreduce && !fused) comm_allreduce_dev(ctx, ctx->scalars.p + dot->slot, cnt, 0);
+}
+
 int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x, double *y, double alpha, double beta,
            const SpmvDot *dot, const double *done, const SpmvRange *rng) {
   if (P.n == 0) return 0;
   const int t_begin = rng ? rng->t0 : 0;
   const int ntl = rng ? rng->t1 - rng->t0 : P.ntiles;
   const int part_off = rng ? rng->part_off : 0;
-  auto reduce = [&](int nparts) {  // second stage; with dot->allreduce also over the ranks (same launch if the mailboxes are on)
-    const int cnt = dot->mode == 2 ? 2 : 1;
-    MailArgs ma;
-    const bool fused = dot->allreduce && comm_mail_args(ctx, cnt, &ma);
-    k_final_reduce(ctx, nparts, cnt, dot->slot, false, done, fused ? &ma : nullptr);
-    if (dot->allreduce && !fused) comm_allreduce_dev(ctx, ctx->scalars.p + dot->slot, cnt, 0);
-  };
+  auto reduce = [&](int nparts) { spmv_dot_reduce(ctx, dot, nparts, done); };
   if (ntl <= 0) {
     if (dot && rng && rng->reduce && part_off > 0) reduce(part_off);
     return 0;

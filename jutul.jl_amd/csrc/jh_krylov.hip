@@ -256,10 +256,13 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     comm_allreduce_dev(ctx, sc + slot, c2 ? 2 : 1, 0);
   };
   const int64_t rows_dot = nd / P.bs;
+  // the matrix does not change during the solve: multiply out of its jagged-slice copy when it has one (jh_sell.hip)
+  const bool jagged = sell_refresh(K->A);
   auto spmv = [&](double *in, double *out, const SpmvDot *dot, bool packed = false) {
     if (dist) halo_exchange(disc, in, P.bs, packed, true);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
     K->mark(0, st);
-    k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done);  // dot->allreduce: summed over the ranks in there
+    if (jagged) k_spmv_sell(K->A, in, out, 1.0, 0.0, dot, done);
+    else k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done);  // dot->allreduce: summed over the ranks in there
     K->mark(0, st);
   };
   K->cur_it = 0;
@@ -436,6 +439,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   else if (status == 0 && it >= itmax) status = 1;
   if (it & 1) k_copy(st, x, X[1], n);  // iterate of the last accepted iteration
   if (dist) halo_exchange(disc, x, P.bs);  // consistent!(x) (ext/.../krylov.jl:75)
+  K->A->jval_fresh = false;  // the values may change before the next solve
   *iters_out = it;
   K->collect(it);
   JH_HIP(hipGetLastError());

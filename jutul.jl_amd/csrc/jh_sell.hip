@@ -1,0 +1,235 @@
+// Jagged-slice SpMV for the Krylov loop (a-10; mul!, StaticCSR/mat.jl:24-61).
+//
+// The CSR tile kernel (jh_kernels.hip) pays for the generality of CSR on every product: row pointers, products staged in LDS,
+// three workgroup barriers per tile.  A TPFA Jacobian has short rows of nearly equal length (a cell and its faces), and inside
+// the Krylov loop its values do not change.  So every solve starts by copying the values into a jagged-slice layout (one
+// 20-byte-per-entry pass, ~1.5 SpMVs) and then multiplies out of that:
+//   * rows in slices of 64 = one wavefront, one lane per row;
+//   * inside a slice the rows are sorted by length (the lane -> row map is one byte per row) and the entries are stored
+//     "diagonal by diagonal": the j-th entries of all rows that have one are consecutive.  Lane l reads entry j at
+//     base_j + l: every load of the value / column stream is one fully coalesced 512 / 256-byte wavefront access, and there is
+//     no padding whatever the length distribution is;
+//   * the lane accumulates its row left -> right in registers -- the reference's order (ascending columns, mat.jl:41-61), so
+//     the result has the same bits as the CSR kernel's -- and stores y directly.  No row pointers, no LDS, no barrier.
+// Waves are persistent over an XCD-contiguous range of slices and software-pipelined: the descriptor of slice i+2 and the
+// entries of slice i+1 are in flight while slice i gathers x and accumulates.
+#include <algorithm>
+#include <cstdlib>
+#include <numeric>
+
+#include "jh_internal.hpp"
+
+namespace jh {
+
+void Pattern::build_jagged() {
+  if (jag.built) return;
+  jag.built = true;
+  jag.usable = false;
+  if (bs != 1 || n == 0) return;
+  int32_t kmax = 0;
+  for (int64_t i = 0; i < n; ++i) kmax = std::max(kmax, rowptr[i + 1] - rowptr[i]);
+  if (kmax > JDS_KMAX) return;
+  const int32_t ns = (int32_t)((n + 63) / 64);
+  std::vector<int32_t> base(ns + 1, 0), jc(nnzb + 64, 0), src(nnzb + 64, 0);  // + 64: lanes past a diagonal's count load too
+  std::vector<uint8_t> cnt((size_t)ns * 16, 0), perm((size_t)ns * 64, 0);
+  int64_t pos = 0;
+  int lanes[64];
+  for (int32_t s = 0; s < ns; ++s) {
+    const int64_t r0 = (int64_t)s * 64;
+    const int nr = (int)std::min<int64_t>(64, n - r0);
+    std::iota(lanes, lanes + nr, 0);
+    std::stable_sort(lanes, lanes + nr, [&](int a, int b) {
+      return rowptr[r0 + a + 1] - rowptr[r0 + a] > rowptr[r0 + b + 1] - rowptr[r0 + b];
+    });
+    base[s] = (int32_t)pos;
+    for (int l = 0; l < nr; ++l) perm[(size_t)s * 64 + l] = (uint8_t)lanes[l];
+    for (int j = 0; j < kmax; ++j) {
+      int c = 0;
+      for (int l = 0; l < nr; ++l) {
+        const int64_t row = r0 + lanes[l];
+        if (rowptr[row + 1] - rowptr[row] > j) {
+          jc[pos] = col[rowptr[row] + j];
+          src[pos] = rowptr[row] + j;
+          ++pos;
+          ++c;
+        } else {
+          break;  // sorted by length: no later lane has a j-th entry either
+        }
+      }
+      cnt[(size_t)s * 16 + j] = (uint8_t)c;
+    }
+  }
+  base[ns] = (int32_t)pos;
+  jag.nslices = ns;
+  jag.kmax = kmax;
+  jag.nent = pos;
+  hipStream_t st = ctx->stream;
+  jag.d_base.upload(base, st);
+  jag.d_cnt.upload(cnt, st);
+  jag.d_perm.upload(perm, st);
+  jag.d_col.upload(jc, st);
+  jag.d_src.upload(src, st);
+  JH_HIP(hipStreamSynchronize(st));
+  jag.usable = true;
+}
+
+namespace {
+
+__global__ __launch_bounds__(256) void jagged_copy_kernel(double *__restrict__ jval, const double *__restrict__ val,
+                                                          const int32_t *__restrict__ src, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) jval[i] = val[src[i]];
+}
+
+struct JDesc {
+  int base;
+  uint4 c;  // 16 counts, one byte each
+};
+template <int KU>
+struct JEnt {
+  int col[KU];
+  double val[KU];
+  int prow;
+};
+template <int J>
+__device__ __forceinline__ int jcount(const uint4 &c) {
+  const unsigned w = J < 4 ? c.x : (J < 8 ? c.y : (J < 12 ? c.z : c.w));
+  return (int)((w >> (8 * (J & 3))) & 0xffu);
+}
+
+// Measured on the 10M-cell bench matrix (tools/spmv_probe.py; CSR tile kernel 189 us): lane = row with plain loads and a
+// store in sorted-by-length lane order 173 us; value / column stream with non-temporal loads (read once: keeps the vectors in
+// L2 / Infinity Cache) -8 us; results transposed through LDS so that y leaves in row order -10 us: 154 us.  An LDS window of x
+// for the near columns (what the CSR tile kernel does) made it SLOWER here (160 us: the workgroup barrier and the LDS round
+// trip cost more than the vector L1 serving the gathers); with every column served from LDS it would be 145 us, i.e. the
+// 18% far columns cost ~15 us.  The four wavefronts of a workgroup take four consecutive slices and meet at one barrier per
+// step: kept in step they share the vector-L1 lines of their neighbouring rows' x entries (free-running wavefronts: 165 us).
+template <int KU, int DOT>
+__global__ __launch_bounds__(256) void spmv_jds_kernel(const int32_t *__restrict__ base, const uint4 *__restrict__ cnt16,
+                                                       const uint8_t *__restrict__ perm, const int32_t *__restrict__ jcol,
+                                                       const double *__restrict__ jval, int nslices, int nrows,
+                                                       const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
+                                                       const double *__restrict__ dw, int dot_rows, double *__restrict__ part,
+                                                       size_t pstride, const double *done) {
+  if (done && *done != 0.0) return;
+  __shared__ double tr[4][64];
+  __shared__ double red[8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroup b runs on XCD b % 8 (observed placement, performance only): each XCD sweeps one contiguous eighth of the slices
+  const int nsup = (nslices + 3) / 4;  // steps: four slices = 256 rows each
+  const int chunk = (nsup + NUM_XCD - 1) / NUM_XCD;
+  const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, wgs = gridDim.x / NUM_XCD;
+  const int stride = wgs * 4;
+  const int s_end = min(nslices, 4 * min(nsup, (xcd + 1) * chunk));
+  const int s_loop_end = 4 * min(nsup, (xcd + 1) * chunk);  // uniform over the workgroup (the barrier below)
+  double d0 = 0.0, d1 = 0.0;
+  auto ldesc = [&](int s, JDesc &D) {
+    if (s < s_end) { D.base = base[s]; D.c = cnt16[s]; }
+    else { D.base = 0; D.c = make_uint4(0, 0, 0, 0); }
+  };
+  auto lent = [&](int s, const JDesc &D, JEnt<KU> &E) {
+    int off = D.base;
+#define JH_LENT(J)                                                                                                       \
+    if (J < KU) { /* unconditional: lanes past the count read the next diagonal's entries (arrays padded by 64), unused */ \
+      E.col[J < KU ? J : 0] = __builtin_nontemporal_load(jcol + off + lane);                                             \
+      E.val[J < KU ? J : 0] = __builtin_nontemporal_load(jval + off + lane);                                             \
+      off += jcount<J>(D.c);                                                                                             \
+    }
+    JH_LENT(0) JH_LENT(1) JH_LENT(2) JH_LENT(3) JH_LENT(4) JH_LENT(5) JH_LENT(6) JH_LENT(7)
+#undef JH_LENT
+    E.prow = (int)perm[(size_t)min(s, nslices - 1) * 64 + lane];
+  };
+  int s = 4 * (xcd * chunk + wg) + w;
+  JDesc dc, dn, dnn;
+  JEnt<KU> ec, en;
+  ldesc(s, dc);
+  ldesc(s + stride, dn);
+  lent(s, dc, ec);
+  for (; s - w < s_loop_end; s += stride) {
+    ldesc(s + 2 * stride, dnn);
+    lent(s + stride, dn, en);
+    __syncthreads();  // keeps the four wavefronts on neighbouring slices
+    double xg[KU];
+    // (unconditional as well: an unused lane holds some other entry's column id, a valid index)
+#define JH_GATH(J) if (J < KU) xg[J < KU ? J : 0] = x[ec.col[J < KU ? J : 0]];
+    JH_GATH(0) JH_GATH(1) JH_GATH(2) JH_GATH(3) JH_GATH(4) JH_GATH(5) JH_GATH(6) JH_GATH(7)
+#undef JH_GATH
+    double acc = 0.0;
+#define JH_ACC(J) if (J < KU) { const double t = acc + ec.val[J < KU ? J : 0] * xg[J < KU ? J : 0]; acc = (lane < jcount<J>(dc.c)) ? t : acc; }
+    JH_ACC(0) JH_ACC(1) JH_ACC(2) JH_ACC(3) JH_ACC(4) JH_ACC(5) JH_ACC(6) JH_ACC(7)
+#undef JH_ACC
+    // lane -> row: through the wavefront's LDS strip (the LDS operations of one wavefront complete in order), so that y is
+    // stored -- and the dot weights are read -- as 512 contiguous bytes
+    const int nr = (s < s_end) ? min(64, nrows - s * 64) : 0;
+    if (lane < nr) tr[w][ec.prow] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < nr) {
+      const int row = s * 64 + lane;
+      const double a = tr[w][lane];
+      const double yv = (beta == 0.0) ? alpha * a : alpha * a + beta * y[row];
+      y[row] = yv;
+      if (DOT && row < dot_rows) { d0 += yv * dw[row]; if (DOT == 2) d1 += yv * yv; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    dc = dn; dn = dnn;
+    ec = en;
+  }
+  if (DOT) {  // one partial per workgroup, reduced in a fixed order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); if (DOT == 2) d1 += __shfl_down(d1, off, 64); }
+    if (lane == 0) { red[w] = d0; red[4 + w] = d1; }
+    __syncthreads();
+    if (tid == 0) {
+      part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+      if (DOT == 2) part[pstride + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+  }
+}
+
+}  // namespace
+
+// Copies the current values of A into the jagged-slice order; true if the Krylov loop can multiply with k_spmv_sell.
+bool sell_refresh(jh_csr A) {
+  static const bool off = getenv("JH_SPMV_NO_JAGGED") != nullptr;
+  A->jval_fresh = false;
+  if (off) return false;
+  Pattern &P = *A->pat;
+  if (!P.jag.built) P.build_jagged();
+  if (!P.jag.usable) return false;
+  if (A->jval.n < (size_t)P.jag.nent + 64) A->jval.alloc((size_t)P.jag.nent + 64);
+  const int g = (int)std::max<int64_t>(1, std::min<int64_t>((P.jag.nent + 64 + 255) / 256, 4096));
+  hipLaunchKernelGGL(jagged_copy_kernel, dim3(g), dim3(256), 0, A->ctx->stream, A->jval.p, A->val.p, P.jag.d_src.p, P.jag.nent + 64);
+  A->jval_fresh = true;
+  return true;
+}
+
+int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done) {
+  jh_context ctx = A->ctx;
+  const Pattern &P = *A->pat;
+  const auto &J = P.jag;
+  if (!A->jval_fresh) JH_THROW("jagged-slice SpMV without fresh values (sell_refresh)");
+  const int mode = dot ? dot->mode : 0;
+  static const int wg_per_xcd = getenv("JH_SPMV_WGS") ? atoi(getenv("JH_SPMV_WGS")) : 256;  // 32 CUs x 8 workgroups
+  const int nsup = (J.nslices + 3) / 4;
+  const int chunk = (nsup + NUM_XCD - 1) / NUM_XCD;
+  const int per_xcd = std::max(1, std::min(chunk, wg_per_xcd));
+  dim3 grid(per_xcd * NUM_XCD), block(256);
+  if (mode) ensure_partials(ctx, (size_t)grid.x);
+  const double *dw = dot ? dot->w : nullptr;
+  const int drows = dot ? (int)dot->n_rows : 0;
+#define JH_JDS(KU, DV)                                                                                                          \
+  hipLaunchKernelGGL((spmv_jds_kernel<KU, DV>), grid, block, 0, ctx->stream, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), \
+                     J.d_perm.p, J.d_col.p, A->jval.p, J.nslices, (int)P.n, x, y, alpha, beta, dw, drows, ctx->partials.p, ctx->partial_stride, done)
+  if (J.kmax <= 5) {
+    if (mode == 0) JH_JDS(5, 0); else if (mode == 1) JH_JDS(5, 1); else JH_JDS(5, 2);
+  } else {
+    if (mode == 0) JH_JDS(8, 0); else if (mode == 1) JH_JDS(8, 1); else JH_JDS(8, 2);
+  }
+#undef JH_JDS
+  if (mode) spmv_dot_reduce(ctx, dot, (int)grid.x, done);
+  return (int)grid.x;
+}
+
+}  // namespace jh

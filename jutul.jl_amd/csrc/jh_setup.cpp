@@ -4,6 +4,8 @@
 #include <cstring>
 #include <numeric>
 #include <queue>
+#include <string>
+#include <cstdlib>
 
 #include "jh_internal.hpp"
 
@@ -108,6 +110,17 @@ static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block
   size_t cand_head = 0;
   std::vector<int32_t> q;
   q.reserve(block_rows);
+  // Order inside a block (JH_BLOCK_ORDER): "bfs" = growth order; "layers" (default) = by BFS layer from the seed and, inside a
+  // layer, by a greedy colouring of the layer's own adjacencies.  ILU(0) depends on the ordering only through the orientation
+  // of the edges (which endpoint is eliminated first); growth order chains the cells of a layer one after the other (a
+  // 512-cell block has ~65 dependency levels), colouring the layer keeps every cross-layer orientation and leaves
+  // (layers x colours) ~ 25 levels for the level-scheduled triangular solves.
+  static const int order_mode = [] {
+    const char *e = getenv("JH_BLOCK_ORDER");
+    return (e && std::string(e) == "bfs") ? 0 : 1;
+  }();
+  std::vector<int32_t> depth(order_mode ? nc_all : 0, 0), colour(order_mode ? nc_all : 0, -1), qpos(order_mode ? nc_all : 0, 0);
+  std::vector<int32_t> qsorted;
   int64_t next_unassigned = 0;
   int32_t b = 0;
   while ((int64_t)perm.size() < nc) {
@@ -124,13 +137,33 @@ static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block
     q.clear();
     q.push_back(seed);
     blk[seed] = b;
+    if (order_mode) depth[seed] = 0;
     size_t head = 0;
     while (head < q.size() && (int64_t)q.size() < block_rows) {
       int32_t c = q[head++];
       for (int64_t k = A.ptr[c]; k < A.ptr[c + 1] && (int64_t)q.size() < block_rows; ++k) {
         int32_t o = A.nbr[k];
-        if (blk[o] < 0) { blk[o] = b; q.push_back(o); }
+        if (blk[o] < 0) { blk[o] = b; q.push_back(o); if (order_mode) depth[o] = depth[c] + 1; }
       }
+    }
+    if (order_mode) {
+      for (size_t i = 0; i < q.size(); ++i) { qpos[q[i]] = (int32_t)i; colour[q[i]] = -1; }
+      for (int32_t c : q) {  // greedy colouring inside the BFS layer, in growth order
+        unsigned used = 0;
+        for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k) {
+          const int32_t o = A.nbr[k];
+          if (blk[o] == b && depth[o] == depth[c] && colour[o] >= 0 && colour[o] < 32) used |= 1u << colour[o];
+        }
+        int col = 0;
+        while (col < 31 && (used >> col) & 1u) ++col;
+        colour[c] = col;
+      }
+      qsorted = q;
+      std::sort(qsorted.begin(), qsorted.end(), [&](int32_t a, int32_t c) {
+        if (depth[a] != depth[c]) return depth[a] < depth[c];
+        if (colour[a] != colour[c]) return colour[a] < colour[c];
+        return qpos[a] < qpos[c];
+      });
     }
     // unassigned neighbours of the block become seed candidates
     for (int32_t c : q)
@@ -140,7 +173,8 @@ static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block
       cand.erase(cand.begin(), cand.begin() + cand_head);
       cand_head = 0;
     }
-    perm.insert(perm.end(), q.begin(), q.end());
+    if (order_mode) perm.insert(perm.end(), qsorted.begin(), qsorted.end());
+    else perm.insert(perm.end(), q.begin(), q.end());
     block_ptr.push_back((int32_t)perm.size());
     ++b;
   }

@@ -197,6 +197,39 @@ def test_spmv_parity(ja, ctx, oracle, bs):
     assert abs(xd.dot(yd) - x @ yd.download()) < 1e-10 * abs(x @ yd.download()) + 1e-12
 
 
+@pytest.mark.parametrize("dims,reorder", [((9, 8, 7), "blocks"), ((5, 1, 1), "none"), ((33, 17, 1), "blocks"), ((4, 4, 4), "none")])
+def test_spmv_jagged_slice_layout_matches_csr_bitwise(ja, ctx, oracle, dims, reorder):
+    """The Krylov loop multiplies out of a jagged-slice copy of the Jacobian (64-row slices, rows sorted by length, entries stored
+    diagonal by diagonal): same left-to-right accumulation (mat.jl:41-61) => the same bits as the CSR tile kernel, and the oracle's
+    product to rounding.  Ragged last slice, rows of every length 1..7, alpha/beta forms."""
+    N = ja.cartesian_neighbors(dims)
+    nc = int(np.prod(dims))
+    rng = np.random.default_rng(11)
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, reorder=reorder, block_rows=64)
+    A = ja.StaticSparsityMatrixCSR(disc)
+    rowptr, colidx = disc.pattern()
+    nz = rng.standard_normal(A.nnzb)
+    A.nzval = nz
+    x, y0 = rng.standard_normal(nc), rng.standard_normal(nc)
+    for alpha, beta in [(1.0, 0.0), (-2.0, 1.0), (0.5, 3.0)]:
+        ya = ja.mul_(ja.DeviceVector(disc, y0), A, ja.DeviceVector(disc, x), alpha, beta).download()
+        yb = ja.mul_(ja.DeviceVector(disc, y0), A, ja.DeviceVector(disc, x), alpha, beta, jagged=True).download()
+        assert np.array_equal(ya, yb)
+        assert relerr(yb, oracle.spmv(nc, 1, rowptr, colidx, nz, x, y0, alpha, beta)) < RTOL
+    # new values after the first product: the copy is refreshed, not cached
+    nz2 = rng.standard_normal(A.nnzb)
+    A.nzval = nz2
+    yb = ja.mul_(ja.DeviceVector(disc), A, ja.DeviceVector(disc, x), jagged=True).download()
+    assert relerr(yb, oracle.spmv(nc, 1, rowptr, colidx, nz2, x)) < RTOL
+
+
+def test_spmv_jagged_rejects_blocks_and_long_rows(ja, ctx, oracle):
+    nc, rowptr, colidx, nz, rng = random_csr(oracle, (4, 4, 3), 2, seed=4)
+    A = ja.StaticSparsityMatrixCSR(context=ctx, n=nc, bs=2, rowptr=rowptr, colidx=colidx, nzval=nz)
+    with pytest.raises(ja.JutulHIPError, match="jagged"):
+        ja.mul_(A.new_vector(), A, A.new_vector(), jagged=True)
+
+
 def test_spmv_long_rows_and_empty_offdiag(ja, ctx, oracle):
     """Arrow matrix: one dense row (> TILE_NNZ entries -> long-row path), diagonal elsewhere."""
     n = 3000
