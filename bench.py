@@ -425,9 +425,9 @@ def measured_traffic(kernel, args, cells, world):
     measurement -- quoted only if it was taken on exactly this kernel source (hash recorded next to it) and workload; otherwise
     null with the reason."""
     import glob
-    names = {"ilu0_apply": ["ilu_apply_chunked_kernel<1, 1>", "ilu_apply_chunked_kernel<1, 2>"],
-             "spmv": ["spmv_pipe_kernel<1>", "spmv_pipe_kernel<2>"], "assembly": ["assemble_pipe_kernel<0>"],
-             "ilu0_factor": ["ilu_factor_lds_kernel<1>"]}
+    names = {"ilu0_apply": ["ilu_apply_jds_kernel<1, 1, 4>", "ilu_apply_jds_kernel<1, 2, 4>"],
+             "spmv": ["spmv_jds_kernel<5, 1>", "spmv_jds_kernel<5, 2>"], "assembly": ["assemble_pipe_kernel<0>"],
+             "ilu0_factor": ["ilu_factor_prog_kernel<1>"]}
     if world != 1 or args.law != "poisson" or cells != 10_025_988:
         return None, "PMC passes are committed for the default 1-GPU 10M-cell poisson workload only"
     want = kernel_source_hash()

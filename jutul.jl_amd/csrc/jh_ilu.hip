@@ -61,6 +61,27 @@ struct jh_ilu_s {
   DevBuf<int32_t> d_send_ptr, d_send_local, d_send_slot;
   uint64_t halo_epoch = 0;
   bool factored = false;
+  // ---- chunk-jagged layout (the performance path of the LDS mode, see ilu_apply_jds_kernel) ----------------------------------
+  bool jag = false;      // l_val / u_val / dinv are stored in chunk-jagged order
+  int jag_ku = 4;        // diagonals held in registers per sweep (4 or 8)
+  int64_t jl_nent = 0, ju_nent = 0, j_nslots = 0;  // jagged entry counts (+ padding), 64 * chunks
+  std::vector<int32_t> chunk_ptr;                  // per block: first chunk; block b has ceil(rows/64) chunks per sweep
+  std::vector<int32_t> jl_map, ju_map, jd_map;     // A slot of every jagged L / U entry and of every bwd lane's pivot (-1: no row)
+  DevBuf<int32_t> d_chunk_ptr, d_jl_map, d_ju_map, d_jd_map;
+  DevBuf<int4> d_jf_desc, d_jb_desc;               // per chunk: entry base, counts 0-3, counts 4-7, lvlo | lvhi << 16
+  DevBuf<uint32_t> d_jf_row, d_jb_row;             // per chunk lane: block-local row | level << 16 (0xffff....: no row)
+  DevBuf<uint16_t> d_jl_col, d_ju_col;             // block-local column of every jagged entry
+  // the jagged position of every old-order L / U entry and pivot (factor kernels that still produce the row-major order)
+  std::vector<int32_t> jl_of_old, ju_of_old, jd_of_old;
+  DevBuf<int32_t> d_jl_of_old, d_ju_of_old, d_jd_of_old;
+  DevBuf<double> jl_val, ju_val, jdinv;  // factor values in chunk-jagged order
+  // program-driven factorisation (ilu_factor_prog_kernel): per block the entry ranges and a 16-bit instruction stream
+  bool prog = false;
+  std::vector<int32_t> blk_lbase, blk_ubase, blk_prog;  // [nb + 1] first jagged L / U entry and first program word of every block
+  DevBuf<int32_t> d_blk_lbase, d_blk_ubase, d_blk_prog;
+  DevBuf<uint16_t> d_prog;
+  size_t prog_lds_bytes = 0;
+  int prog_max_vals = 0, prog_max_words = 0;
 };
 
 namespace {
@@ -140,6 +161,11 @@ struct IluDev {
   const int32_t *send_ptr, *send_local, *send_slot;
   double *send_buf;
   double *const *send_dst;  // push halo: per send slot the address in the neighbour's landing buffer (overrides send_buf)
+  // chunk-jagged layout
+  const int32_t *chunk_ptr;
+  const int4 *jf_desc, *jb_desc;
+  const uint32_t *jf_row, *jb_row;
+  const uint16_t *jl_col, *ju_col;
 };
 
 // ---- numeric factorisation of one row (ilu0_factor!, ilu0.jl:108-144) -----------------------------------------------
@@ -305,6 +331,87 @@ __global__ void ilu_factor_lds_kernel(IluDev F, const double *__restrict__ aval,
   for (int j = tid; j < nl * BB; j += T) F.l_val[(size_t)l0 * BB + j] = lv[j];
   for (int j = tid; j < nu * BB; j += T) F.u_val[(size_t)u0 * BB + j] = uv[j];
   for (int j = tid; j < nr * BB; j += T) F.dinv[(size_t)b0 * BB + j] = dv[j];  // already inverted
+}
+
+// ---- program-driven numeric factorisation into the chunk-jagged layout ------------------------------------------------------
+// ilu_factor_lds_kernel above finds every update pair of the IKJ elimination (ilu0.jl:108-144) by searching U rows in LDS --
+// counters (profiles/r02a): 87% of the wave cycles are waits, 165M scalar + 97M vector instructions per launch, 1.13 ms.  The
+// pattern is static, so the searches are done ONCE on the host: every row gets a short program over a unified block-local
+// value array  vals = [ L entries | U entries | pivots ]  (jagged order, so the final store is contiguous):
+//     per L entry (ascending column k):  lidx, kd, nupd, nupd x (tgt, src)
+//         l = vals[lidx] * vals[kd]       (kd: inverted pivot of row k);   vals[lidx] = l
+//         vals[tgt] -= l * vals[src]      (src: U entry (k, j); tgt: this row's entry / pivot in column j)
+//     then the row's pivot is inverted.
+// One workgroup per block: values gathered from A through the jagged maps, programs copied to LDS, rows of one dependency
+// level in parallel, barrier, next level; L, U and inverted pivots leave in the order the apply reads them.
+template <int BS>
+__global__ void ilu_factor_prog_kernel(IluDev F, const double *__restrict__ aval, const int32_t *__restrict__ lbase,
+                                       const int32_t *__restrict__ ubase, const int32_t *__restrict__ pbase,
+                                       const int32_t *__restrict__ jl_map, const int32_t *__restrict__ ju_map,
+                                       const int32_t *__restrict__ jd_map, const uint16_t *__restrict__ prog, int max_vals) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BB = BS * BS;
+  double *vals = reinterpret_cast<double *>(smem);
+  uint16_t *pw = reinterpret_cast<uint16_t *>(vals + (size_t)max_vals * BB);
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const int b0 = F.blk_ptr[b], nr = F.blk_ptr[b + 1] - b0;
+  const int l0 = lbase[b], nl = lbase[b + 1] - l0;
+  const int u0 = ubase[b], nu = ubase[b + 1] - u0;
+  const int c0 = F.chunk_ptr[b], nd = (F.chunk_ptr[b + 1] - c0) * 64;  // pivot slots (backward chunk lanes)
+  const int p0 = pbase[b], np = pbase[b + 1] - p0;
+  // gather through the maps, four entries per thread at a time: the map loads, then the dependent value loads, are in flight
+  // together (one entry per thread and iteration leaves the block waiting on two memory latencies per 128 entries)
+  auto gather = [&](const int32_t *map, int first, int count, int vbase) {
+    for (int j0 = tid; j0 < count; j0 += 4 * T) {
+      int m[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int j = j0 + u * T; m[u] = j < count ? map[first + j] : -1; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u * T;
+        if (j < count) {
+#pragma unroll
+          for (int e = 0; e < BB; ++e) vals[(size_t)(vbase + j) * BB + e] = m[u] >= 0 ? aval[(size_t)m[u] * BB + e] : 0.0;
+        }
+      }
+    }
+  };
+  gather(jl_map, l0, nl, 0);
+  gather(ju_map, u0, nu, nl);
+  gather(jd_map, c0 * 64, nd, nl + nu);
+  for (int j = tid; j < np; j += T) pw[j] = prog[p0 + j];
+  __syncthreads();
+  // program layout: [row offsets (nr + 1)] [pivot index of every row (nr)] [instructions]
+  const uint16_t *rptr = pw, *rdiag = pw + nr + 1, *code = pw + 2 * nr + 1;
+  const int lev0 = F.flev_off[b], nlev = F.flev_off[b + 1] - 1 - lev0;
+  for (int lev = 0; lev < nlev; ++lev) {
+    const int s = F.flev_ptr[lev0 + lev] - b0, e = F.flev_ptr[lev0 + lev + 1] - b0;
+    for (int t = s + tid; t < e; t += T) {
+      int pc = rptr[t];
+      const int pe = rptr[t + 1];
+      while (pc < pe) {
+        const int lidx = code[pc], kd = code[pc + 1], nupd = code[pc + 2];
+        pc += 3;
+        const Blk<BS> lik = blk_mul<BS>(blk_load<BS>(vals + (size_t)lidx * BB), blk_load<BS>(vals + (size_t)kd * BB));  // nz_l * inv(A_kk)
+        blk_store<BS>(vals + (size_t)lidx * BB, lik);
+        if (blk_nonzero<BS>(lik)) {
+          for (int u = 0; u < nupd; ++u) {
+            const int tgt = code[pc + 2 * u], src = code[pc + 2 * u + 1];
+            Blk<BS> v = blk_load<BS>(vals + (size_t)tgt * BB);
+            blk_sub<BS>(v, blk_mul<BS>(lik, blk_load<BS>(vals + (size_t)src * BB)));
+            blk_store<BS>(vals + (size_t)tgt * BB, v);
+          }
+        }
+        pc += 2 * nupd;
+      }
+      const int di = rdiag[t];
+      blk_store<BS>(vals + (size_t)di * BB, blk_inv<BS>(blk_load<BS>(vals + (size_t)di * BB)));
+    }
+    __syncthreads();
+  }
+  for (int j = tid; j < nl * BB; j += T) F.l_val[(size_t)l0 * BB + j] = vals[j];
+  for (int j = tid; j < nu * BB; j += T) F.u_val[(size_t)u0 * BB + j] = vals[(size_t)nl * BB + j];
+  for (int j = tid; j < nd * BB; j += T) F.dinv[(size_t)c0 * 64 * BB + j] = vals[(size_t)(nl + nu) * BB + j];
 }
 
 // LDS mode: one workgroup per block, levels separated by __syncthreads()
@@ -657,6 +764,187 @@ __global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const d
   }
 }
 
+// ---- chunk-jagged apply: the same one-wavefront-per-block sweep with the factor stored for it ---------------------------------
+// Counters on the row-major chunked kernel above (profiles/r02a: SQ_ACTIVE_INST_ANY x 7 waves/SIMD = 82% of the issue slots,
+// 3 500 instructions per wavefront for 512 rows) say it is bound by instruction issue, not by bytes: per-row pointer pairs,
+// per-entry predicated scattered loads, level bookkeeping.  Here the factor is stored the way the sweep consumes it:
+//   * a sweep (forward L / backward U) walks the block in chunks of 64 rows; inside a chunk the lanes are sorted by entry
+//     count and the entries are stored diagonal by diagonal (all first entries, all second entries, ...): lane l reads entry j
+//     at base_j + l -- unconditional, fully coalesced loads, no row pointers (8 bytes per row and sweep gone), no padding;
+//   * per chunk one 16-byte descriptor (entry base, eight one-byte diagonal counts, first / last level), read with scalar
+//     loads two chunks ahead; per lane one 32-bit word (block-local row | level << 16);
+//   * the entries and rows of chunk c+1 are in flight while chunk c is processed level by level out of registers and LDS;
+//     a lane's own right-hand side is read when its chunk starts (nobody else writes it).
+// Same arithmetic as fwd_row / bwd_row (ascending columns, inverted pivots), hence the same bits as the kernels above.
+template <int BS, int KU>
+struct JRow {
+  unsigned word;         // row | level << 16
+  int col[KU];
+  double val[KU * BS * BS];
+  double dinv[BS * BS];  // backward sweep only
+};
+template <int J>
+__device__ __forceinline__ int jd_count(const int4 &d) {
+  const unsigned w = J < 4 ? (unsigned)d.y : (unsigned)d.z;
+  return (int)((w >> (8 * (J & 3))) & 0xffu);
+}
+template <int BS, int KU, bool BWD>
+__device__ __forceinline__ void jds_load(const IluDev &F, const int4 &D, int chunk, int lane, JRow<BS, KU> &R) {
+  constexpr int BB = BS * BS;
+  const uint16_t *cols = BWD ? F.ju_col : F.jl_col;
+  const double *vals = BWD ? F.u_val : F.l_val;
+  R.word = (BWD ? F.jb_row : F.jf_row)[(size_t)chunk * 64 + lane];
+  int off = D.x;
+#define JH_JL(J)                                                                                          \
+  if (J < KU && jd_count<(J < 8 ? J : 0)>(D) > 0) { /* wave-uniform: the diagonal exists in this chunk */ \
+    R.col[J < KU ? J : 0] = (int)cols[off + lane]; /* lanes past the count read the next diagonal's */     \
+    _Pragma("unroll") for (int i = 0; i < BB; ++i) R.val[(J < KU ? J : 0) * BB + i] = vals[(size_t)(off + lane) * BB + i]; \
+    off += jd_count<(J < 8 ? J : 0)>(D);                                                                   \
+  }
+  JH_JL(0) JH_JL(1) JH_JL(2) JH_JL(3) JH_JL(4) JH_JL(5) JH_JL(6) JH_JL(7)
+#undef JH_JL
+  if (BWD) {
+#pragma unroll
+    for (int i = 0; i < BB; ++i) R.dinv[i] = F.dinv[((size_t)chunk * 64 + lane) * BB + i];
+  }
+}
+template <int BS, int KU, bool BWD>
+__device__ __forceinline__ void jds_sweep(const IluDev &F, double *xs, int c0, int nch, int lane) {
+  constexpr int BB = BS * BS;
+  const int4 *desc = BWD ? F.jb_desc : F.jf_desc;
+  int4 dc = desc[c0], dn = desc[c0 + 1], dnn;  // (the descriptor arrays are padded by two entries)
+  JRow<BS, KU> cur, nxt;
+  jds_load<BS, KU, BWD>(F, dc, c0, lane, cur);
+  for (int c = 0; c < nch; ++c) {
+    dnn = desc[c0 + c + 2];
+    if (c + 1 < nch) jds_load<BS, KU, BWD>(F, dn, c0 + c + 1, lane, nxt);
+    const int lt = (int)(cur.word & 0xffffu), lev = (int)(cur.word >> 16);
+    const int lvlo = dc.w & 0xffff, lvhi = (int)((unsigned)dc.w >> 16);
+    double v[BS];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) v[e] = xs[lt * BS + e];  // this row's right-hand side: only the row itself ever writes it
+    for (int lv = BWD ? lvlo : max(lvlo, 1); lv <= lvhi; ++lv) {  // forward: level-0 rows have no L entries, x = b
+      if (lev == lv) {
+#define JH_JC(J)                                                                                              \
+        if (J < KU && jd_count<(J < 8 ? J : 0)>(dc) > 0) {                                                   \
+          const int k = cur.col[J < KU ? J : 0];                                                             \
+          const bool a = lane < jd_count<(J < 8 ? J : 0)>(dc);                                               \
+          if (BS == 1) {                                                                                      \
+            const double t = v[0] - cur.val[J < KU ? J : 0] * xs[k];                                         \
+            v[0] = a ? t : v[0];                                                                              \
+          } else {                                                                                            \
+            _Pragma("unroll") for (int e = 0; e < BS; ++e) {                                                 \
+              double sum = 0.0;                                                                               \
+              _Pragma("unroll") for (int d = 0; d < BS; ++d) sum += cur.val[(J < KU ? J : 0) * BB + d * BS + e] * xs[k * BS + d]; \
+              v[e] = a ? v[e] - sum : v[e];                                                                   \
+            }                                                                                                 \
+          }                                                                                                   \
+        }
+        JH_JC(0) JH_JC(1) JH_JC(2) JH_JC(3) JH_JC(4) JH_JC(5) JH_JC(6) JH_JC(7)
+#undef JH_JC
+        if (BWD) {
+          if (BS == 1) {
+            xs[lt] = cur.dinv[0] * v[0];
+          } else {
+            double o[BS];
+#pragma unroll
+            for (int e = 0; e < BS; ++e) {
+              double sum = 0.0;
+#pragma unroll
+              for (int d = 0; d < BS; ++d) sum += cur.dinv[d * BS + e] * v[d];
+              o[e] = sum;
+            }
+#pragma unroll
+            for (int e = 0; e < BS; ++e) xs[lt * BS + e] = o[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < BS; ++e) xs[lt * BS + e] = v[e];
+        }
+      }
+      __syncthreads();  // one wavefront: orders this level's LDS writes before the next level's reads
+    }
+    dc = dn; dn = dnn;
+    cur = nxt;
+  }
+}
+
+template <int BS, int GM, int KU>
+__global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec, IluGather G) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];
+  if (GM == 2 && G.pub_rec && blockIdx.x == 0 && threadIdx.x == 0)
+    publish_record(G.sc_rw, G.pub_pair, G.pub_eps, G.pub_rec, G.pub_seq);  // raises the done flag on convergence
+  if (GM != 0 && G.done && *G.done != 0.0) return;  // speculative launch after the Krylov solve has converged
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
+  const int nr = b1 - b0;
+  const int c0 = F.chunk_ptr[b], nch = F.chunk_ptr[b + 1] - c0;
+  double ca = 0.0, cb = 0.0;
+  if (GM == 1) {
+    ca = G.sc[G.rho_slot] / G.sc[G.cv_slot];  // alpha
+  } else if (GM == 2) {
+    const double rho = G.sc[G.rho_slot], rho_next = G.sc[G.rho_next_slot];
+    const double alpha = rho / G.sc[G.cv_slot];
+    cb = G.sc[G.ts_slot + 1] == 0.0 ? 0.0 : G.sc[G.ts_slot] / G.sc[G.ts_slot + 1];  // omega (0/0 guard, see bicg_omega)
+    ca = (rho_next / rho) * (alpha / cb);        // beta
+  }
+  // the block's rows are the device rows [b0, b1): read coalesced in device order, dropped at their ilu position
+  for (int t = lane; t < nr; t += 64) {
+    const int dev = b0 + t;
+    const int pos = (int)F.rowmap16[dev];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) {
+      const size_t o = (size_t)dev * BS + e;
+      double v;
+      if (GM == 0) {
+        v = bvec[o];
+      } else if (GM == 1) {
+        v = (dev < G.n_owned_rows) ? G.r[o] - ca * G.q[o] : 0.0;
+        G.out[o] = v;
+      } else {
+        const double pa = G.out[o] - cb * G.q[o];
+        v = (dev < G.n_owned_rows) ? G.r[o] + ca * pa : 0.0;
+        G.out[o] = v;
+      }
+      xs[pos * BS + e] = v;
+    }
+  }
+  __syncthreads();
+  jds_sweep<BS, KU, false>(F, xs, c0, nch, lane);
+  jds_sweep<BS, KU, true>(F, xs, c0, nch, lane);
+  __syncthreads();
+  for (int t = lane; t < nr; t += 64) {
+    const int dev = b0 + t;
+    const int pos = (int)F.rowmap16[dev];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[pos * BS + e];
+  }
+  if (F.send_ptr) {  // rows that neighbouring ranks hold as ghosts go straight into the halo send buffer (no pack kernel)
+    for (int j = F.send_ptr[b] + lane; j < F.send_ptr[b + 1]; j += 64) {
+      const int t = F.send_local[j];
+      if (F.send_dst) {  // xGMI store into the receiving rank's landing buffer
+        double *dp = F.send_dst[F.send_slot[j]];
+#pragma unroll
+        for (int e = 0; e < BS; ++e) __hip_atomic_store(dp + e, xs[t * BS + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        const size_t o = (size_t)F.send_slot[j] * BS;
+#pragma unroll
+        for (int e = 0; e < BS; ++e) F.send_buf[o + e] = xs[t * BS + e];
+      }
+    }
+  }
+}
+
+// old (row-major) factor arrays -> chunk-jagged arrays, after a factor kernel that still writes the row-major order
+__global__ void ilu_jag_permute_kernel(double *__restrict__ dst, const double *__restrict__ src, const int32_t *__restrict__ pos, int64_t cnt, int bb) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cnt * bb; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = i / bb;
+    const int e = (int)(i - k * bb);
+    const int32_t p = pos[k];
+    if (p >= 0) dst[(size_t)p * bb + e] = src[i];
+  }
+}
+
 // GLOBAL mode kernels: x lives in HBM in ilu order
 template <int BS>
 __global__ void ilu_gather_kernel(double *xg, const double *bvec, const int32_t *rowmap, int64_t n, bool scatter) {
@@ -733,6 +1021,8 @@ IluDev dev_view(jh_ilu M) {
   F.l_col16 = M->d_l_col16.p; F.u_col16 = M->d_u_col16.p; F.u_row16 = M->d_u_row16.p; F.rowmap16 = M->d_rowmap16.p;
   F.l_val = M->l_val.p; F.u_val = M->u_val.p; F.dinv = M->dinv.p;
   F.send_ptr = nullptr; F.send_local = nullptr; F.send_slot = nullptr; F.send_buf = nullptr; F.send_dst = nullptr;
+  F.chunk_ptr = M->d_chunk_ptr.p; F.jf_desc = M->d_jf_desc.p; F.jb_desc = M->d_jb_desc.p;
+  F.jf_row = M->d_jf_row.p; F.jb_row = M->d_jb_row.p; F.jl_col = M->d_jl_col.p; F.ju_col = M->d_ju_col.p;
   return F;
 }
 
@@ -926,6 +1216,157 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       }
       M->halo_epoch = H.epoch;
     }
+    // one wavefront per small block keeps many blocks resident per CU (the level loop is latency-bound)
+    M->threads = maxrows <= 1024 ? 64 : (maxrows <= 2048 ? 128 : 256);
+    if (const char *e = getenv("JH_ILU_THREADS")) { int t = atoi(e); if (t == 64 || t == 128 || t == 256 || t == 512) M->threads = t; }
+    // ---- chunk-jagged layout (ilu_apply_jds_kernel): per sweep and 64-row chunk, lanes sorted by entry count, entries stored
+    // diagonal by diagonal.  Needs block-local 16-bit ids and at most 8 strict-L / strict-U entries per row.
+    if (lds && M->threads == 64 && maxrows < 65536 && maxlev < 0xffff && !getenv("JH_ILU_NO_JAGGED")) {
+      int maxcnt = 0;
+      for (int64_t t = 0; t < n; ++t) maxcnt = std::max({maxcnt, M->l_ptr[t + 1] - M->l_ptr[t], M->u_ptr[t + 1] - M->u_ptr[t]});
+      if (maxcnt <= 8) {
+        M->jag = true;
+        M->jag_ku = maxcnt <= 4 ? 4 : 8;
+        M->chunk_ptr.assign(nb + 1, 0);
+        for (int64_t b = 0; b < nb; ++b) M->chunk_ptr[b + 1] = M->chunk_ptr[b] + (M->blk_ptr[b + 1] - M->blk_ptr[b] + 63) / 64;
+        const int64_t nchunks = M->chunk_ptr[nb];
+        M->j_nslots = nchunks * 64;
+        std::vector<int4> fdesc(nchunks + 2, make_int4(0, 0, 0, 0)), bdesc(nchunks + 2, make_int4(0, 0, 0, 0));  // + 2: read ahead
+        std::vector<uint32_t> frow(M->j_nslots, 0xffff0000u), brow(M->j_nslots, 0xffff0000u);
+        std::vector<uint16_t> jlc, juc;
+        jlc.reserve(M->l_col.size() + 64); juc.reserve(M->u_col.size() + 64);
+        M->jl_map.clear(); M->ju_map.clear();
+        M->jd_map.assign(M->j_nslots, -1);
+        M->jl_of_old.assign(M->l_col.size(), -1); M->ju_of_old.assign(M->u_col.size(), -1); M->jd_of_old.assign(n, -1);
+        int lanes[64];
+        for (int64_t b = 0; b < nb; ++b) {
+          const int32_t b0 = M->blk_ptr[b], b1 = M->blk_ptr[b + 1];
+          for (int32_t c = 0; c < M->chunk_ptr[b + 1] - M->chunk_ptr[b]; ++c) {
+            const int64_t ch = M->chunk_ptr[b] + c;
+            const int32_t p0 = b0 + 64 * c, nrc = std::min(64, b1 - p0);
+            for (int sweep = 0; sweep < 2; ++sweep) {
+              const std::vector<int32_t> &ptr = sweep ? M->u_ptr : M->l_ptr;
+              std::iota(lanes, lanes + nrc, 0);
+              std::stable_sort(lanes, lanes + nrc, [&](int a, int c2) { return ptr[p0 + a + 1] - ptr[p0 + a] > ptr[p0 + c2 + 1] - ptr[p0 + c2]; });
+              std::vector<uint16_t> &jc = sweep ? juc : jlc;
+              std::vector<int32_t> &jm = sweep ? M->ju_map : M->jl_map;
+              std::vector<int32_t> &jold = sweep ? M->ju_of_old : M->jl_of_old;
+              const std::vector<int32_t> &ocol = sweep ? M->u_col : M->l_col, &omap = sweep ? M->u_map : M->l_map;
+              int4 D;
+              D.x = (int)jc.size();
+              unsigned cw[2] = {0, 0};
+              for (int j = 0; j < 8; ++j) {
+                int cn = 0;
+                for (int l = 0; l < nrc; ++l) {
+                  const int32_t p = p0 + lanes[l];
+                  if (ptr[p + 1] - ptr[p] <= j) break;  // sorted by count
+                  const int32_t old = ptr[p] + j;
+                  jold[old] = (int32_t)jc.size();
+                  jc.push_back((uint16_t)ocol[old]);
+                  jm.push_back(omap[old]);
+                  ++cn;
+                }
+                cw[j >> 2] |= (unsigned)cn << (8 * (j & 3));
+              }
+              D.y = (int)cw[0]; D.z = (int)cw[1];
+              int lo = 0xffff, hi = 0;
+              for (int l = 0; l < nrc; ++l) {
+                const int32_t p = p0 + lanes[l];  // ilu row (forward) or U-order position (backward)
+                const int lv = sweep ? (int)M->u_lev[p] : (int)M->l_lev[p];
+                const int lt = sweep ? M->u_row[p] : p - b0;
+                (sweep ? brow : frow)[ch * 64 + l] = (uint32_t)lt | ((uint32_t)lv << 16);
+                lo = std::min(lo, lv); hi = std::max(hi, lv);
+                if (sweep) { M->jd_map[ch * 64 + l] = M->d_map[p]; M->jd_of_old[p] = (int32_t)(ch * 64 + l); }
+              }
+              D.w = (int)((unsigned)lo | ((unsigned)hi << 16));
+              (sweep ? bdesc : fdesc)[ch] = D;
+            }
+          }
+        }
+        // ---- factorisation programs (ilu_factor_prog_kernel): the update pairs of the IKJ elimination, found once here -------
+        {
+          M->blk_lbase.assign(nb + 1, 0); M->blk_ubase.assign(nb + 1, 0); M->blk_prog.assign(nb + 1, 0);
+          for (int64_t b = 0; b < nb; ++b) { M->blk_lbase[b] = fdesc[M->chunk_ptr[b]].x; M->blk_ubase[b] = bdesc[M->chunk_ptr[b]].x; }
+          M->blk_lbase[nb] = (int32_t)jlc.size(); M->blk_ubase[nb] = (int32_t)juc.size();
+          std::vector<uint16_t> prog;
+          prog.reserve((size_t)n * 2 + M->l_col.size() * 5);
+          bool ok = true;
+          int max_vals = 0, max_words = 0;
+          std::vector<uint16_t> code;
+          for (int64_t b = 0; b < nb && ok; ++b) {
+            const int32_t b0 = M->blk_ptr[b], nrb = M->blk_ptr[b + 1] - b0;
+            const int32_t l0 = M->blk_lbase[b], nl = M->blk_lbase[b + 1] - l0, u0 = M->blk_ubase[b], nu = M->blk_ubase[b + 1] - u0;
+            const int32_t dslot0 = M->chunk_ptr[b] * 64, nd = (M->chunk_ptr[b + 1] - M->chunk_ptr[b]) * 64;
+            if (nl + nu + nd >= 65536) { ok = false; break; }
+            max_vals = std::max(max_vals, nl + nu + nd);
+            M->blk_prog[b] = (int32_t)prog.size();
+            const size_t head = prog.size();
+            prog.resize(head + 2 * (size_t)nrb + 1);  // row offsets (nrb + 1), pivot indices (nrb)
+            code.clear();
+            auto didx = [&](int32_t t) { return (uint16_t)(nl + nu + (M->jd_of_old[M->upos_of[t]] - dslot0)); };  // t: ilu row
+            for (int32_t lt = 0; lt < nrb; ++lt) {
+              const int32_t t = b0 + lt, ipos = M->upos_of[t];
+              prog[head + lt] = (uint16_t)code.size();
+              prog[head + nrb + 1 + lt] = didx(t);
+              const int32_t ls = M->l_ptr[t], le = M->l_ptr[t + 1], us = M->u_ptr[ipos], ue = M->u_ptr[ipos + 1];
+              for (int32_t p = ls; p < le; ++p) {
+                const int32_t k = M->l_col[p], kpos = M->upos_of[b0 + k];
+                code.push_back((uint16_t)(M->jl_of_old[p] - l0));
+                code.push_back(didx(b0 + k));
+                const size_t cnt_at = code.size();
+                code.push_back(0);
+                uint16_t nupd = 0;
+                for (int32_t q = M->u_ptr[kpos]; q < M->u_ptr[kpos + 1]; ++q) {  // U row k, ascending columns
+                  const int32_t j = M->u_col[q];
+                  int32_t tgt = -1;
+                  if (j == lt) {
+                    tgt = didx(t);
+                  } else if (j < lt) {  // a later strict-L entry of this row (process_partial_row! on rem_l_pos, ilu0.jl:100-106)
+                    for (int32_t p2 = p + 1; p2 < le; ++p2) if (M->l_col[p2] == j) { tgt = M->jl_of_old[p2] - l0; break; }
+                  } else {
+                    for (int32_t qi = us; qi < ue; ++qi) if (M->u_col[qi] == j) { tgt = nl + (M->ju_of_old[qi] - u0); break; }
+                  }
+                  if (tgt < 0) continue;  // (k, j) has no counterpart in row i: dropped fill, ILU(0)
+                  code.push_back((uint16_t)tgt);
+                  code.push_back((uint16_t)(nl + (M->ju_of_old[q] - u0)));
+                  ++nupd;
+                }
+                code[cnt_at] = nupd;
+              }
+              if (code.size() >= 65536) { ok = false; break; }
+            }
+            prog[head + nrb] = (uint16_t)code.size();
+            prog.insert(prog.end(), code.begin(), code.end());
+            max_words = std::max<int>(max_words, (int)(2 * (size_t)nrb + 1 + code.size()));
+          }
+          M->blk_prog[nb] = (int32_t)prog.size();
+          size_t bytes = sizeof(double) * P.bs * P.bs * (size_t)max_vals + sizeof(uint16_t) * (size_t)max_words;
+          bytes = (bytes + 15) & ~(size_t)15;
+          if (ok && bytes <= 160 * 1024 - 512 && !getenv("JH_ILU_NO_PROG")) {
+            M->prog = true;
+            M->prog_lds_bytes = bytes; M->prog_max_vals = max_vals; M->prog_max_words = max_words;
+            hipStream_t sp = M->ctx->stream;
+            M->d_blk_lbase.upload(M->blk_lbase, sp); M->d_blk_ubase.upload(M->blk_ubase, sp); M->d_blk_prog.upload(M->blk_prog, sp);
+            if (prog.empty()) prog.push_back(0);
+            M->d_prog.upload(prog, sp);
+          }
+        }
+        M->jl_nent = (int64_t)jlc.size(); M->ju_nent = (int64_t)juc.size();
+        jlc.resize(jlc.size() + 64, 0); juc.resize(juc.size() + 64, 0);  // lanes past a diagonal's count load too
+        hipStream_t sj = M->ctx->stream;
+        M->d_chunk_ptr.upload(M->chunk_ptr, sj);
+        M->d_jf_desc.upload(fdesc, sj); M->d_jb_desc.upload(bdesc, sj);
+        M->d_jf_row.upload(frow, sj); M->d_jb_row.upload(brow, sj);
+        M->d_jl_col.upload(jlc, sj); M->d_ju_col.upload(juc, sj);
+        M->d_jl_map.upload(M->jl_map, sj); M->d_ju_map.upload(M->ju_map, sj); M->d_jd_map.upload(M->jd_map, sj);
+        M->d_jl_of_old.upload(M->jl_of_old, sj); M->d_ju_of_old.upload(M->ju_of_old, sj); M->d_jd_of_old.upload(M->jd_of_old, sj);
+        const size_t bbj = (size_t)P.bs * P.bs;
+        M->jl_val.alloc((size_t)(M->jl_nent + 64) * bbj); M->ju_val.alloc((size_t)(M->ju_nent + 64) * bbj); M->jdinv.alloc((size_t)M->j_nslots * bbj);
+        JH_HIP(hipMemsetAsync(M->jl_val.p, 0, M->jl_val.n * sizeof(double), sj));
+        JH_HIP(hipMemsetAsync(M->ju_val.p, 0, M->ju_val.n * sizeof(double), sj));
+        JH_HIP(hipMemsetAsync(M->jdinv.p, 0, M->jdinv.n * sizeof(double), sj));
+      }
+    }
     // upload
     hipStream_t s = M->ctx->stream;
     if (lds) {  // 16-bit copies for the chunked apply
@@ -939,6 +1380,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
           rm[M->rowmap[t]] = (uint16_t)(t - M->blk_ptr[b]);  // device row -> position inside the block
         }
       M->d_l_col16.upload(lc, s); M->d_u_col16.upload(uc, s); M->d_u_row16.upload(ur, s); M->d_rowmap16.upload(rm, s);
+      if (!M->rowmap_local) M->jag = false;  // the jagged kernels read and write the vector in device order
+    } else {
+      M->jag = false;
     }
     if (!M->send_ptr.empty()) {
       M->d_send_ptr.upload(M->send_ptr, s); M->d_send_local.upload(M->send_local, s); M->d_send_slot.upload(M->send_slot, s);
@@ -951,14 +1395,13 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     M->d_u_ptr.upload(M->u_ptr, s); M->d_u_col.upload(M->u_col, s); M->d_u_map.upload(M->u_map, s);
     M->d_d_map.upload(M->d_map, s); M->d_u_row.upload(M->u_row, s); M->d_upos_of.upload(M->upos_of, s);
     const int bb = P.bs * P.bs;
-    M->l_val.alloc(std::max<size_t>(M->l_col.size(), 1) * bb);
-    M->u_val.alloc(std::max<size_t>(M->u_col.size(), 1) * bb);
-    M->dinv.alloc((size_t)n * bb);
+    if (!(M->jag && M->prog)) {  // row-major factor arrays: only for the kernels that still use them
+      M->l_val.alloc(std::max<size_t>(M->l_col.size(), 1) * bb);
+      M->u_val.alloc(std::max<size_t>(M->u_col.size(), 1) * bb);
+      M->dinv.alloc((size_t)n * bb);
+    }
     if (!lds) M->xg.alloc((size_t)n * P.bs);
     M->lds_bytes = lds ? (size_t)maxrows * P.bs * sizeof(double) : 0;
-    // one wavefront per small block keeps many blocks resident per CU (the level loop is latency-bound)
-    M->threads = maxrows <= 1024 ? 64 : (maxrows <= 2048 ? 128 : 256);
-    if (const char *e = getenv("JH_ILU_THREADS")) { int t = atoi(e); if (t == 64 || t == 128 || t == 256 || t == 512) M->threads = t; }
     JH_HIP(hipStreamSynchronize(s));
     *out = M.release();
   });
@@ -1005,6 +1448,33 @@ extern "C" int32_t jh_diag_precond_create(jh_csr A, int32_t kind, double w, jh_i
 }
 
 namespace jh {
+// row-major factor arrays -> chunk-jagged ones (factor kernels that still produce the row-major order)
+static void ilu_to_jagged(jh_ilu M) {
+  hipStream_t s = M->ctx->stream;
+  const int bb = M->bs * M->bs;
+  auto g = [](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096))); };
+  if (!M->l_col.empty())
+    hipLaunchKernelGGL(ilu_jag_permute_kernel, g((int64_t)M->l_col.size() * bb), dim3(256), 0, s, M->jl_val.p, M->l_val.p, M->d_jl_of_old.p, (int64_t)M->l_col.size(), bb);
+  if (!M->u_col.empty())
+    hipLaunchKernelGGL(ilu_jag_permute_kernel, g((int64_t)M->u_col.size() * bb), dim3(256), 0, s, M->ju_val.p, M->u_val.p, M->d_ju_of_old.p, (int64_t)M->u_col.size(), bb);
+  hipLaunchKernelGGL(ilu_jag_permute_kernel, g(M->n * bb), dim3(256), 0, s, M->jdinv.p, M->dinv.p, M->d_jd_of_old.p, M->n, bb);
+}
+// launches the chunk-jagged apply (GM as in ilu_apply_chunked_kernel)
+static void ilu_apply_jagged(jh_ilu M, IluDev F, const double *b, double *x, const IluGather &G) {
+  F.l_val = M->jl_val.p; F.u_val = M->ju_val.p; F.dinv = M->jdinv.p;
+  const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
+  hipStream_t s = M->ctx->stream;
+#define JH_J(BSV, GMV, KUV) hipLaunchKernelGGL((ilu_apply_jds_kernel<BSV, GMV, KUV>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x, G)
+#define JH_JK(BSV, GMV) do { if (M->jag_ku == 4) JH_J(BSV, GMV, 4); else JH_J(BSV, GMV, 8); } while (0)
+  switch (M->bs * 10 + G.mode) {
+    case 10: JH_JK(1, 0); break; case 11: JH_JK(1, 1); break; case 12: JH_JK(1, 2); break;
+    case 20: JH_JK(2, 0); break; case 21: JH_JK(2, 1); break; case 22: JH_JK(2, 2); break;
+    case 30: JH_JK(3, 0); break; case 31: JH_JK(3, 1); break; case 32: JH_JK(3, 2); break;
+    default: JH_THROW("bad jagged apply mode");
+  }
+#undef JH_JK
+#undef JH_J
+}
 void ilu_factor(jh_ilu M) {
   jh_context ctx = M->ctx;
   hipStream_t s = ctx->stream;
@@ -1021,17 +1491,35 @@ void ilu_factor(jh_ilu M) {
   }
   const int bb = M->bs * M->bs;
   const double *aval = M->A->val.p;
+  if (M->jag && M->prog) {  // straight into the chunk-jagged arrays
+    IluDev F = dev_view(M);
+    F.l_val = M->jl_val.p; F.u_val = M->ju_val.p; F.dinv = M->jdinv.p;
+    const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
+    static const int pthreads = getenv("JH_ILU_FACTOR_THREADS") ? atoi(getenv("JH_ILU_FACTOR_THREADS")) : 512;
+#define JH_PROG(BSV)                                                                                                             \
+    do {                                                                                                                          \
+      if (M->prog_lds_bytes > 64 * 1024)                                                                                          \
+        JH_HIP(hipFuncSetAttribute((const void *)ilu_factor_prog_kernel<BSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes)); \
+      hipLaunchKernelGGL(ilu_factor_prog_kernel<BSV>, dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
+                         M->d_blk_ubase.p, M->d_blk_prog.p, M->d_jl_map.p, M->d_ju_map.p, M->d_jd_map.p, M->d_prog.p, M->prog_max_vals); \
+    } while (0)
+    switch (M->bs) { case 1: JH_PROG(1); break; case 2: JH_PROG(2); break; case 3: JH_PROG(3); break; }
+#undef JH_PROG
+    M->factored = true;
+    return;
+  }
   if (M->lds_mode && M->factor_lds_bytes) {
     IluDev F = dev_view(M);
     const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
     const int mr = (int)M->max_block_rows;
     // the bulk load/store phases want many lanes (memory-level parallelism); the level loop only needs a few
-    static const int fthreads = getenv("JH_ILU_FACTOR_THREADS") ? atoi(getenv("JH_ILU_FACTOR_THREADS")) : 256;
+    static const int fthreads = getenv("JH_ILU_FACTOR_THREADS") ? atoi(getenv("JH_ILU_FACTOR_THREADS")) : 512;
     switch (M->bs) {
       case 1: hipLaunchKernelGGL(ilu_factor_lds_kernel<1>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr, (int)M->max_levels); break;
       case 2: hipLaunchKernelGGL(ilu_factor_lds_kernel<2>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr, (int)M->max_levels); break;
       case 3: hipLaunchKernelGGL(ilu_factor_lds_kernel<3>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr, (int)M->max_levels); break;
     }
+    if (M->jag) ilu_to_jagged(M);
     M->factored = true;
     return;
   }
@@ -1067,6 +1555,7 @@ void ilu_factor(jh_ilu M) {
     case 2: hipLaunchKernelGGL(ilu_invert_kernel<2>, gi, dim3(256), 0, s, M->dinv.p, M->n); break;
     case 3: hipLaunchKernelGGL(ilu_invert_kernel<3>, gi, dim3(256), 0, s, M->dinv.p, M->n); break;
   }
+  if (M->jag) ilu_to_jagged(M);
   M->factored = true;
 }
 
@@ -1084,6 +1573,7 @@ void ilu_apply(jh_ilu M, const double *b, double *x) {
   }
   IluDev F = dev_view(M);
   const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
+  if (M->jag) { ilu_apply_jagged(M, F, b, x, IluGather()); return; }
   if (M->lds_mode) {
     switch (M->bs) {
       case 1: hipLaunchKernelGGL(ilu_apply_blocks_pf_kernel<1>, dim3((unsigned)nb), dim3(M->threads), M->lds_bytes, s, F, b, x); break;
@@ -1136,6 +1626,7 @@ void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x, bool pack) {
     F.send_buf = M->A->disc->halo.d_send_buf.p;
     F.send_dst = halo_push_targets(M->A->disc);  // non-null when the push halo is enabled: the exchange that follows is a push
   }
+  if (M->jag) { ilu_apply_jagged(M, F, nullptr, x, G); return; }
   const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
 #define JH_FUSED(BSV, GMV) hipLaunchKernelGGL((ilu_apply_chunked_kernel<BSV, GMV>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, (const double *)nullptr, x, G)
   switch (M->bs * 10 + G.mode) {
@@ -1178,12 +1669,27 @@ extern "C" int32_t jh_ilu0_get_factor(jh_ilu M, double *lu) {
     if (M->kind != 0) JH_THROW("jh_ilu0_get_factor is for ILU(0) handles");
     const Pattern &P = *M->pat;
     const int bb = M->bs * M->bs;
+    auto hslot = [&](int32_t k) -> int64_t { return P.nz_hslot.empty() ? k : P.nz_hslot[k]; };
+    if (M->jag) {  // chunk-jagged storage: every entry knows the slot of A it came from
+      std::vector<double> l(M->jl_val.n), u(M->ju_val.n), d(M->jdinv.n);
+      JH_HIP(hipStreamSynchronize(M->ctx->stream));
+      JH_HIP(hipMemcpy(l.data(), M->jl_val.p, l.size() * sizeof(double), hipMemcpyDeviceToHost));
+      JH_HIP(hipMemcpy(u.data(), M->ju_val.p, u.size() * sizeof(double), hipMemcpyDeviceToHost));
+      JH_HIP(hipMemcpy(d.data(), M->jdinv.p, d.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (size_t j = 0; j < M->jl_map.size(); ++j)
+        for (int e = 0; e < bb; ++e) lu[hslot(M->jl_map[j]) * bb + e] = l[j * bb + e];
+      for (size_t j = 0; j < M->ju_map.size(); ++j)
+        for (int e = 0; e < bb; ++e) lu[hslot(M->ju_map[j]) * bb + e] = u[j * bb + e];
+      for (size_t j = 0; j < M->jd_map.size(); ++j)
+        if (M->jd_map[j] >= 0)
+          for (int e = 0; e < bb; ++e) lu[hslot(M->jd_map[j]) * bb + e] = d[j * bb + e];
+      return;
+    }
     std::vector<double> l(M->l_val.n), u(M->u_val.n), d(M->dinv.n);
     JH_HIP(hipStreamSynchronize(M->ctx->stream));
     JH_HIP(hipMemcpy(l.data(), M->l_val.p, l.size() * sizeof(double), hipMemcpyDeviceToHost));
     JH_HIP(hipMemcpy(u.data(), M->u_val.p, u.size() * sizeof(double), hipMemcpyDeviceToHost));
     JH_HIP(hipMemcpy(d.data(), M->dinv.p, d.size() * sizeof(double), hipMemcpyDeviceToHost));
-    auto hslot = [&](int32_t k) -> int64_t { return P.nz_hslot.empty() ? k : P.nz_hslot[k]; };
     for (size_t j = 0; j < M->l_map.size(); ++j)
       for (int e = 0; e < bb; ++e) lu[hslot(M->l_map[j]) * bb + e] = l[j * bb + e];
     for (size_t j = 0; j < M->u_map.size(); ++j)
