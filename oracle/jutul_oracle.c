@@ -520,6 +520,152 @@ int jo_fill_conservation_eq(int N, I64 nc, const I64 *facepos, const double *acc
   return 0;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* A.4b generic-AD alternatives (SURVEY a-7): (i) cell-based GenericAutoDiffCache, (ii) face-based */
+/*      PotentialFlow{:fvm}.  Independent formulations of the same residual / Jacobian, used as  */
+/*      the checker of the device path for runtime-defined laws (jh_law_create_custom).          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Dual whose partials are taken w.r.t. the N <= 3 primary variables of ONE entity (local_ad(state, var),
+ * equations.jl:562-566, new_entity_index :589-590): a state value of cell c is seeded iff c == var. */
+typedef struct { double v; double d[3]; } gdual;
+static inline gdual g_const(double v) { gdual r = {v, {0, 0, 0}}; return r; }
+static inline gdual g_add(gdual a, gdual b) { gdual r; r.v = a.v + b.v; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+static inline gdual g_sub(gdual a, gdual b) { gdual r; r.v = a.v - b.v; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+static inline gdual g_mul(gdual a, gdual b) { gdual r; r.v = a.v * b.v; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+static inline gdual g_scale(double s, gdual a) { gdual r; r.v = s * a.v; for (int i = 0; i < 3; ++i) r.d[i] = s * a.d[i]; return r; }
+static inline gdual g_adds(gdual a, double s) { a.v += s; return a; }
+static inline gdual g_exp(gdual a) { double e = exp(a.v); gdual r; r.v = e; for (int i = 0; i < 3; ++i) r.d[i] = e * a.d[i]; return r; }
+static inline gdual g_sqrt(gdual a) { double q = sqrt(a.v); gdual r; r.v = q; for (int i = 0; i < 3; ++i) r.d[i] = 0.5 * a.d[i] / q; return r; }
+/* flux.jl:335-405 */
+static inline gdual g_face_average(gdual a, gdual b) { return g_scale(0.5, g_add(a, b)); }
+static inline gdual g_potential_drop(gdual ps, gdual po, double gdz, gdual rs, gdual ro) { return g_add(g_sub(ps, po), g_scale(gdz, g_face_average(rs, ro))); }
+static inline gdual g_upwind(gdual drop, gdual vs, gdual vo) { return drop.v < 0.0 ? vo : vs; }
+
+/* The laws the device tests define as user source (tests/test_gpu_parity.py), restated on gdual:
+ *  law 1 "compressible" (N = 1), par = rho0, c, mu, p_ref:
+ *      rho(p) = rho0 exp(c (p - p_ref)); q = (T/mu) face_average(rho_s, rho_o) two_point_potential_drop(...); M = rho(p)
+ *  law 2 "reaction" (N = 2), par = a, b, k:
+ *      mob = a + face_average(v_s, v_o)^2; q_u = T (mob (u_s - u_o)); q_v = (b T)(v_s - v_o) + gdz upwind(v_s - v_o, v_s, v_o)
+ *      M_u = u + k u^3; M_v = sqrt(v) u */
+static void gen_flux(int law, const gdual *s, const gdual *o, double T, double gdz, const double *par, gdual *q) {
+  if (law == 1) {
+    gdual rs = g_scale(par[0], g_exp(g_scale(par[1], g_adds(s[0], -par[3]))));
+    gdual ro = g_scale(par[0], g_exp(g_scale(par[1], g_adds(o[0], -par[3]))));
+    gdual dphi = g_potential_drop(s[0], o[0], gdz, rs, ro);
+    q[0] = g_scale(T / par[2], g_mul(g_face_average(rs, ro), dphi));
+  } else {
+    gdual fa = g_face_average(s[1], o[1]);
+    gdual mob = g_adds(g_mul(fa, fa), par[0]);
+    q[0] = g_scale(T, g_mul(mob, g_sub(s[0], o[0])));
+    gdual dv = g_sub(s[1], o[1]);
+    q[1] = g_add(g_scale(par[1] * T, dv), g_scale(gdz, g_upwind(dv, s[1], o[1])));
+  }
+}
+static void gen_mass(int law, const gdual *x, const double *par, gdual *M) {
+  if (law == 1) {
+    M[0] = g_scale(par[0], g_exp(g_scale(par[1], g_adds(x[0], -par[3]))));
+  } else {
+    M[0] = g_add(x[0], g_scale(par[2], g_mul(x[0], g_mul(x[0], x[0]))));
+    M[1] = g_mul(g_sqrt(x[1]), x[0]);
+  }
+}
+/* state of cell c seen from the entity `var` the partials are taken for */
+static inline void gen_seed(int N, const double *X, I64 c, I64 var, gdual *x) {
+  for (int e = 0; e < N; ++e) { x[e] = g_const(X[(size_t)N * (c - 1) + e]); if (c == var) x[e].d[e] = 1.0; }
+}
+
+/* (i) inner_update_equation_for_entity (equations.jl:578-594) + fill_equation_entries_impl! (ad/generic.jl:53-96):
+ * for every cell i and every entry j of its stencil (the CSR row: var = colidx[j]) the WHOLE cell equation
+ *     R_i = vol_i (M(x_i) - M(x0_i)) / dt + sum over the half-faces of i of q(x_i, x_other)  (+ source value)
+ * is evaluated with duals seeded on `var`; the value of the diagonal entry is the residual, the partials of entry j are the
+ * Jacobian block (row i, column var).  No flux antisymmetry is used anywhere. */
+int jo_generic_cell_assemble(int law, int N, I64 nc, const I64 *facepos, const I64 *other, const I64 *face, const I64 *sign,
+                             const I64 *rowptr, const I64 *colidx, const double *X, const double *X0, const double *vol,
+                             const double *Tf, const double *gdz, double dt, const double *par, I64 nsrc, const I64 *src_cells,
+                             const double *src_vals, double *nz, double *r) {
+  if (N < 1 || N > 3 || (law != 1 && law != 2)) return -1;
+  const I64 NN = (I64)N * N;
+  double *srcv = (double *)calloc((size_t)nc * N, sizeof(double));
+  for (I64 k = 0; k < nsrc; ++k)
+    for (int e = 0; e < N; ++e) srcv[(size_t)(src_cells[k] - 1) * N + e] += src_vals[k * N + e];
+#pragma omp parallel for schedule(static)
+  for (I64 i = 1; i <= nc; ++i) {
+    for (I64 j = rowptr[i - 1]; j <= rowptr[i] - 1; ++j) {
+      const I64 var = colidx[j - 1];
+      gdual xi[3], x0i[3], M[3], M0[3], eq[3];
+      gen_seed(N, X, i, var, xi);
+      for (int e = 0; e < N; ++e) x0i[e] = g_const(X0[(size_t)N * (i - 1) + e]);
+      gen_mass(law, xi, par, M);
+      gen_mass(law, x0i, par, M0);
+      for (int e = 0; e < N; ++e) eq[e] = g_scale(vol[i - 1] / dt, g_sub(M[e], g_const(M0[e].v)));
+      for (I64 k = facepos[i - 1]; k <= facepos[i] - 1; ++k) {
+        gdual xo[3], q[3];
+        gen_seed(N, X, other[k - 1], var, xo);
+        const double gz = gdz ? (double)sign[k - 1] * gdz[face[k - 1] - 1] : 0.0;
+        gen_flux(law, xi, xo, Tf[face[k - 1] - 1], gz, par, q);
+        for (int e = 0; e < N; ++e) eq[e] = g_add(eq[e], q[e]);
+      }
+      for (int e = 0; e < N; ++e) {
+        if (var == i) r[(size_t)N * (i - 1) + e] = eq[e].v + srcv[(size_t)(i - 1) * N + e];  /* fill_residual on the diagonal entry */
+        for (int d = 0; d < N; ++d) nz[(size_t)(j - 1) * NN + (size_t)N * d + e] = eq[e].d[d];  /* update_jacobian_entry! */
+      }
+    }
+  }
+  free(srcv);
+  return 0;
+}
+
+/* (ii) face-based PotentialFlow{:fvm} assembly (conservation/fvm_assembly.jl:175-283): ONE flux per face (left -> right),
+ * differentiated w.r.t. each of its two stencil cells in turn; r[l] += q, r[r] -= q and the four Jacobian blocks
+ * (l,l) += dq/dl, (r,l) -= dq/dl, (l,r) += dq/dr, (r,r) -= dq/dr; accumulation + sources on the diagonal.  Serial scatter-add
+ * like the reference's loop.  N_lr: neighbourship [2, nf]. */
+int jo_fvm_face_assemble(int law, int N, I64 nc, I64 nf, const I64 *N_lr, const I64 *rowptr, const I64 *colidx, const double *X,
+                         const double *X0, const double *vol, const double *Tf, const double *gdz, double dt, const double *par,
+                         I64 nsrc, const I64 *src_cells, const double *src_vals, double *nz, double *r) {
+  if (N < 1 || N > 3 || (law != 1 && law != 2)) return -1;
+  const I64 NN = (I64)N * N;
+  memset(nz, 0, sizeof(double) * (size_t)(rowptr[nc] - 1) * NN);
+  memset(r, 0, sizeof(double) * (size_t)nc * N);
+  for (I64 c = 1; c <= nc; ++c) {  /* accumulation on the diagonal block */
+    gdual x[3], x0[3], M[3], M0[3];
+    gen_seed(N, X, c, c, x);
+    for (int e = 0; e < N; ++e) x0[e] = g_const(X0[(size_t)N * (c - 1) + e]);
+    gen_mass(law, x, par, M);
+    gen_mass(law, x0, par, M0);
+    I64 pos = find_sparse_position_csr(rowptr, colidx, c, c);
+    if (!pos) return -4;
+    for (int e = 0; e < N; ++e) {
+      gdual a = g_scale(vol[c - 1] / dt, g_sub(M[e], g_const(M0[e].v)));
+      r[(size_t)N * (c - 1) + e] += a.v;
+      for (int d = 0; d < N; ++d) nz[(size_t)(pos - 1) * NN + (size_t)N * d + e] += a.d[d];
+    }
+  }
+  for (I64 k = 0; k < nsrc; ++k)
+    for (int e = 0; e < N; ++e) r[(size_t)N * (src_cells[k] - 1) + e] += src_vals[k * N + e];
+  for (I64 f = 1; f <= nf; ++f) {
+    const I64 l = N_lr[2 * (f - 1)], rc = N_lr[2 * (f - 1) + 1];
+    const double gz = gdz ? gdz[f - 1] : 0.0;  /* stored left -> right */
+    for (int wrt = 0; wrt < 2; ++wrt) {
+      const I64 var = wrt == 0 ? l : rc;
+      gdual xl[3], xr[3], q[3];
+      gen_seed(N, X, l, var, xl);
+      gen_seed(N, X, rc, var, xr);
+      gen_flux(law, xl, xr, Tf[f - 1], gz, par, q);
+      I64 pl = find_sparse_position_csr(rowptr, colidx, l, var), pr = find_sparse_position_csr(rowptr, colidx, rc, var);
+      if (!pl || !pr) return -4;
+      for (int e = 0; e < N; ++e) {
+        if (wrt == 0) { r[(size_t)N * (l - 1) + e] += q[e].v; r[(size_t)N * (rc - 1) + e] -= q[e].v; }
+        for (int d = 0; d < N; ++d) {
+          nz[(size_t)(pl - 1) * NN + (size_t)N * d + e] += q[e].d[d];
+          nz[(size_t)(pr - 1) * NN + (size_t)N * d + e] -= q[e].d[d];
+        }
+      }
+    }
+  }
+  return 0;
+}
+
 /* convergence_criterion (equations.jl:619-629): per equation max_cells |r[e, :]| */
 int jo_convergence(int N, I64 nc, const double *r, I64 r_stride_e, I64 r_stride_c, double *e_out) {
   for (int e = 0; e < N; ++e) {

@@ -306,6 +306,38 @@ def fill_conservation_eq(nc, N, hfm, acc, hf, pos_acc, pos_flux, nnz_flat, equat
     return nz, r
 
 
+GEN_LAW = {"compressible": 1, "reaction": 2}
+
+
+def generic_cell_assemble(law, N, nc, hfm, rowptr, colidx, X, X0, vol, Tf, gdz, dt, par, src_cells=(), src_values=()):
+    """a-7 (i): cell-based GenericAutoDiffCache path (equations.jl:578-594, ad/generic.jl:53-96) for the user laws of the device
+    tests.  Returns (nz flat block-major, r [N, nc] flat)."""
+    nz = np.zeros(int(rowptr[-1] - 1) * N * N)
+    r = np.zeros(N * nc)
+    sc, sv = _i(src_cells), _f(np.asarray(src_values, dtype=np.float64).reshape(-1))
+    g = _f(gdz) if gdz is not None else None
+    _ck(lib().jo_generic_cell_assemble(C.c_int(GEN_LAW[law]), C.c_int(N), C.c_int64(nc), _pi(hfm["face_pos"]), _pi(hfm["other"]),
+                                       _pi(hfm["faces"]), _pi(hfm["face_sign"]), _pi(_i(rowptr)), _pi(_i(colidx)), _pf(_f(X)), _pf(_f(X0)),
+                                       _pf(_f(vol)), _pf(_f(Tf)), _pf(g), C.c_double(dt), _pf(_f(par)), C.c_int64(sc.size), _pi(sc), _pf(sv),
+                                       _pf(nz), _pf(r)), "generic_cell_assemble")
+    return nz, r
+
+
+def fvm_face_assemble(law, N, nc, Nlr, rowptr, colidx, X, X0, vol, Tf, gdz, dt, par, src_cells=(), src_values=()):
+    """a-7 (ii): face-based PotentialFlow{:fvm} assembly (conservation/fvm_assembly.jl:175-283)."""
+    Nlr = np.asarray(Nlr, dtype=np.int64)
+    nf = Nlr.shape[1]
+    nz = np.zeros(int(rowptr[-1] - 1) * N * N)
+    r = np.zeros(N * nc)
+    sc, sv = _i(src_cells), _f(np.asarray(src_values, dtype=np.float64).reshape(-1))
+    g = _f(gdz) if gdz is not None else None
+    Nf = _i(np.asfortranarray(Nlr).T.reshape(-1))
+    _ck(lib().jo_fvm_face_assemble(C.c_int(GEN_LAW[law]), C.c_int(N), C.c_int64(nc), C.c_int64(nf), _pi(Nf), _pi(_i(rowptr)), _pi(_i(colidx)),
+                                   _pf(_f(X)), _pf(_f(X0)), _pf(_f(vol)), _pf(_f(Tf)), _pf(g), C.c_double(dt), _pf(_f(par)),
+                                   C.c_int64(sc.size), _pi(sc), _pf(sv), _pf(nz), _pf(r)), "fvm_face_assemble")
+    return nz, r
+
+
 def convergence(N, nc, r, equation_major=False):
     e = np.zeros(N)
     se, sc = (nc, 1) if equation_major else (1, N)

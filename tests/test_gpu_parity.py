@@ -1028,6 +1028,12 @@ def test_custom_law_reproduces_the_builtin_compressible_law(ja, oracle):
         out.append((lsys.r.download(), np.array(lsys.jac.nzval)))
     np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-13, atol=1e-15)
     np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-13, atol=1e-15)
+    # independent checker: the oracle's cell-based generic-AD path (GenericAutoDiffCache, equations.jl:578-594, ad/generic.jl:53-96)
+    osys = oracle.TPFASystem(g["N"], nc)
+    nz_o, r_o = oracle.generic_cell_assemble("compressible", 1, nc, osys.hfm, osys.rowptr, osys.colidx, P, P0, g["volumes"], T, gdz, 0.7,
+                                             [1.3, 0.07, 0.9, 1.1], [3], [0.25])
+    np.testing.assert_allclose(out[1][0], r_o, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(out[1][1], nz_o, rtol=1e-12, atol=1e-14)
     # and a full Newton step converges with it
     law.set_state(P0)
     ok, its, _ = ja.Simulator(law, ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"),
@@ -1035,9 +1041,10 @@ def test_custom_law_reproduces_the_builtin_compressible_law(ja, oracle):
     assert ok and 2 <= its <= 8
 
 
-def test_custom_two_equation_law_jacobian_matches_finite_differences(ja):
-    """A law that is not built in (2 equations per cell): the dual-generated 2x2-block Jacobian == central differences of the
-    residual; conservation of the flux part; compile errors are reported."""
+def test_custom_two_equation_law_jacobian_matches_finite_differences(ja, oracle):
+    """A law that is not built in (2 equations per cell): residual and dual-generated 2x2-block Jacobian == the oracle's
+    cell-based generic-AD path slot by slot, and == central differences of the residual; conservation of the flux part;
+    compile errors are reported."""
     g = ja.tet_lattice_mesh(4, 4, 3)
     nc = g["nc"]
     T = g["T"] / g["T"].mean()
@@ -1059,6 +1066,13 @@ def test_custom_two_equation_law_jacobian_matches_finite_differences(ja):
 
     r0 = residual(X)
     A = lsys.jac  # Jacobian at X
+    osys = oracle.TPFASystem(g["N"], nc, nblk=2)
+    nz_o, r_o = oracle.generic_cell_assemble("reaction", 2, nc, osys.hfm, osys.rowptr, osys.colidx, X, X0, g["volumes"], T, gdz, dt,
+                                             [0.4, 0.7, 0.3])
+    np.testing.assert_allclose(r0, r_o, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(np.array(A.nzval), nz_o, rtol=1e-12, atol=1e-13)
+    nz_f, r_f = oracle.fvm_face_assemble("reaction", 2, nc, g["N"], osys.rowptr, osys.colidx, X, X0, g["volumes"], T, gdz, dt, [0.4, 0.7, 0.3])
+    np.testing.assert_allclose(np.array(A.nzval), nz_f, rtol=1e-12, atol=1e-13)  # face-based PotentialFlow{:fvm} form
     y = np.zeros(2 * nc)
     v = rng.standard_normal(2 * nc)
     Jv = ja.mul_(ja.DeviceVector(disc), A, ja.DeviceVector(disc, v)).download()
