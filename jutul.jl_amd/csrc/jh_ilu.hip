@@ -18,6 +18,7 @@
 // In both modes each row performs the reference's IKJ update sequence (ascending k, `L_ik = A_ik*inv(D_k)`,
 // inverted pivots stored at the end), so factors agree with the oracle to rounding.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <numeric>
 
@@ -1043,6 +1044,14 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     auto M = std::make_unique<jh_ilu_s>();
     M->ctx = A->ctx; M->A = A; M->pat = A->pat; M->bs = P.bs; M->n = n;
     JH_HIP(hipSetDevice(M->ctx->device));
+    const bool timing = getenv("JH_SETUP_TIMING") != nullptr;
+    auto tlast = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!timing) return;
+      auto nw = std::chrono::steady_clock::now();
+      fprintf(stderr, "[jutul_hip setup] ilu0: %-22s %.3f s\n", what, std::chrono::duration<double>(nw - tlast).count());
+      tlast = nw;
+    };
     // part id per device row
     std::vector<int32_t> part(n, 0);
     int64_t np = 1;
@@ -1088,6 +1097,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       }
       blev[i] = lv;
     }
+    lap("levels");
     // ilu ordering: LDS mode (part, flev, row); GLOBAL mode (flev, row)
     std::vector<int32_t> order(n);
     std::iota(order.begin(), order.end(), 0);
@@ -1108,6 +1118,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       M->blk_ptr = {0, (int32_t)n};
     }
     const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
+    lap("row sort");
     // level pointers: block b owns flev_ptr[flev_off[b] .. flev_off[b+1]) = level starts + one end sentinel,
     // i.e. level l of block b spans ilu rows [flev_ptr[flev_off[b]+l], flev_ptr[flev_off[b]+l+1])
     int64_t maxlev = 0;
@@ -1156,6 +1167,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       int64_t b = lds ? part[order[t]] : 0;
       M->u_row[pos] = t - M->blk_ptr[b];
     }
+    lap("level pointers, U order");
     // L (forward order) and U (backward order) storage
     M->l_ptr.assign(n + 1, 0);
     M->u_ptr.assign(n + 1, 0);
@@ -1176,6 +1188,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         if (part[P.col[k]] == part[i]) { M->u_col.push_back(ilu_of[P.col[k]] - b0); M->u_map.push_back(k); }
       M->u_ptr[pos + 1] = (int32_t)M->u_col.size();
     }
+    lap("L / U entries");
     if (lds) {
       int64_t mxl = 0, mxu = 0;
       for (int64_t b = 0; b < nb; ++b) {
@@ -1216,6 +1229,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       }
       M->halo_epoch = H.epoch;
     }
+    lap("sizes, halo lists");
     // one wavefront per small block keeps many blocks resident per CU (the level loop is latency-bound)
     M->threads = maxrows <= 1024 ? 64 : (maxrows <= 2048 ? 128 : 256);
     if (const char *e = getenv("JH_ILU_THREADS")) { int t = atoi(e); if (t == 64 || t == 128 || t == 256 || t == 512) M->threads = t; }
@@ -1233,81 +1247,80 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         M->j_nslots = nchunks * 64;
         std::vector<int4> fdesc(nchunks + 2, make_int4(0, 0, 0, 0)), bdesc(nchunks + 2, make_int4(0, 0, 0, 0));  // + 2: read ahead
         std::vector<uint32_t> frow(M->j_nslots, 0xffff0000u), brow(M->j_nslots, 0xffff0000u);
-        std::vector<uint16_t> jlc, juc;
-        jlc.reserve(M->l_col.size() + 64); juc.reserve(M->u_col.size() + 64);
-        M->jl_map.clear(); M->ju_map.clear();
+        // the jagged order permutes the entries inside a block: block b keeps the ranges [l_ptr[b0], l_ptr[b1]) / [u_ptr[b0], u_ptr[b1]),
+        // so the blocks can be laid out independently -- on all host cores
+        const size_t nlent = M->l_col.size(), nuent = M->u_col.size();
+        std::vector<uint16_t> jlc(nlent + 64, 0), juc(nuent + 64, 0);  // + 64: lanes past a diagonal's count load too
+        M->jl_map.assign(nlent, 0); M->ju_map.assign(nuent, 0);
         M->jd_map.assign(M->j_nslots, -1);
-        M->jl_of_old.assign(M->l_col.size(), -1); M->ju_of_old.assign(M->u_col.size(), -1); M->jd_of_old.assign(n, -1);
-        int lanes[64];
-        for (int64_t b = 0; b < nb; ++b) {
-          const int32_t b0 = M->blk_ptr[b], b1 = M->blk_ptr[b + 1];
-          for (int32_t c = 0; c < M->chunk_ptr[b + 1] - M->chunk_ptr[b]; ++c) {
-            const int64_t ch = M->chunk_ptr[b] + c;
-            const int32_t p0 = b0 + 64 * c, nrc = std::min(64, b1 - p0);
-            for (int sweep = 0; sweep < 2; ++sweep) {
-              const std::vector<int32_t> &ptr = sweep ? M->u_ptr : M->l_ptr;
-              std::iota(lanes, lanes + nrc, 0);
-              std::stable_sort(lanes, lanes + nrc, [&](int a, int c2) { return ptr[p0 + a + 1] - ptr[p0 + a] > ptr[p0 + c2 + 1] - ptr[p0 + c2]; });
-              std::vector<uint16_t> &jc = sweep ? juc : jlc;
-              std::vector<int32_t> &jm = sweep ? M->ju_map : M->jl_map;
-              std::vector<int32_t> &jold = sweep ? M->ju_of_old : M->jl_of_old;
-              const std::vector<int32_t> &ocol = sweep ? M->u_col : M->l_col, &omap = sweep ? M->u_map : M->l_map;
-              int4 D;
-              D.x = (int)jc.size();
-              unsigned cw[2] = {0, 0};
-              for (int j = 0; j < 8; ++j) {
-                int cn = 0;
-                for (int l = 0; l < nrc; ++l) {
-                  const int32_t p = p0 + lanes[l];
-                  if (ptr[p + 1] - ptr[p] <= j) break;  // sorted by count
-                  const int32_t old = ptr[p] + j;
-                  jold[old] = (int32_t)jc.size();
-                  jc.push_back((uint16_t)ocol[old]);
-                  jm.push_back(omap[old]);
-                  ++cn;
-                }
-                cw[j >> 2] |= (unsigned)cn << (8 * (j & 3));
-              }
-              D.y = (int)cw[0]; D.z = (int)cw[1];
-              int lo = 0xffff, hi = 0;
-              for (int l = 0; l < nrc; ++l) {
-                const int32_t p = p0 + lanes[l];  // ilu row (forward) or U-order position (backward)
-                const int lv = sweep ? (int)M->u_lev[p] : (int)M->l_lev[p];
-                const int lt = sweep ? M->u_row[p] : p - b0;
-                (sweep ? brow : frow)[ch * 64 + l] = (uint32_t)lt | ((uint32_t)lv << 16);
-                lo = std::min(lo, lv); hi = std::max(hi, lv);
-                if (sweep) { M->jd_map[ch * 64 + l] = M->d_map[p]; M->jd_of_old[p] = (int32_t)(ch * 64 + l); }
-              }
-              D.w = (int)((unsigned)lo | ((unsigned)hi << 16));
-              (sweep ? bdesc : fdesc)[ch] = D;
-            }
-          }
-        }
-        // ---- factorisation programs (ilu_factor_prog_kernel): the update pairs of the IKJ elimination, found once here -------
-        {
-          M->blk_lbase.assign(nb + 1, 0); M->blk_ubase.assign(nb + 1, 0); M->blk_prog.assign(nb + 1, 0);
-          for (int64_t b = 0; b < nb; ++b) { M->blk_lbase[b] = fdesc[M->chunk_ptr[b]].x; M->blk_ubase[b] = bdesc[M->chunk_ptr[b]].x; }
-          M->blk_lbase[nb] = (int32_t)jlc.size(); M->blk_ubase[nb] = (int32_t)juc.size();
-          std::vector<uint16_t> prog;
-          prog.reserve((size_t)n * 2 + M->l_col.size() * 5);
-          bool ok = true;
-          int max_vals = 0, max_words = 0;
+        M->jl_of_old.assign(nlent, -1); M->ju_of_old.assign(nuent, -1); M->jd_of_old.assign(n, -1);
+        M->blk_lbase.assign(nb + 1, 0); M->blk_ubase.assign(nb + 1, 0); M->blk_prog.assign(nb + 1, 0);
+        for (int64_t b = 0; b <= nb; ++b) { M->blk_lbase[b] = M->l_ptr[M->blk_ptr[b]]; M->blk_ubase[b] = M->u_ptr[M->blk_ptr[b]]; }
+        std::vector<std::vector<uint16_t>> progs(nb);  // factorisation program of every block (ilu_factor_prog_kernel)
+        std::vector<int> blk_vals(nb, 0);
+        std::vector<char> blk_ok(nb, 1);
+        parallel_ranges(nb, 16, [&](int64_t bb0, int64_t bb1) {
+          int lanes[64];
           std::vector<uint16_t> code;
-          for (int64_t b = 0; b < nb && ok; ++b) {
-            const int32_t b0 = M->blk_ptr[b], nrb = M->blk_ptr[b + 1] - b0;
+          for (int64_t b = bb0; b < bb1; ++b) {
+            const int32_t b0 = M->blk_ptr[b], b1 = M->blk_ptr[b + 1], nrb = b1 - b0;
+            int32_t wpos[2] = {M->blk_lbase[b], M->blk_ubase[b]};  // running jagged position of the forward / backward sweep
+            for (int32_t c = 0; c < M->chunk_ptr[b + 1] - M->chunk_ptr[b]; ++c) {
+              const int64_t ch = M->chunk_ptr[b] + c;
+              const int32_t p0 = b0 + 64 * c, nrc = std::min(64, b1 - p0);
+              for (int sweep = 0; sweep < 2; ++sweep) {
+                const std::vector<int32_t> &ptr = sweep ? M->u_ptr : M->l_ptr;
+                std::iota(lanes, lanes + nrc, 0);
+                std::stable_sort(lanes, lanes + nrc, [&](int a, int c2) { return ptr[p0 + a + 1] - ptr[p0 + a] > ptr[p0 + c2 + 1] - ptr[p0 + c2]; });
+                std::vector<uint16_t> &jc = sweep ? juc : jlc;
+                std::vector<int32_t> &jm = sweep ? M->ju_map : M->jl_map;
+                std::vector<int32_t> &jold = sweep ? M->ju_of_old : M->jl_of_old;
+                const std::vector<int32_t> &ocol = sweep ? M->u_col : M->l_col, &omap = sweep ? M->u_map : M->l_map;
+                int32_t &w = wpos[sweep];
+                int4 D;
+                D.x = (int)w;
+                unsigned cw[2] = {0, 0};
+                for (int j = 0; j < 8; ++j) {
+                  int cn = 0;
+                  for (int l = 0; l < nrc; ++l) {
+                    const int32_t p = p0 + lanes[l];
+                    if (ptr[p + 1] - ptr[p] <= j) break;  // sorted by count
+                    const int32_t old = ptr[p] + j;
+                    jold[old] = w;
+                    jc[w] = (uint16_t)ocol[old];
+                    jm[w] = omap[old];
+                    ++w;
+                    ++cn;
+                  }
+                  cw[j >> 2] |= (unsigned)cn << (8 * (j & 3));
+                }
+                D.y = (int)cw[0]; D.z = (int)cw[1];
+                int lo = 0xffff, hi = 0;
+                for (int l = 0; l < nrc; ++l) {
+                  const int32_t p = p0 + lanes[l];  // ilu row (forward) or U-order position (backward)
+                  const int lv = sweep ? (int)M->u_lev[p] : (int)M->l_lev[p];
+                  const int lt = sweep ? M->u_row[p] : p - b0;
+                  (sweep ? brow : frow)[ch * 64 + l] = (uint32_t)lt | ((uint32_t)lv << 16);
+                  lo = std::min(lo, lv); hi = std::max(hi, lv);
+                  if (sweep) { M->jd_map[ch * 64 + l] = M->d_map[p]; M->jd_of_old[p] = (int32_t)(ch * 64 + l); }
+                }
+                D.w = (int)((unsigned)lo | ((unsigned)hi << 16));
+                (sweep ? bdesc : fdesc)[ch] = D;
+              }
+            }
+            // ---- factorisation program: the update pairs of the IKJ elimination (ilu0.jl:108-144), found once here ----------
             const int32_t l0 = M->blk_lbase[b], nl = M->blk_lbase[b + 1] - l0, u0 = M->blk_ubase[b], nu = M->blk_ubase[b + 1] - u0;
             const int32_t dslot0 = M->chunk_ptr[b] * 64, nd = (M->chunk_ptr[b + 1] - M->chunk_ptr[b]) * 64;
-            if (nl + nu + nd >= 65536) { ok = false; break; }
-            max_vals = std::max(max_vals, nl + nu + nd);
-            M->blk_prog[b] = (int32_t)prog.size();
-            const size_t head = prog.size();
-            prog.resize(head + 2 * (size_t)nrb + 1);  // row offsets (nrb + 1), pivot indices (nrb)
+            blk_vals[b] = nl + nu + nd;
+            if (nl + nu + nd >= 65536) { blk_ok[b] = 0; continue; }
+            std::vector<uint16_t> &prog = progs[b];
+            prog.assign(2 * (size_t)nrb + 1, 0);  // row offsets (nrb + 1), pivot indices (nrb)
             code.clear();
             auto didx = [&](int32_t t) { return (uint16_t)(nl + nu + (M->jd_of_old[M->upos_of[t]] - dslot0)); };  // t: ilu row
-            for (int32_t lt = 0; lt < nrb; ++lt) {
+            for (int32_t lt = 0; lt < nrb && blk_ok[b]; ++lt) {
               const int32_t t = b0 + lt, ipos = M->upos_of[t];
-              prog[head + lt] = (uint16_t)code.size();
-              prog[head + nrb + 1 + lt] = didx(t);
+              prog[lt] = (uint16_t)code.size();
+              prog[nrb + 1 + lt] = didx(t);
               const int32_t ls = M->l_ptr[t], le = M->l_ptr[t + 1], us = M->u_ptr[ipos], ue = M->u_ptr[ipos + 1];
               for (int32_t p = ls; p < le; ++p) {
                 const int32_t k = M->l_col[p], kpos = M->upos_of[b0 + k];
@@ -1333,26 +1346,40 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
                 }
                 code[cnt_at] = nupd;
               }
-              if (code.size() >= 65536) { ok = false; break; }
+              if (code.size() >= 65536) blk_ok[b] = 0;
             }
-            prog[head + nrb] = (uint16_t)code.size();
+            prog[nrb] = (uint16_t)code.size();
             prog.insert(prog.end(), code.begin(), code.end());
-            max_words = std::max<int>(max_words, (int)(2 * (size_t)nrb + 1 + code.size()));
           }
-          M->blk_prog[nb] = (int32_t)prog.size();
+        });
+        {
+          bool ok = true;
+          int max_vals = 0, max_words = 0;
+          size_t total = 0;
+          for (int64_t b = 0; b < nb; ++b) {
+            ok = ok && blk_ok[b];
+            max_vals = std::max(max_vals, blk_vals[b]);
+            max_words = std::max<int>(max_words, (int)progs[b].size());
+            M->blk_prog[b] = (int32_t)total;
+            total += progs[b].size();
+          }
+          M->blk_prog[nb] = (int32_t)total;
           size_t bytes = sizeof(double) * P.bs * P.bs * (size_t)max_vals + sizeof(uint16_t) * (size_t)max_words;
           bytes = (bytes + 15) & ~(size_t)15;
-          if (ok && bytes <= 160 * 1024 - 512 && !getenv("JH_ILU_NO_PROG")) {
+          if (ok && total < (size_t)INT32_MAX && bytes <= 160 * 1024 - 512 && !getenv("JH_ILU_NO_PROG")) {
+            std::vector<uint16_t> prog(std::max<size_t>(total, 1), 0);
+            parallel_ranges(nb, 64, [&](int64_t bb0, int64_t bb1) {
+              for (int64_t b = bb0; b < bb1; ++b)
+                if (!progs[b].empty()) std::copy(progs[b].begin(), progs[b].end(), prog.begin() + M->blk_prog[b]);
+            });
             M->prog = true;
             M->prog_lds_bytes = bytes; M->prog_max_vals = max_vals; M->prog_max_words = max_words;
             hipStream_t sp = M->ctx->stream;
             M->d_blk_lbase.upload(M->blk_lbase, sp); M->d_blk_ubase.upload(M->blk_ubase, sp); M->d_blk_prog.upload(M->blk_prog, sp);
-            if (prog.empty()) prog.push_back(0);
             M->d_prog.upload(prog, sp);
           }
         }
-        M->jl_nent = (int64_t)jlc.size(); M->ju_nent = (int64_t)juc.size();
-        jlc.resize(jlc.size() + 64, 0); juc.resize(juc.size() + 64, 0);  // lanes past a diagonal's count load too
+        M->jl_nent = (int64_t)nlent; M->ju_nent = (int64_t)nuent;
         hipStream_t sj = M->ctx->stream;
         M->d_chunk_ptr.upload(M->chunk_ptr, sj);
         M->d_jf_desc.upload(fdesc, sj); M->d_jb_desc.upload(bdesc, sj);
@@ -1367,6 +1394,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         JH_HIP(hipMemsetAsync(M->jdinv.p, 0, M->jdinv.n * sizeof(double), sj));
       }
     }
+    lap("jagged layout + programs");
     // upload
     hipStream_t s = M->ctx->stream;
     if (lds) {  // 16-bit copies for the chunked apply
@@ -1403,6 +1431,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     if (!lds) M->xg.alloc((size_t)n * P.bs);
     M->lds_bytes = lds ? (size_t)maxrows * P.bs * sizeof(double) : 0;
     JH_HIP(hipStreamSynchronize(s));
+    lap("upload");
     *out = M.release();
   });
 }

@@ -2,9 +2,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <exception>
 #include <memory>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -39,6 +43,24 @@ static inline int32_t guard(F &&f) noexcept {
     set_error("unknown error");
     return -2;
   }
+}
+
+// ---- host-side parallel loop for the set-up phases (integer work over independent rows / blocks) ------------------------------
+// fn(begin, end) on contiguous index ranges, one per hardware thread (at most 64); exceptions are rethrown on the caller.
+template <class F>
+static inline void parallel_ranges(int64_t n, int64_t min_per_thread, F &&fn) {
+  int64_t nt = (int64_t)std::thread::hardware_concurrency();
+  if (const char *e = getenv("JH_SETUP_THREADS")) nt = atoi(e);
+  nt = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nt, 64), n / std::max<int64_t>(1, min_per_thread)));
+  if (nt <= 1) { fn((int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err((size_t)nt);
+  for (int64_t t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      try { fn(n * t / nt, n * (t + 1) / nt); } catch (...) { err[(size_t)t] = std::current_exception(); }
+    });
+  for (auto &x : th) x.join();
+  for (auto &e : err) if (e) std::rethrow_exception(e);
 }
 
 // ---- tiling constants for the CSR row-segment kernels ------------------------------------------------

@@ -1,6 +1,7 @@
 // Host-side setup of the TPFA discretisation: connectivity (a-1), pattern (a-3), positions (a-4), device
 // ordering, CSR tiles.  Runs once per Simulator setup; everything here is integer work.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <numeric>
 #include <queue>
@@ -245,6 +246,20 @@ static void order_by_partition(const Adj &A, int64_t nc, const int64_t *partitio
 
 using namespace jh;
 
+namespace {
+// JH_SETUP_TIMING=1: seconds per set-up phase on stderr
+struct PhaseTimer {
+  bool on = getenv("JH_SETUP_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[jutul_hip setup] %-28s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+}  // namespace
+
 // --------------------------------------------------------------------------------------------------------------
 // jh_tpfa_create
 // --------------------------------------------------------------------------------------------------------------
@@ -267,8 +282,10 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
     d->nf = nf;
     d->nhf = 2 * nf;
     d->N = block_n;
+    PhaseTimer pt;
     d->Nhost.assign(N, N + 2 * nf);
     Adj A = build_adjacency(nc, nf, N);
+    pt.lap("adjacency");
     if (n_owned <= 0 || n_owned > nc) n_owned = nc;
 
     auto pat = std::make_shared<Pattern>();
@@ -285,6 +302,7 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
     } else if (reorder != JH_REORDER_NONE) {
       JH_THROW("unknown reorder mode");
     }
+    pt.lap("device ordering (blocks)");
     bool ident = pat->perm.empty();
     if (!ident)
       for (int64_t i = n_owned; i < nc; ++i)
@@ -309,34 +327,39 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
     std::vector<int64_t> hrp(nc + 1, 0);
     for (int64_t h = 0; h < nc; ++h) hrp[h + 1] = hrp[h] + (A.ptr[h + 1] - A.ptr[h]) + 1;
     if (!ident) pat->nz_hslot.resize(pat->nnzb);
-    std::vector<std::pair<int32_t, int32_t>> tmp, tmph;
-    for (int64_t i = 0; i < nc; ++i) {
-      int64_t h = ident ? i : pat->perm[i];
-      tmp.clear();
-      tmp.emplace_back((int32_t)i, 0);
-      for (int64_t k = A.ptr[h]; k < A.ptr[h + 1]; ++k)
-        tmp.emplace_back(ident ? A.nbr[k] : pat->iperm[A.nbr[k]], A.sface[k]);
-      std::sort(tmp.begin(), tmp.end());
-      int32_t base = pat->rowptr[i];
-      for (size_t j = 0; j < tmp.size(); ++j) {
-        if (j > 0 && tmp[j].first == tmp[j - 1].first)
-          JH_THROW("two faces connect the same pair of cells: multigraph neighborships are not supported");
-        pat->col[base + j] = tmp[j].first;
-        d->nz_face[base + j] = tmp[j].second;
-        if (tmp[j].first == (int32_t)i) pat->diag[i] = base + (int32_t)j;
+    // rows are independent: sorted device columns, signed face ids, diagonal slot, host slots -- on all host cores
+    parallel_ranges(nc, 4096, [&](int64_t r_begin, int64_t r_end) {
+      std::vector<std::pair<int32_t, int32_t>> tmp, tmph;
+      for (int64_t i = r_begin; i < r_end; ++i) {
+        int64_t h = ident ? i : pat->perm[i];
+        tmp.clear();
+        tmp.emplace_back((int32_t)i, 0);
+        for (int64_t k = A.ptr[h]; k < A.ptr[h + 1]; ++k)
+          tmp.emplace_back(ident ? A.nbr[k] : pat->iperm[A.nbr[k]], A.sface[k]);
+        std::sort(tmp.begin(), tmp.end());
+        int32_t base = pat->rowptr[i];
+        for (size_t j = 0; j < tmp.size(); ++j) {
+          if (j > 0 && tmp[j].first == tmp[j - 1].first)
+            JH_THROW("two faces connect the same pair of cells: multigraph neighborships are not supported");
+          pat->col[base + j] = tmp[j].first;
+          d->nz_face[base + j] = tmp[j].second;
+          if (tmp[j].first == (int32_t)i) pat->diag[i] = base + (int32_t)j;
+        }
+        if (!ident) {
+          // host slot = position of host column in host row h (ascending host columns incl. diagonal)
+          tmph.clear();
+          for (size_t j = 0; j < tmp.size(); ++j) tmph.emplace_back(pat->perm[tmp[j].first], (int32_t)j);
+          std::sort(tmph.begin(), tmph.end());
+          for (size_t j = 0; j < tmph.size(); ++j) pat->nz_hslot[base + tmph[j].second] = (int32_t)(hrp[h] + j);
+        }
       }
-      if (!ident) {
-        // host slot = position of host column in host row h (ascending host columns incl. diagonal)
-        tmph.clear();
-        for (size_t j = 0; j < tmp.size(); ++j) tmph.emplace_back(pat->perm[tmp[j].first], (int32_t)j);
-        std::sort(tmph.begin(), tmph.end());
-        for (size_t j = 0; j < tmph.size(); ++j) pat->nz_hslot[base + tmph[j].second] = (int32_t)(hrp[h] + j);
-      }
-    }
+    });
     for (int64_t i = 0; i < nc; ++i)
       if (pat->rowptr[i + 1] - pat->rowptr[i] > TILE_NNZ / 2) JH_THROW("cell with more than 511 faces is not supported");
+    pt.lap("device CSR pattern");
     pat->build_tiles();
     pat->upload();
+    pt.lap("tiles + upload");
     d->d_nz_face.upload(d->nz_face, ctx->stream);
     JH_HIP(hipStreamSynchronize(ctx->stream));
     d->pat = pat;
