@@ -55,7 +55,10 @@ int32_t jh_timer_stop_ms(jh_context ctx, double *ms);
 /* TwoPointPotentialFlowHardCoded(N, nc) (flux.jl:172-190) via get_facepos (utils.jl:813-874) and
  * get_connection (flux.jl:128-142); CSR pattern per declare_pattern (conservation.jl:486-505) +
  * static_sparsity_sparse (StaticCSR/mat.jl:73-76).
- * N: 2 x nf neighborship, column-major, 1-based.  block_n: equations = primary variables per cell.
+ * N: 2 x nf neighborship, column-major, 1-based; several faces between one cell pair are accepted with the reference's
+ * semantics (one pattern entry per pair, residual / diagonal sum all faces, the off-diagonal holds the last face's derivative:
+ * sparse() merge + plain assignment per half-face, conservation.jl:486-505, ad.jl:74-76).  block_n: equations = primary
+ * variables per cell.
  * partition (may be NULL): nc entries, 1-based part id per cell; cells of one part become contiguous on the
  * device (used as the block-Jacobi ILU(0) partition, precond/ilu.jl:37-60).  block_rows: target rows per
  * automatically grown block when partition == NULL and reorder == JH_REORDER_BLOCKS (0 = default: 512, or 256

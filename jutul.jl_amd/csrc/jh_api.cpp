@@ -206,6 +206,7 @@ extern "C" int32_t jh_csr_create_from_pattern(jh_context ctx, int64_t n, int32_t
     pat->n = n;
     pat->bs = bs;
     pat->nnzb = rowptr[n] - 1;
+    pat->nnzb_host = pat->nnzb;
     if (pat->nnzb > 2000000000LL) JH_THROW("too many non-zeros for 32-bit device indices");
     pat->rowptr.resize(n + 1);
     pat->col.resize(pat->nnzb);
@@ -239,7 +240,7 @@ extern "C" int32_t jh_csr_sizes(jh_csr A, int64_t *n, int64_t *nnzb, int32_t *bs
   return guard([&] {
     if (!A) JH_THROW("null handle");
     if (n) *n = A->pat->n;
-    if (nnzb) *nnzb = A->pat->nnzb;
+    if (nnzb) *nnzb = A->pat->nnzb_host;
     if (bs) *bs = A->pat->bs;
   });
 }
@@ -250,12 +251,13 @@ extern "C" int32_t jh_csr_set_values(jh_csr A, const double *nz) {
     JH_HIP(hipSetDevice(ctx->device));
     const Pattern &P = *A->pat;
     int bb = P.bs * P.bs;
-    size_t cnt = (size_t)P.nnzb * bb;
+    size_t cnt = (size_t)P.nnzb_host * bb;  // the host pattern; shadow slots of a multigraph read the zeroed spare slot behind it
     if (P.nz_hslot.empty()) {
       JH_HIP(hipMemcpyAsync(A->val.p, nz, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     } else {
-      ctx->ensure_stage(cnt);
+      ctx->ensure_stage(cnt + bb);
       JH_HIP(hipMemcpyAsync(ctx->stage.p, nz, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      JH_HIP(hipMemsetAsync(ctx->stage.p + cnt, 0, bb * sizeof(double), ctx->stream));
       k_gather_blocks(ctx->stream, A->val.p, ctx->stage.p, P.d_nz_hslot.p, P.nnzb, bb, false);
     }
     JH_HIP(hipStreamSynchronize(ctx->stream));
@@ -268,11 +270,11 @@ extern "C" int32_t jh_csr_get_values(jh_csr A, double *nz) {
     JH_HIP(hipSetDevice(ctx->device));
     const Pattern &P = *A->pat;
     int bb = P.bs * P.bs;
-    size_t cnt = (size_t)P.nnzb * bb;
+    size_t cnt = (size_t)P.nnzb_host * bb;
     if (P.nz_hslot.empty()) {
       JH_HIP(hipMemcpyAsync(nz, A->val.p, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     } else {
-      ctx->ensure_stage(cnt);
+      ctx->ensure_stage(cnt + bb);  // + the spare slot the shadow slots of a multigraph scatter into
       k_gather_blocks(ctx->stream, ctx->stage.p, A->val.p, P.d_nz_hslot.p, P.nnzb, bb, true);
       JH_HIP(hipMemcpyAsync(nz, ctx->stage.p, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }
@@ -510,7 +512,7 @@ extern "C" int32_t jh_tpfa_get_pattern_layout(jh_tpfa d, int32_t layout, int64_t
     if (layout == JH_LAYOUT_BLOCK_MAJOR || d->N == 1) { check(jh_tpfa_get_pattern(d, rowptr, colidx)); return; }
     d->build_tables();
     const int N = d->N;
-    const int64_t nc = d->nc, nnzb = d->nnzb;
+    const int64_t nc = d->nc, nnzb = d->pat->nnzb_host;
     for (int64_t i = 0; i < nc; ++i) {
       const int64_t rp = d->h_rowptr[i] - 1, len = d->h_rowptr[i + 1] - d->h_rowptr[i];
       for (int e = 0; e < N; ++e) {
@@ -536,7 +538,7 @@ extern "C" int32_t jh_tpfa_get_positions_layout(jh_tpfa d, int32_t layout, int64
     if (layout == JH_LAYOUT_BLOCK_MAJOR || d->N == 1) { check(jh_tpfa_get_positions(d, pos_acc, pos_flux)); return; }
     d->build_tables();
     const int N = d->N;
-    const int64_t NN = (int64_t)N * N, nnzb = d->nnzb;
+    const int64_t NN = (int64_t)N * N, nnzb = d->pat->nnzb_host;
     auto conv = [&](const std::vector<int64_t> &blk, int64_t count, int64_t *out, auto row_of) {
       if (!out) return;
       for (int64_t idx = 0; idx < count; ++idx) {
@@ -555,7 +557,7 @@ extern "C" int32_t jh_tpfa_get_positions_layout(jh_tpfa d, int32_t layout, int64
 static void values_layout(jh_csr A, int layout, double *nz, bool to_host) {
   const Pattern &P = *A->pat;
   const int N = P.bs;
-  const int64_t NN = (int64_t)N * N, nnzb = P.nnzb;
+  const int64_t NN = (int64_t)N * N, nnzb = P.nnzb_host;
   std::vector<double> blk((size_t)nnzb * NN);
   std::vector<int64_t> rp = host_block_rowptr(A);
   if (to_host) check(jh_csr_get_values(A, blk.data()));

@@ -442,6 +442,7 @@ void k_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
     if (L->nsrc)
       hipLaunchKernelGGL(sources_kernel, dim3((unsigned)((L->nsrc * L->N + 255) / 256)), dim3(256), 0, ctx->stream, r->d.p,
                          L->src_cell.p, L->src_val.p, L->nsrc, L->N);
+    k_zero_slots(ctx->stream, A->val.p, P.d_shadow_slots.p, (int64_t)P.shadow_slots.size(), P.bs * P.bs);
     return;
   }
   LawPar par;
@@ -475,6 +476,8 @@ void k_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
   if (L->nsrc)
     hipLaunchKernelGGL(sources_kernel, dim3((unsigned)((L->nsrc * L->N + 255) / 256)), dim3(256), 0, ctx->stream, r->d.p,
                        L->src_cell.p, L->src_val.p, L->nsrc, L->N);
+  // multigraph neighbourships: only the last parallel face's off-diagonal is stored (Pattern::shadow_slots)
+  k_zero_slots(ctx->stream, A->val.p, P.d_shadow_slots.p, (int64_t)P.shadow_slots.size(), P.bs * P.bs);
 }
 
 // update_primary_variables! / choose_increment (variables/utils.jl:146-174): scale -> abs -> rel -> lower -> upper

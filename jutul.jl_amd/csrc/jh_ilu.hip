@@ -1175,8 +1175,8 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     for (int64_t t = 0; t < n; ++t) {
       int32_t i = order[t];
       int32_t b0 = M->blk_ptr[lds ? part[i] : 0];
-      for (int32_t k = P.rowptr[i]; k < P.diag[i]; ++k)
-        if (part[P.col[k]] == part[i]) { M->l_col.push_back(ilu_of[P.col[k]] - b0); M->l_map.push_back(k); }
+      for (int32_t k = P.rowptr[i]; k < P.diag[i]; ++k)  // (shadow slots of a multigraph pattern hold no value: Pattern::shadow_slots)
+        if (part[P.col[k]] == part[i] && !P.is_shadow(k)) { M->l_col.push_back(ilu_of[P.col[k]] - b0); M->l_map.push_back(k); }
       M->l_ptr[t + 1] = (int32_t)M->l_col.size();
     }
     for (int64_t pos = 0; pos < n; ++pos) {
@@ -1185,7 +1185,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       int32_t b0 = M->blk_ptr[lds ? part[i] : 0];
       M->d_map[pos] = P.diag[i];
       for (int32_t k = P.diag[i] + 1; k < P.rowptr[i + 1]; ++k)
-        if (part[P.col[k]] == part[i]) { M->u_col.push_back(ilu_of[P.col[k]] - b0); M->u_map.push_back(k); }
+        if (part[P.col[k]] == part[i] && !P.is_shadow(k)) { M->u_col.push_back(ilu_of[P.col[k]] - b0); M->u_map.push_back(k); }
       M->u_ptr[pos + 1] = (int32_t)M->u_col.size();
     }
     lap("L / U entries");

@@ -156,7 +156,17 @@ namespace jh {
 struct Pattern {
   jh_context ctx = nullptr;
   int64_t n = 0;     // block rows
-  int64_t nnzb = 0;  // block non-zeros
+  int64_t nnzb = 0;  // block non-zeros on the device
+  // Multigraph neighbourships (several faces between one cell pair): the reference's pattern holds ONE entry per pair
+  // (sparse() merges duplicates, conservation.jl:486-505; nnzb_host counts those), the device keeps one slot per face so that
+  // every half-face has its own transmissibility.  Per pair the slot of the highest face id is the primary one; the others
+  // ("shadow" slots) map to no host slot and their off-diagonal value is stored as zero -- the reference assigns, not adds,
+  // the off-diagonal per half-face (ad.jl:74-76), so the last parallel face wins there while residual and diagonal sum all.
+  int64_t nnzb_host = 0;
+  std::vector<int32_t> shadow_slots;  // device slots of the shadow entries (usually empty)
+  std::vector<char> shadow_flag;      // per device slot, only allocated when shadow_slots is not empty
+  DevBuf<int32_t> d_shadow_slots;
+  bool is_shadow(int64_t k) const { return !shadow_flag.empty() && shadow_flag[(size_t)k]; }
   int bs = 1;
   std::vector<int32_t> rowptr, col, diag;  // host copies, 0-based, device numbering
   // device order <-> host order (empty => identity)
@@ -199,7 +209,7 @@ struct Pattern {
 
 struct jh_tpfa_s {
   jh_context ctx = nullptr;
-  int64_t nc = 0, nf = 0, nhf = 0, nnzb = 0;
+  int64_t nc = 0, nf = 0, nhf = 0, nnzb = 0;  // nnzb: device slots (== pat->nnzb); the host pattern has pat->nnzb_host
   int N = 1;
   std::vector<int64_t> Nhost;  // 2*nf, 1-based, as given
   std::shared_ptr<jh::Pattern> pat;
@@ -323,6 +333,7 @@ void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max
 bool comm_mail_args(jh_context ctx, int n, MailArgs *out);
 void comm_allreduce_dev(jh_context ctx, double *p, int n, int op);
 void k_unit_diag(hipStream_t s, const Pattern &P, double *val, double *r, int64_t n_owned);
+void k_zero_slots(hipStream_t s, double *val, const int32_t *slots, int64_t n, int bb);
 void k_scale_system(hipStream_t s, const Pattern &P, double *val, double *r, int kind, double dt);
 
 // ---- assembly (jh_assembly.hip) -------------------------------------------------------------------------------

@@ -542,6 +542,15 @@ void k_scale_system(hipStream_t s, const Pattern &P, double *val, double *r, int
   if (P.n) hipLaunchKernelGGL(scale_system_kernel, dim3((unsigned)((P.n + 255) / 256)), dim3(256), 0, s, P.d_rowptr.p, P.d_diag.p, val, r, P.n, P.bs, kind, dt);
 }
 
+__global__ void zero_slots_kernel(double *val, const int32_t *slots, int64_t n, int bb) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * bb; i += (int64_t)gridDim.x * blockDim.x)
+    val[(size_t)slots[i / bb] * bb + (i % bb)] = 0.0;
+}
+// shadow slots of a multigraph pattern: the off-diagonal of all but the last parallel face is not stored (Pattern::shadow_slots)
+void k_zero_slots(hipStream_t s, double *val, const int32_t *slots, int64_t n, int bb) {
+  if (n) hipLaunchKernelGGL(zero_slots_kernel, dim3(grid_for(n * bb)), dim3(256), 0, s, val, slots, n, bb);
+}
+
 void k_unit_diag(hipStream_t s, const Pattern &P, double *val, double *r, int64_t n_owned) {
   int64_t ng = P.n - n_owned;
   if (ng <= 0) return;

@@ -2,6 +2,7 @@
 // ordering, CSR tiles.  Runs once per Simulator setup; everything here is integer work.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <numeric>
 #include <queue>
@@ -323,10 +324,28 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
     pat->col.resize(pat->nnzb);
     pat->diag.resize(nc);
     d->nz_face.resize(pat->nnzb);
-    // host CSR (host numbering) rowptr to compute host slots: row h has deg(h)+1 entries, ascending host cols
+    // host CSR (host numbering) rowptr to compute host slots: row h has (distinct neighbours of h) + 1 entries, ascending host cols
     std::vector<int64_t> hrp(nc + 1, 0);
-    for (int64_t h = 0; h < nc; ++h) hrp[h + 1] = hrp[h] + (A.ptr[h + 1] - A.ptr[h]) + 1;
-    if (!ident) pat->nz_hslot.resize(pat->nnzb);
+    bool multigraph = false;
+    {
+      std::vector<int32_t> ucount(nc);
+      std::vector<char> dup_in_range;
+      parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
+        std::vector<int32_t> nb;
+        for (int64_t h = b; h < e; ++h) {
+          nb.assign(A.nbr.begin() + A.ptr[h], A.nbr.begin() + A.ptr[h + 1]);
+          std::sort(nb.begin(), nb.end());
+          ucount[h] = (int32_t)(std::unique(nb.begin(), nb.end()) - nb.begin());
+        }
+      });
+      for (int64_t h = 0; h < nc; ++h) {
+        hrp[h + 1] = hrp[h] + ucount[h] + 1;
+        if (ucount[h] != (int32_t)(A.ptr[h + 1] - A.ptr[h])) multigraph = true;
+      }
+    }
+    pat->nnzb_host = hrp[nc];
+    if (!ident || multigraph) pat->nz_hslot.resize(pat->nnzb);
+    if (multigraph) pat->shadow_flag.assign(pat->nnzb, 0);
     // rows are independent: sorted device columns, signed face ids, diagonal slot, host slots -- on all host cores
     parallel_ranges(nc, 4096, [&](int64_t r_begin, int64_t r_end) {
       std::vector<std::pair<int32_t, int32_t>> tmp, tmph;
@@ -336,26 +355,39 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
         tmp.emplace_back((int32_t)i, 0);
         for (int64_t k = A.ptr[h]; k < A.ptr[h + 1]; ++k)
           tmp.emplace_back(ident ? A.nbr[k] : pat->iperm[A.nbr[k]], A.sface[k]);
-        std::sort(tmp.begin(), tmp.end());
+        // ascending device columns; parallel faces (multigraph) by ascending face id: the last one is the pair's primary slot
+        std::sort(tmp.begin(), tmp.end(), [](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) {
+          return a.first != b.first ? a.first < b.first : std::abs(a.second) < std::abs(b.second);
+        });
         int32_t base = pat->rowptr[i];
         for (size_t j = 0; j < tmp.size(); ++j) {
-          if (j > 0 && tmp[j].first == tmp[j - 1].first)
-            JH_THROW("two faces connect the same pair of cells: multigraph neighborships are not supported");
           pat->col[base + j] = tmp[j].first;
           d->nz_face[base + j] = tmp[j].second;
           if (tmp[j].first == (int32_t)i) pat->diag[i] = base + (int32_t)j;
+          if (multigraph && j + 1 < tmp.size() && tmp[j + 1].first == tmp[j].first) pat->shadow_flag[base + j] = 1;
         }
-        if (!ident) {
-          // host slot = position of host column in host row h (ascending host columns incl. diagonal)
+        if (!ident || multigraph) {
+          // host slot = position of host column in host row h (ascending distinct host columns incl. diagonal); shadow slots
+          // map to the spare slot behind the host pattern (jh_csr_get/set_values)
           tmph.clear();
-          for (size_t j = 0; j < tmp.size(); ++j) tmph.emplace_back(pat->perm[tmp[j].first], (int32_t)j);
+          for (size_t j = 0; j < tmp.size(); ++j) tmph.emplace_back(ident ? tmp[j].first : pat->perm[tmp[j].first], (int32_t)j);
           std::sort(tmph.begin(), tmph.end());
-          for (size_t j = 0; j < tmph.size(); ++j) pat->nz_hslot[base + tmph[j].second] = (int32_t)(hrp[h] + j);
+          int64_t rank = -1;
+          for (size_t j = 0; j < tmph.size(); ++j) {
+            if (j == 0 || tmph[j].first != tmph[j - 1].first) ++rank;
+            const int32_t slot = base + tmph[j].second;
+            pat->nz_hslot[slot] = (multigraph && pat->shadow_flag[slot]) ? (int32_t)pat->nnzb_host : (int32_t)(hrp[h] + rank);
+          }
         }
       }
     });
     for (int64_t i = 0; i < nc; ++i)
       if (pat->rowptr[i + 1] - pat->rowptr[i] > TILE_NNZ / 2) JH_THROW("cell with more than 511 faces is not supported");
+    if (multigraph) {
+      for (int64_t k = 0; k < pat->nnzb; ++k)
+        if (pat->shadow_flag[k]) pat->shadow_slots.push_back((int32_t)k);
+      pat->d_shadow_slots.upload(pat->shadow_slots, ctx->stream);
+    }
     pt.lap("device CSR pattern");
     pat->build_tiles();
     pat->upload();
@@ -384,7 +416,7 @@ extern "C" int32_t jh_tpfa_sizes(jh_tpfa d, int64_t *nc, int64_t *nf, int64_t *n
     if (nc) *nc = d->nc;
     if (nf) *nf = d->nf;
     if (nhf) *nhf = d->nhf;
-    if (nnzb) *nnzb = d->nnzb;
+    if (nnzb) *nnzb = d->pat->nnzb_host;  // the reference's pattern: one entry per cell pair
     if (block_n) *block_n = d->N;
   });
 }

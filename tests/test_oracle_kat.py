@@ -463,3 +463,19 @@ def test_gmres_converges_and_residual_history_is_true_residual(oracle, side):
     assert np.allclose(x, xb, rtol=1e-6, atol=1e-8)
     x0, st0 = oracle.gmres(nc, 1, rowptr, colidx, nz, b, prec=None, rtol=1e-10, atol=1e-14, itmax=nc)
     assert st0["solved"] and st0["iterations"] <= nc
+
+
+def test_multigraph_two_cells_two_faces_hand_computed(oracle):
+    """Two cells joined by TWO faces (T1, T2), Poisson law, hand-computed from the reference's loops: the pattern has one
+    off-diagonal entry per cell pair (sparse() merges duplicates, conservation.jl:486-505); residual and diagonal sum both
+    half-faces (fill_conservation_eq!, conservation.jl:373-430); the off-diagonal slot is assigned per half-face in ascending
+    face order (update_jacobian_inner!, ad.jl:74-76), so it ends up holding -T2 only."""
+    N = np.array([[1, 2], [2, 1]], dtype=np.int64)           # columns = faces: N[:,0] = (1,2), N[:,1] = (2,1)
+    nc, T1, T2, dt = 2, 3.0, 5.0, 0.5
+    U, U0, vol = np.array([2.0, 1.0]), np.array([1.5, 1.25]), np.array([1.0, 1.0])
+    osys = oracle.TPFASystem(N, nc)
+    assert list(osys.rowptr) == [1, 3, 5] and list(osys.colidx) == [1, 2, 1, 2]
+    nz, r = osys.assemble(oracle.Law("poisson", dt), U, U0, vol, np.array([T1, T2]))
+    q = (T1 + T2) * (U[0] - U[1])
+    assert np.allclose(r, [(U[0] - U0[0]) / dt + q, (U[1] - U0[1]) / dt - q], rtol=1e-14)
+    assert np.allclose(nz, [1 / dt + T1 + T2, -T2, -T2, 1 / dt + T1 + T2], rtol=1e-14)
