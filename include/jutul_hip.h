@@ -318,6 +318,14 @@ int32_t jh_halo_ipc_export(jh_tpfa d, char *handle64);
 int32_t jh_halo_ipc_attach(jh_tpfa d, const char *nbr_handles, const int64_t *nbr_offset, const int64_t *nbr_stride, int32_t *ok);
 int32_t jh_halo_ipc_selftest(jh_tpfa d, jh_vec v, const double *expected_ghosts, int32_t *ok);
 int32_t jh_halo_ipc_enable(jh_tpfa d, int32_t enable);
+/* partition(N, nparts) in the role of the reference's MetisPartitioner (partitioning.jl:29-51, generate_metis_graph :64-78;
+ * Metis itself is third-party): recursive bisection of the cell graph, every cut grown breadth-first from a pseudo-peripheral
+ * cell and refined by Fiduccia-Mattheyses moves; face_weights (may be NULL) weight the edges like the reference's |A|-weighted
+ * graph.  out[c] in 1..nparts, every part non-empty, part sizes within `imbalance` (e.g. 0.03; < 0: default) of nc / nparts per
+ * bisection.  Host integer work, no device needed.  A partition vector is an input of jh_tpfa_create / jh_ilu0_create and of
+ * the host-side subdomain logic: any partitioner can be used instead. */
+int32_t jh_partition_graph(int64_t nc, int64_t nf, const int64_t *N, const double *face_weights, int64_t nparts, double imbalance,
+                           int64_t *out);
 /* consistent!(v) (ext/.../linalg.jl:46, krylov.jl:54,75; interface.jl:200): owner values -> ghosts */
 int32_t jh_halo_exchange(jh_tpfa d, jh_vec v);
 int32_t jh_halo_exchange_state(jh_law L);

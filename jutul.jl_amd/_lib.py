@@ -120,6 +120,7 @@ SIGNATURES = {
     "jh_halo_exchange": [H, H],
     "jh_halo_exchange_state": [H],
     "jh_allreduce": [H, F64P, C.c_int32, C.c_int32],
+    "jh_partition_graph": [C.c_int64, C.c_int64, I64P, F64P, C.c_int64, C.c_double, I64P],
 }
 
 

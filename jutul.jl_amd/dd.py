@@ -56,6 +56,20 @@ def cartesian_partition(pts, dims):
     return compress_partition(p)
 
 
+def partition_graph(N, nc, nparts, face_weights=None, imbalance=0.03):
+    """Graph partition without coordinates, in the role of the reference's MetisPartitioner (partitioning.jl:29-51): recursive
+    bisection + Fiduccia-Mattheyses refinement inside libjutul_hip.so (jh_partition_graph; host code, no GPU needed).
+    N: 2 x nf neighbourship (1-based); returns the 1-based part of every cell."""
+    import ctypes as C
+    from . import _lib
+    N = np.asarray(N, dtype=np.int64)
+    Nf = np.ascontiguousarray(np.asfortranarray(N).T.reshape(-1))
+    out = np.zeros(int(nc), dtype=np.int64)
+    w = None if face_weights is None else np.ascontiguousarray(face_weights, dtype=np.float64)
+    _lib.check(_lib.load().jh_partition_graph(int(nc), int(N.shape[1]), _lib.pi(Nf), _lib.pf(w), int(nparts), float(imbalance), _lib.pi(out)))
+    return out
+
+
 def process_partition(N, partition, weights=None):
     """process_partition (partitioning.jl:128-160): split every coarse block into its connected components; the first
     component (the one containing the block's lowest cell) keeps the id, the others get max+1, max+2, ...
