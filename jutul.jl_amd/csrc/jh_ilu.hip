@@ -1374,6 +1374,8 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
             });
             M->prog = true;
             M->prog_lds_bytes = bytes; M->prog_max_vals = max_vals; M->prog_max_words = max_words;
+            if (timing) fprintf(stderr, "[jutul_hip setup] ilu0: factor programs: LDS %zu B per block (values %d, words %d), %zu words total, %lld rows in the largest block\n",
+                                bytes, max_vals, max_words, total, (long long)maxrows);
             hipStream_t sp = M->ctx->stream;
             M->d_blk_lbase.upload(M->blk_lbase, sp); M->d_blk_ubase.upload(M->blk_ubase, sp); M->d_blk_prog.upload(M->blk_prog, sp);
             M->d_prog.upload(prog, sp);
