@@ -63,6 +63,16 @@ static inline void parallel_ranges(int64_t n, int64_t min_per_thread, F &&fn) {
   for (auto &e : err) if (e) std::rethrow_exception(e);
 }
 
+// ---- graph partitioner (jh_partition.cpp): recursive bisection + Fiduccia-Mattheyses refinement --------------------------------
+struct PGraph {
+  int64_t n;           // cells 0 .. n-1 take part; neighbour ids >= n are ignored (ghost cells of a rank-local subdomain)
+  const int64_t *ptr;  // adjacency, without self loops
+  const int32_t *nbr;
+  const double *w;     // edge weights or nullptr (all 1)
+};
+void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t nparts, double imbalance, int64_t max_part,
+                      std::vector<int32_t> &label);
+
 // ---- tiling constants for the CSR row-segment kernels ------------------------------------------------
 constexpr int TILE_THREADS = 256;  // 4 wavefronts
 constexpr int TILE_NNZ = 1024;     // block-nnz staged in LDS per workgroup
