@@ -71,7 +71,7 @@ struct PGraph {
   const double *w;     // edge weights or nullptr (all 1)
 };
 void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t nparts, double imbalance, int64_t max_part,
-                      std::vector<int32_t> &label);
+                      std::vector<int32_t> &label, int32_t rim_cell);
 
 // ---- tiling constants for the CSR row-segment kernels ------------------------------------------------
 constexpr int TILE_THREADS = 256;  // 4 wavefronts

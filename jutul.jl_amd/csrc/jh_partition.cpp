@@ -25,55 +25,63 @@ namespace {
 struct Job {
   int32_t lab = 0;  // the cells carry this label; the k parts get lab .. lab + k - 1
   int64_t k = 1;
-  std::vector<int32_t> cells;
+  int64_t off = 0, n = 0;  // the job's cells: cells[off .. off + n) of the shared list (children split their parent's segment)
+  int32_t start = -1;      // a cell on the job's rim if one is known (an end of the parent's sweep), else -1
 };
 
 struct Bisector {
   const PGraph &G;
   std::vector<int32_t> &label;
+  std::vector<int32_t> cells, order;  // the jobs' cell lists / breadth-first orders, one segment per job: no allocation per job
   std::vector<int32_t> mark, locked;  // shared stamp arrays: concurrent jobs own disjoint cells, stamps are globally fresh
   std::atomic<int32_t> stamp{0};
   double imbalance;
   int64_t max_part;
-  Bisector(const PGraph &g, std::vector<int32_t> &lab, double imb, int64_t mp)
-      : G(g), label(lab), mark(g.n, 0), locked(g.n, 0), imbalance(imb), max_part(mp) {}
+  static constexpr int64_t hint_min = 65536;  // jobs above this size are shared between the threads, see partition_bisect
+  Bisector(const PGraph &g, std::vector<int32_t> &lab, std::vector<int32_t> &&c, double imb, int64_t mp)
+      : G(g), label(lab), cells(std::move(c)), order(cells.size()), mark(g.n, 0), locked(g.n, 0), imbalance(imb), max_part(mp) {}
 
   inline double weight(int64_t k) const { return G.w ? G.w[k] : 1.0; }
 
-  // breadth-first order of the job's cells from `start` (restarts cover disconnected pieces); returns the last cell reached from
-  // the first start (a far end of that piece)
-  int32_t bfs_order(int32_t lab, const std::vector<int32_t> &cells, int32_t start, std::vector<int32_t> &order) {
+  // breadth-first order of the n cells c[] (label lab) from `start` into o[] (restarts cover disconnected pieces); returns the
+  // last cell reached from the first start (a far end of that piece).  levels (optional): the positions in o[] where a
+  // breadth-first level begins.
+  int32_t bfs_order(int32_t lab, const int32_t *c, int64_t n, int32_t start, int32_t *o, std::vector<int64_t> *levels = nullptr) {
     const int32_t st = ++stamp;
-    order.clear();
-    order.reserve(cells.size());
+    if (levels) levels->clear();
     int32_t far = start, s = start;
-    size_t next_restart = 0;
+    int64_t next_restart = 0, tail = 0;
     bool first = true;
-    while (order.size() < cells.size()) {
+    while (tail < n) {
       if (s < 0) {
-        while (next_restart < cells.size() && mark[cells[next_restart]] == st) ++next_restart;
-        if (next_restart == cells.size()) break;
-        s = cells[next_restart];
+        while (next_restart < n && mark[c[next_restart]] == st) ++next_restart;
+        if (next_restart == n) break;
+        s = c[next_restart];
       }
-      size_t head = order.size();
+      int64_t head = tail, level_end = head;
       mark[s] = st;
-      order.push_back(s);
-      while (head < order.size()) {
-        const int32_t v = order[head++];
+      o[tail++] = s;
+      while (head < tail) {
+        if (head == level_end) {
+          if (levels) levels->push_back(head);
+          level_end = tail;
+        }
+        const int32_t v = o[head++];
         for (int64_t k = G.ptr[v]; k < G.ptr[v + 1]; ++k) {
-          const int32_t o = G.nbr[k];
-          if (o < G.n && label[o] == lab && mark[o] != st) { mark[o] = st; order.push_back(o); }
+          const int32_t w = G.nbr[k];
+          if (w < G.n && label[w] == lab && mark[w] != st) { mark[w] = st; o[tail++] = w; }
         }
       }
-      if (first) { far = order.back(); first = false; }
+      if (first) { far = o[tail - 1]; first = false; }
       s = -1;
     }
     return far;
   }
 
-  // Fiduccia-Mattheyses passes on the cut between labels a and b (only the job's cells carry them)
-  void fm_refine(int32_t a, int32_t b, const std::vector<int32_t> &cells, int64_t &na, int64_t &nb, int64_t max_a, int64_t max_b,
-                 int64_t min_a, int64_t min_b) {
+  // Fiduccia-Mattheyses passes on the cut between labels a and b (only the job's cells carry them); near_cut: a superset of the
+  // cells that have a neighbour on the other side
+  void fm_refine(int32_t a, int32_t b, int64_t ncells, const int32_t *near_cut, int64_t n_near, int64_t &na, int64_t &nb,
+                 int64_t max_a, int64_t max_b, int64_t min_a, int64_t min_b) {
     auto gain_of = [&](int32_t v) {  // reduction of the cut weight if v changes side
       const int32_t mine = label[v], other = mine == a ? b : a;
       double g = 0.0;
@@ -96,9 +104,9 @@ struct Bisector {
       }
       return false;
     };
-    // cells near the cut: one scan of the job, afterwards kept up to date from the moves (a pass touches the cut's surroundings only)
+    // the cells on the cut, afterwards kept up to date from the moves (a pass touches the cut's surroundings only)
     std::vector<int32_t> cand;
-    for (int32_t v : cells) if (on_cut(v)) cand.push_back(v);
+    for (int64_t i = 0; i < n_near; ++i) if (on_cut(near_cut[i])) cand.push_back(near_cut[i]);
     for (int pass = 0; pass < 4; ++pass) {
       const int32_t st = ++stamp;
       std::priority_queue<std::pair<double, int32_t>> pq;
@@ -106,7 +114,7 @@ struct Bisector {
       std::vector<int32_t> moved;
       double total = 0.0, best = 0.0;
       size_t best_len = 0;
-      const size_t max_moves = std::max<size_t>(64, cells.size() / 8);
+      const size_t max_moves = std::max<size_t>(64, (size_t)ncells / 8);
       while (!pq.empty() && moved.size() < max_moves) {
         auto [g, v] = pq.top();
         pq.pop();
@@ -149,9 +157,10 @@ struct Bisector {
   }
 
   // one bisection: job -> (A, B)
-  void split(Job &job, Job &A, Job &B) {
-    const int64_t k1 = job.k / 2, k2 = job.k - k1, n = (int64_t)job.cells.size();
+  void split(const Job &job, Job &A, Job &B) {
+    const int64_t k1 = job.k / 2, k2 = job.k - k1, n = job.n;
     const int32_t la = job.lab, lb = job.lab + (int32_t)k1;  // side B takes the labels lab + k1 ...
+    int32_t *c = cells.data() + job.off, *o = order.data() + job.off;
     // side sizes: proportional to the part counts, each side within `imbalance` of its share, no side too small for its parts
     // and -- max_part > 0 -- none so large that a leaf would have to exceed max_part cells
     int64_t min_a = k1, min_b = k2, cap_a = n - k2, cap_b = n - k1;
@@ -164,32 +173,48 @@ struct Bisector {
     }
     int64_t target_a = (int64_t)std::llround((double)n * (double)k1 / (double)job.k);
     target_a = std::max(min_a, std::min(cap_a, target_a));
-    // grow side A breadth-first from a pseudo-peripheral cell (the far end of a first sweep)
-    std::vector<int32_t> order;
-    const int32_t far = bfs_order(la, job.cells, job.cells[0], order);
-    bfs_order(la, job.cells, far, order);
-    for (int64_t i = target_a; i < n; ++i) label[order[i]] = lb;
+    // grow side A breadth-first from a pseudo-peripheral cell: the far end of a first sweep, or -- large jobs, whose sweeps are
+    // the serial part of the run -- an end of the parent's sweep (for all jobs that would cost 4% more cut: the many small ones
+    // take the first sweep)
+    std::vector<int64_t> levels;
+    int32_t far = job.start;
+    if (far < 0 || n <= hint_min || label[far] != la) far = bfs_order(la, c, n, c[0], o);
+    bfs_order(la, c, n, far, o, &levels);
+    for (int64_t i = target_a; i < n; ++i) label[o[i]] = lb;
     int64_t na = target_a, nb = n - target_a;
     const int64_t max_a = std::min(cap_a, target_a + (int64_t)std::floor(imbalance * (double)target_a));
     const int64_t max_b = std::min(cap_b, (n - target_a) + (int64_t)std::floor(imbalance * (double)(n - target_a)));
-    fm_refine(la, lb, job.cells, na, nb, max_a, max_b, min_a, min_b);
-    A.lab = la; A.k = k1;
-    B.lab = lb; B.k = k2;
-    A.cells.reserve((size_t)na);
-    B.cells.reserve((size_t)nb);
-    for (int32_t v : order) (label[v] == la ? A.cells : B.cells).push_back(v);  // children keep a breadth-first order
-    if ((int64_t)A.cells.size() < k1 || (int64_t)B.cells.size() < k2) JH_THROW("partitioner lost a part (internal error)");
+    // neighbours are at most one breadth-first level apart: the cut lies inside the level of position target_a and its two
+    // neighbours
+    const int64_t lv = (int64_t)(std::upper_bound(levels.begin(), levels.end(), target_a) - levels.begin()) - 1;  // level of o[target_a]
+    const int64_t lo = levels[std::max<int64_t>(0, lv - 1)];
+    const int64_t hi = lv + 2 < (int64_t)levels.size() ? levels[lv + 2] : n;
+    fm_refine(la, lb, n, o + lo, hi - lo, na, nb, max_a, max_b, min_a, min_b);
+    if (na < k1 || nb < k2) JH_THROW("partitioner lost a part (internal error)");
+    // the children split the segment and keep the breadth-first order
+    int64_t wa = 0, wb = na;
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t v = o[i];
+      if (label[v] == la) c[wa++] = v; else c[wb++] = v;
+    }
+    if (wa != na || wb != n) JH_THROW("partitioner: side counts are inconsistent (internal error)");
+    A.lab = la; A.k = k1; A.off = job.off; A.n = na;
+    B.lab = lb; B.k = k2; B.off = job.off + na; B.n = nb;
+    A.start = label[o[0]] == la ? o[0] : -1;  // where this sweep began / ended, unless the refinement moved the cell across
+    B.start = label[o[n - 1]] == lb ? o[n - 1] : -1;
   }
 };
 
 }  // namespace
 
 // label[c] in 0 .. nparts-1 for the cells listed (label must be 0 for them on entry and outside 0..nparts-1 elsewhere, e.g. -1);
-// neighbours with index >= G.n are ignored.  max_part > 0 caps the size of every part.
+// neighbours with index >= G.n are ignored.  max_part > 0 caps the size of every part.  rim_cell: a cell known to lie on the rim
+// of the graph (e.g. the last one a breadth-first search reached) or -1.
 void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t nparts, double imbalance, int64_t max_part,
-                      std::vector<int32_t> &label) {
+                      std::vector<int32_t> &label, int32_t rim_cell) {
   if (nparts <= 1 || cells.empty()) return;
-  Bisector bis(G, label, imbalance, max_part);
+  const int64_t ncells = (int64_t)cells.size();
+  Bisector bis(G, label, std::move(cells), imbalance, max_part);
   std::mutex m;
   std::condition_variable cv;
   std::vector<Job> queue;
@@ -199,8 +224,10 @@ void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t npa
     Job j;
     j.lab = 0;
     j.k = nparts;
-    j.cells = std::move(cells);
-    queue.push_back(std::move(j));
+    j.off = 0;
+    j.n = ncells;
+    j.start = rim_cell;
+    queue.push_back(j);
   }
   int nt = (int)std::thread::hardware_concurrency();
   if (const char *e = getenv("JH_SETUP_THREADS")) nt = atoi(e);
@@ -213,29 +240,29 @@ void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t npa
         cv.wait(lk, [&] { return !queue.empty() || active == 0 || err; });
         if (err || queue.empty()) return;  // queue empty here means active == 0: all done
         size_t best = 0;                   // largest job first: the big splits are the serial part
-        for (size_t i = 1; i < queue.size(); ++i) if (queue[i].cells.size() > queue[best].cells.size()) best = i;
-        job = std::move(queue[best]);
+        for (size_t i = 1; i < queue.size(); ++i) if (queue[i].n > queue[best].n) best = i;
+        job = queue[best];
         queue.erase(queue.begin() + (ptrdiff_t)best);
         ++active;
       }
       try {
         // small jobs are finished by the thread that holds them (no queue traffic below 64k cells)
         std::vector<Job> local;
-        local.push_back(std::move(job));
+        local.push_back(job);
         while (!local.empty()) {
-          Job cur = std::move(local.back());
+          const Job cur = local.back();
           local.pop_back();
           if (cur.k <= 1) continue;
           Job A, B;
           bis.split(cur, A, B);
-          if (cur.cells.size() > 65536 && nt > 1) {
+          if (cur.n > Bisector::hint_min && nt > 1) {
             std::lock_guard<std::mutex> lk(m);
-            queue.push_back(std::move(A));
-            queue.push_back(std::move(B));
+            queue.push_back(A);
+            queue.push_back(B);
             cv.notify_all();
           } else {
-            local.push_back(std::move(A));
-            local.push_back(std::move(B));
+            local.push_back(A);
+            local.push_back(B);
           }
         }
       } catch (...) {
@@ -291,7 +318,7 @@ extern "C" int32_t jh_partition_graph(int64_t nc, int64_t nf, const int64_t *N, 
     PGraph G{nc, ptr.data(), nbr.data(), face_weights ? w.data() : nullptr};
     std::vector<int32_t> label(nc, 0), cells(nc);
     std::iota(cells.begin(), cells.end(), 0);
-    partition_bisect(G, std::move(cells), nparts, imbalance, 0, label);
+    partition_bisect(G, std::move(cells), nparts, imbalance, 0, label, -1);
     for (int64_t c = 0; c < nc; ++c) out[c] = (int64_t)label[c] + 1;
   });
 }

@@ -73,27 +73,46 @@ struct Adj {
 };
 
 static Adj build_adjacency(int64_t nc, int64_t nf, const int64_t *N) {
+  // all host cores: counts and cursors are bumped atomically, then every row is put back into ascending face order (what a
+  // serial fill produces) so that nothing downstream depends on the thread timing
   Adj A;
   A.ptr.assign(nc + 1, 0);
-  for (int64_t f = 0; f < nf; ++f) {
-    int64_t l = N[2 * f], r = N[2 * f + 1];
-    if (l < 1 || l > nc || r < 1 || r > nc)
-      JH_THROW("neighborship entry out of range (utils.jl:822: max(N) <= nc)");
-    if (l == r) JH_THROW("face connecting a cell to itself is not supported");
-    A.ptr[l]++;
-    A.ptr[r]++;
-  }
+  int64_t *ptr = A.ptr.data();
+  parallel_ranges(nf, 1 << 18, [&](int64_t f0, int64_t f1) {
+    for (int64_t f = f0; f < f1; ++f) {
+      const int64_t l = N[2 * f], r = N[2 * f + 1];
+      if (l < 1 || l > nc || r < 1 || r > nc)
+        JH_THROW("neighborship entry out of range (utils.jl:822: max(N) <= nc)");
+      if (l == r) JH_THROW("face connecting a cell to itself is not supported");
+      __atomic_fetch_add(&ptr[l], 1, __ATOMIC_RELAXED);
+      __atomic_fetch_add(&ptr[r], 1, __ATOMIC_RELAXED);
+    }
+  });
   for (int64_t c = 0; c < nc; ++c) A.ptr[c + 1] += A.ptr[c];
   A.nbr.resize(A.ptr[nc]);
   A.sface.resize(A.ptr[nc]);
   std::vector<int64_t> cur(A.ptr.begin(), A.ptr.end() - 1);
-  for (int64_t f = 0; f < nf; ++f) {
-    int64_t l = N[2 * f] - 1, r = N[2 * f + 1] - 1;
-    A.nbr[cur[l]] = (int32_t)r;
-    A.sface[cur[l]++] = (int32_t)(f + 1);
-    A.nbr[cur[r]] = (int32_t)l;
-    A.sface[cur[r]++] = -(int32_t)(f + 1);
-  }
+  int64_t *cu = cur.data();
+  parallel_ranges(nf, 1 << 18, [&](int64_t f0, int64_t f1) {
+    for (int64_t f = f0; f < f1; ++f) {
+      const int64_t l = N[2 * f] - 1, r = N[2 * f + 1] - 1;
+      const int64_t pl = __atomic_fetch_add(&cu[l], 1, __ATOMIC_RELAXED), pr = __atomic_fetch_add(&cu[r], 1, __ATOMIC_RELAXED);
+      A.nbr[pl] = (int32_t)r;
+      A.sface[pl] = (int32_t)(f + 1);
+      A.nbr[pr] = (int32_t)l;
+      A.sface[pr] = -(int32_t)(f + 1);
+    }
+  });
+  parallel_ranges(nc, 1 << 16, [&](int64_t c0, int64_t c1) {
+    for (int64_t c = c0; c < c1; ++c)
+      for (int64_t i = A.ptr[c] + 1; i < A.ptr[c + 1]; ++i) {  // insertion sort by face (rows are short)
+        const int32_t sf = A.sface[i], nb = A.nbr[i];
+        int64_t j = i;
+        for (; j > A.ptr[c] && std::abs(A.sface[j - 1]) > std::abs(sf); --j) { A.sface[j] = A.sface[j - 1]; A.nbr[j] = A.nbr[j - 1]; }
+        A.sface[j] = sf;
+        A.nbr[j] = nb;
+      }
+  });
   return A;
 }
 
@@ -136,6 +155,20 @@ static void centre_bfs_order(const Adj &A, const std::vector<int32_t> &lab, int3
   std::copy(rest.begin(), rest.end(), cells + bq.size());
 }
 
+namespace {
+// JH_SETUP_TIMING=1: seconds per set-up phase on stderr
+struct PhaseTimer {
+  bool on = getenv("JH_SETUP_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[jutul_hip setup] %-28s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+}  // namespace
+
 // Blocks by recursive graph bisection + Fiduccia-Mattheyses refinement (jh_partition.cpp) -- the default.  Compact blocks cut
 // fewer couplings than blocks grown along the rim of the assigned region ("onion", below): 13% instead of 18% of the
 // half-faces at 512 cells per block on the tet lattice = 24.0 instead of 26.6 BiCGStab iterations at 2M cells, and a
@@ -145,31 +178,40 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
   const int64_t nparts = std::max<int64_t>(1, (nc + block_rows / 2) / block_rows);
   const int64_t max_part = std::max<int64_t>(block_rows + block_rows / 8, (nc + nparts - 1) / nparts);
   std::vector<int32_t> label(A.ptr.size() - 1, -1);
+  PhaseTimer pt;
   {
     // The input numbering may be arbitrary (the bench grid's is scrambled): every sweep of the partitioner would miss the
     // cache on every cell.  One breadth-first renumbering first (neighbours end up close in memory), the bisections run on the
     // renumbered graph of the owned cells, the labels are mapped back.
     std::vector<int32_t> ord, newid(nc, -1);
     ord.reserve(nc);
+    int64_t first_piece = 0;  // cells of the first connected piece: its last cell is a far end of the graph
     for (int64_t s0 = 0; s0 < nc; ++s0) {
       if (newid[s0] >= 0) continue;
       newid[s0] = (int32_t)ord.size();
       ord.push_back((int32_t)s0);
       for (size_t h = ord.size() - 1; h < ord.size(); ++h) {
+        if (h + 8 < ord.size()) __builtin_prefetch(&A.ptr[ord[h + 8]]);  // the queue runs ahead of the random accesses
+        if (h + 4 < ord.size()) __builtin_prefetch(&A.nbr[A.ptr[ord[h + 4]]]);
         const int32_t c = ord[h];
         for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k) {
           const int32_t o = A.nbr[k];
           if (o < nc && newid[o] < 0) { newid[o] = (int32_t)ord.size(); ord.push_back(o); }
         }
       }
+      if (s0 == 0) first_piece = (int64_t)ord.size();
     }
+    pt.lap("  blocks: renumber");
     std::vector<int64_t> ptr2(nc + 1, 0);
-    for (int64_t i = 0; i < nc; ++i) {
-      const int32_t c = ord[i];
-      int64_t deg = 0;
-      for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k) deg += A.nbr[k] < nc;
-      ptr2[i + 1] = ptr2[i] + deg;
-    }
+    parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
+      for (int64_t i = b; i < e; ++i) {
+        const int32_t c = ord[i];
+        int64_t deg = 0;
+        for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k) deg += A.nbr[k] < nc;
+        ptr2[i + 1] = deg;
+      }
+    });
+    for (int64_t i = 0; i < nc; ++i) ptr2[i + 1] += ptr2[i];
     std::vector<int32_t> nbr2(ptr2[nc]);
     parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
       for (int64_t i = b; i < e; ++i) {
@@ -182,7 +224,9 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
     std::vector<int32_t> lab2(nc, 0), cells(nc);
     std::iota(cells.begin(), cells.end(), 0);
     PGraph G{nc, ptr2.data(), nbr2.data(), nullptr};
-    partition_bisect(G, std::move(cells), nparts, 0.04, max_part, lab2);
+    pt.lap("  blocks: graph");
+    partition_bisect(G, std::move(cells), nparts, 0.04, max_part, lab2, (int32_t)(first_piece - 1));
+    pt.lap("  blocks: bisection");
     for (int64_t i = 0; i < nc; ++i) label[ord[i]] = lab2[i];
   }
   std::vector<int32_t> cnt(nparts + 1, 0);
@@ -198,6 +242,7 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
     for (int64_t b = b0; b < b1; ++b)
       centre_bfs_order(A, label, (int32_t)b, perm.data() + block_ptr[b], block_ptr[b + 1] - block_ptr[b], dist, bq);
   });
+  pt.lap("  blocks: order inside");
 }
 
 static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block_rows, std::vector<int32_t> &perm,
@@ -391,19 +436,6 @@ static void order_by_partition(const Adj &A, int64_t nc, const int64_t *partitio
 
 using namespace jh;
 
-namespace {
-// JH_SETUP_TIMING=1: seconds per set-up phase on stderr
-struct PhaseTimer {
-  bool on = getenv("JH_SETUP_TIMING") != nullptr;
-  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-  void lap(const char *what) {
-    if (!on) return;
-    auto n = std::chrono::steady_clock::now();
-    fprintf(stderr, "[jutul_hip setup] %-28s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
-    t = n;
-  }
-};
-}  // namespace
 
 // --------------------------------------------------------------------------------------------------------------
 // jh_tpfa_create
