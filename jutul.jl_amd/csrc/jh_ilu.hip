@@ -1079,115 +1079,150 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     M->max_block_rows = maxrows;
     M->lds_mode = (np > 1) && ((size_t)maxrows * P.bs * sizeof(double) <= LDS_CAP_BYTES);
 
+    // The parts are independent from here on: everything below runs part by part (block by block) on all host cores.
+    // rows of every part in ascending device-row order (counting sort)
+    std::vector<int64_t> pstart(np + 1, 0);
+    for (int64_t b = 0; b < np; ++b) pstart[b + 1] = pstart[b] + psize[b];
+    std::vector<int32_t> prow(n);
+    {
+      std::vector<int64_t> cur(pstart.begin(), pstart.end() - 1);
+      for (int64_t i = 0; i < n; ++i) prow[cur[part[i]]++] = (int32_t)i;
+    }
     // dependency levels inside each part (forward: strict-lower entries; backward: strict-upper entries)
     std::vector<int32_t> flev(n, 0), blev(n, 0);
-    for (int64_t i = 0; i < n; ++i) {
-      int32_t lv = 0;
-      for (int32_t k = P.rowptr[i]; k < P.diag[i]; ++k) {
-        int32_t c = P.col[k];
-        if (part[c] == part[i]) lv = std::max(lv, flev[c] + 1);
+    parallel_ranges(np, 16, [&](int64_t p0, int64_t p1) {
+      for (int64_t p = p0; p < p1; ++p) {
+        for (int64_t r = pstart[p]; r < pstart[p + 1]; ++r) {
+          const int32_t i = prow[r];
+          int32_t lv = 0;
+          for (int32_t k = P.rowptr[i]; k < P.diag[i]; ++k) {
+            const int32_t c = P.col[k];
+            if (part[c] == p) lv = std::max(lv, flev[c] + 1);
+          }
+          flev[i] = lv;
+        }
+        for (int64_t r = pstart[p + 1] - 1; r >= pstart[p]; --r) {
+          const int32_t i = prow[r];
+          int32_t lv = 0;
+          for (int32_t k = P.diag[i] + 1; k < P.rowptr[i + 1]; ++k) {
+            const int32_t c = P.col[k];
+            if (part[c] == p) lv = std::max(lv, blev[c] + 1);
+          }
+          blev[i] = lv;
+        }
       }
-      flev[i] = lv;
-    }
-    for (int64_t i = n - 1; i >= 0; --i) {
-      int32_t lv = 0;
-      for (int32_t k = P.diag[i] + 1; k < P.rowptr[i + 1]; ++k) {
-        int32_t c = P.col[k];
-        if (part[c] == part[i]) lv = std::max(lv, blev[c] + 1);
-      }
-      blev[i] = lv;
-    }
-    lap("levels");
-    // ilu ordering: LDS mode (part, flev, row); GLOBAL mode (flev, row)
-    std::vector<int32_t> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    const bool lds = M->lds_mode;
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-      if (lds && part[a] != part[b]) return part[a] < part[b];
-      if (flev[a] != flev[b]) return flev[a] < flev[b];
-      return a < b;
     });
-    M->rowmap = order;
-    std::vector<int32_t> ilu_of(n);
-    for (int64_t t = 0; t < n; ++t) ilu_of[order[t]] = (int32_t)t;
-    // execution blocks
+    lap("levels");
+    // execution blocks: LDS mode one per part, GLOBAL mode a single one; brow = their rows in ascending device-row order
+    const bool lds = M->lds_mode;
     if (lds) {
       M->blk_ptr.assign(np + 1, 0);
-      for (int64_t b = 0; b < np; ++b) M->blk_ptr[b + 1] = M->blk_ptr[b] + (int32_t)psize[b];
+      for (int64_t b = 0; b < np; ++b) M->blk_ptr[b + 1] = (int32_t)pstart[b + 1];
     } else {
       M->blk_ptr = {0, (int32_t)n};
+      std::iota(prow.begin(), prow.end(), 0);
     }
+    const std::vector<int32_t> &brow = prow;
     const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
-    lap("row sort");
-    // level pointers: block b owns flev_ptr[flev_off[b] .. flev_off[b+1]) = level starts + one end sentinel,
-    // i.e. level l of block b spans ilu rows [flev_ptr[flev_off[b]+l], flev_ptr[flev_off[b]+l+1])
-    int64_t maxlev = 0;
-    M->flev_off.clear();
-    for (int64_t b = 0; b < nb; ++b) {
-      M->flev_off.push_back((int32_t)M->flev_ptr.size());
-      int32_t cur = -1;
-      int64_t cnt = 0;
-      for (int32_t t = M->blk_ptr[b]; t < M->blk_ptr[b + 1]; ++t) {
-        int32_t lv = flev[order[t]];
-        if (lv != cur) { M->flev_ptr.push_back(t); cur = lv; ++cnt; }
+    // levels per block (every level 0 .. max occurs: a row of level l depends on one of level l - 1)
+    std::vector<int32_t> nflev(nb), nblev(nb);
+    parallel_ranges(nb, 16, [&](int64_t b0, int64_t b1) {
+      for (int64_t b = b0; b < b1; ++b) {
+        int32_t mf = 0, mb = 0;
+        for (int32_t r = M->blk_ptr[b]; r < M->blk_ptr[b + 1]; ++r) { mf = std::max(mf, flev[brow[r]]); mb = std::max(mb, blev[brow[r]]); }
+        nflev[b] = mf + 1;
+        nblev[b] = mb + 1;
       }
-      M->flev_ptr.push_back(M->blk_ptr[b + 1]);
-      maxlev = std::max(maxlev, cnt);
-    }
-    M->flev_off.push_back((int32_t)M->flev_ptr.size());
-    // U-order: per block rows sorted by (blev, ilu row)
-    std::vector<int32_t> uord(n);
-    std::iota(uord.begin(), uord.end(), 0);  // ilu rows
+    });
+    // level pointers: block b owns flev_ptr[flev_off[b] .. flev_off[b+1]) = level starts + one end sentinel,
+    // i.e. level l of block b spans ilu rows [flev_ptr[flev_off[b]+l], flev_ptr[flev_off[b]+l+1]); blev_* likewise over U-order
+    // positions
+    int64_t maxlev = 0;
+    M->flev_off.assign(nb + 1, 0);
     M->blev_off.assign(nb + 1, 0);
     for (int64_t b = 0; b < nb; ++b) {
-      auto beg = uord.begin() + M->blk_ptr[b], end = uord.begin() + M->blk_ptr[b + 1];
-      std::sort(beg, end, [&](int32_t a, int32_t c) {
-        int32_t la = blev[order[a]], lc = blev[order[c]];
-        if (la != lc) return la < lc;
-        return a < c;
-      });
-      M->blev_off[b] = (int32_t)M->blev_ptr.size();
-      int32_t cur = -1;
-      int64_t cnt = 0;
-      for (int32_t pos = M->blk_ptr[b]; pos < M->blk_ptr[b + 1]; ++pos) {
-        int32_t lv = blev[order[uord[pos]]];
-        if (lv != cur) { M->blev_ptr.push_back(pos); cur = lv; ++cnt; }
-      }
-      M->blev_ptr.push_back(M->blk_ptr[b + 1]);
-      maxlev = std::max(maxlev, cnt);
+      M->flev_off[b + 1] = M->flev_off[b] + nflev[b] + 1;
+      M->blev_off[b + 1] = M->blev_off[b] + nblev[b] + 1;
+      maxlev = std::max<int64_t>(maxlev, std::max(nflev[b], nblev[b]));
     }
-    M->blev_off[nb] = (int32_t)M->blev_ptr.size();
+    M->flev_ptr.assign(M->flev_off[nb], 0);
+    M->blev_ptr.assign(M->blev_off[nb], 0);
     M->max_levels = maxlev;
+    // ilu ordering: rows of a block by (flev, device row); U-order: its ilu rows by (blev, ilu row) -- two counting sorts
+    std::vector<int32_t> order(n), ilu_of(n), uord(n);
     M->upos_of.resize(n);
     M->u_row.resize(n);
-    for (int64_t pos = 0; pos < n; ++pos) {
-      int32_t t = uord[pos];
-      M->upos_of[t] = (int32_t)pos;
-      // local id of the row inside its execution block
-      int64_t b = lds ? part[order[t]] : 0;
-      M->u_row[pos] = t - M->blk_ptr[b];
-    }
-    lap("level pointers, U order");
-    // L (forward order) and U (backward order) storage
+    parallel_ranges(nb, 16, [&](int64_t b0, int64_t b1) {
+      std::vector<int32_t> cnt;
+      for (int64_t b = b0; b < b1; ++b) {
+        const int32_t r0 = M->blk_ptr[b], r1 = M->blk_ptr[b + 1];
+        int32_t *fp = M->flev_ptr.data() + M->flev_off[b], *bp = M->blev_ptr.data() + M->blev_off[b];
+        cnt.assign((size_t)nflev[b] + 1, 0);
+        for (int32_t r = r0; r < r1; ++r) cnt[flev[brow[r]] + 1]++;
+        for (int32_t l = 0; l < nflev[b]; ++l) cnt[l + 1] += cnt[l];
+        for (int32_t l = 0; l <= nflev[b]; ++l) fp[l] = r0 + cnt[l];  // (the last one is the end sentinel r1)
+        for (int32_t r = r0; r < r1; ++r) {
+          const int32_t i = brow[r], t = r0 + cnt[flev[i]]++;
+          order[t] = i;
+          ilu_of[i] = t;
+        }
+        cnt.assign((size_t)nblev[b] + 1, 0);
+        for (int32_t t = r0; t < r1; ++t) cnt[blev[order[t]] + 1]++;
+        for (int32_t l = 0; l < nblev[b]; ++l) cnt[l + 1] += cnt[l];
+        for (int32_t l = 0; l <= nblev[b]; ++l) bp[l] = r0 + cnt[l];
+        for (int32_t t = r0; t < r1; ++t) {
+          const int32_t pos = r0 + cnt[blev[order[t]]]++;
+          uord[pos] = t;
+          M->upos_of[t] = pos;
+          M->u_row[pos] = t - r0;  // local id of the row inside its execution block
+        }
+      }
+    });
+    M->rowmap = order;
+    lap("row order, level pointers");
+    // L (forward order) and U (backward order) storage: count, prefix, fill
     M->l_ptr.assign(n + 1, 0);
     M->u_ptr.assign(n + 1, 0);
     M->d_map.resize(n);
-    for (int64_t t = 0; t < n; ++t) {
-      int32_t i = order[t];
-      int32_t b0 = M->blk_ptr[lds ? part[i] : 0];
-      for (int32_t k = P.rowptr[i]; k < P.diag[i]; ++k)  // (shadow slots of a multigraph pattern hold no value: Pattern::shadow_slots)
-        if (part[P.col[k]] == part[i] && !P.is_shadow(k)) { M->l_col.push_back(ilu_of[P.col[k]] - b0); M->l_map.push_back(k); }
-      M->l_ptr[t + 1] = (int32_t)M->l_col.size();
+    parallel_ranges(n, 1 << 16, [&](int64_t t0, int64_t t1) {
+      for (int64_t t = t0; t < t1; ++t) {
+        const int32_t i = order[t], j = order[uord[t]];
+        int32_t nl = 0, nu = 0;
+        for (int32_t k = P.rowptr[i]; k < P.diag[i]; ++k)  // (shadow slots of a multigraph pattern hold no value: Pattern::shadow_slots)
+          nl += part[P.col[k]] == part[i] && !P.is_shadow(k);
+        for (int32_t k = P.diag[j] + 1; k < P.rowptr[j + 1]; ++k) nu += part[P.col[k]] == part[j] && !P.is_shadow(k);
+        M->l_ptr[t + 1] = nl;
+        M->u_ptr[t + 1] = nu;
+      }
+    });
+    {
+      int64_t sl = 0, su = 0;
+      for (int64_t t = 0; t < n; ++t) { sl += M->l_ptr[t + 1]; su += M->u_ptr[t + 1]; }
+      if (sl > INT32_MAX || su > INT32_MAX) JH_THROW("ILU(0): more than 2^31 - 1 entries in a factor");
     }
-    for (int64_t pos = 0; pos < n; ++pos) {
-      int32_t t = uord[pos];
-      int32_t i = order[t];
-      int32_t b0 = M->blk_ptr[lds ? part[i] : 0];
-      M->d_map[pos] = P.diag[i];
-      for (int32_t k = P.diag[i] + 1; k < P.rowptr[i + 1]; ++k)
-        if (part[P.col[k]] == part[i] && !P.is_shadow(k)) { M->u_col.push_back(ilu_of[P.col[k]] - b0); M->u_map.push_back(k); }
-      M->u_ptr[pos + 1] = (int32_t)M->u_col.size();
-    }
+    for (int64_t t = 0; t < n; ++t) { M->l_ptr[t + 1] += M->l_ptr[t]; M->u_ptr[t + 1] += M->u_ptr[t]; }
+    M->l_col.resize(M->l_ptr[n]);
+    M->l_map.resize(M->l_ptr[n]);
+    M->u_col.resize(M->u_ptr[n]);
+    M->u_map.resize(M->u_ptr[n]);
+    parallel_ranges(n, 1 << 16, [&](int64_t t0, int64_t t1) {
+      for (int64_t t = t0; t < t1; ++t) {
+        {
+          const int32_t i = order[t], b0 = M->blk_ptr[lds ? part[i] : 0];
+          int32_t w = M->l_ptr[t];
+          for (int32_t k = P.rowptr[i]; k < P.diag[i]; ++k)
+            if (part[P.col[k]] == part[i] && !P.is_shadow(k)) { M->l_col[w] = ilu_of[P.col[k]] - b0; M->l_map[w++] = k; }
+        }
+        {
+          const int64_t pos = t;
+          const int32_t i = order[uord[pos]], b0 = M->blk_ptr[lds ? part[i] : 0];
+          int32_t w = M->u_ptr[pos];
+          M->d_map[pos] = P.diag[i];
+          for (int32_t k = P.diag[i] + 1; k < P.rowptr[i + 1]; ++k)
+            if (part[P.col[k]] == part[i] && !P.is_shadow(k)) { M->u_col[w] = ilu_of[P.col[k]] - b0; M->u_map[w++] = k; }
+        }
+      }
+    });
     lap("L / U entries");
     if (lds) {
       int64_t mxl = 0, mxu = 0;
