@@ -39,7 +39,11 @@ struct Bisector {
   int64_t max_part;
   static constexpr int64_t hint_min = 65536;  // jobs above this size are shared between the threads, see partition_bisect
   Bisector(const PGraph &g, std::vector<int32_t> &lab, std::vector<int32_t> &&c, double imb, int64_t mp)
-      : G(g), label(lab), cells(std::move(c)), order(cells.size()), mark(g.n, 0), locked(g.n, 0), imbalance(imb), max_part(mp) {}
+      : G(g), label(lab), cells(std::move(c)), imbalance(imb), max_part(mp) {
+    resize_parallel(order, cells.size());
+    resize_parallel(mark, (size_t)g.n);
+    resize_parallel(locked, (size_t)g.n);
+  }
 
   inline double weight(int64_t k) const { return G.w ? G.w[k] : 1.0; }
 

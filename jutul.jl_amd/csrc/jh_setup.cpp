@@ -76,7 +76,7 @@ static Adj build_adjacency(int64_t nc, int64_t nf, const int64_t *N) {
   // all host cores: counts and cursors are bumped atomically, then every row is put back into ascending face order (what a
   // serial fill produces) so that nothing downstream depends on the thread timing
   Adj A;
-  A.ptr.assign(nc + 1, 0);
+  resize_parallel(A.ptr, (size_t)nc + 1);
   int64_t *ptr = A.ptr.data();
   parallel_ranges(nf, 1 << 18, [&](int64_t f0, int64_t f1) {
     for (int64_t f = f0; f < f1; ++f) {
@@ -89,9 +89,11 @@ static Adj build_adjacency(int64_t nc, int64_t nf, const int64_t *N) {
     }
   });
   for (int64_t c = 0; c < nc; ++c) A.ptr[c + 1] += A.ptr[c];
-  A.nbr.resize(A.ptr[nc]);
-  A.sface.resize(A.ptr[nc]);
-  std::vector<int64_t> cur(A.ptr.begin(), A.ptr.end() - 1);
+  resize_parallel(A.nbr, (size_t)A.ptr[nc]);
+  resize_parallel(A.sface, (size_t)A.ptr[nc]);
+  std::vector<int64_t> cur;
+  resize_parallel(cur, (size_t)nc);
+  parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { std::copy(A.ptr.begin() + b, A.ptr.begin() + e, cur.begin() + b); });
   int64_t *cu = cur.data();
   parallel_ranges(nf, 1 << 18, [&](int64_t f0, int64_t f1) {
     for (int64_t f = f0; f < f1; ++f) {
@@ -177,14 +179,19 @@ struct PhaseTimer {
 static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, std::vector<int32_t> &perm, std::vector<int32_t> &block_ptr) {
   const int64_t nparts = std::max<int64_t>(1, (nc + block_rows / 2) / block_rows);
   const int64_t max_part = std::max<int64_t>(block_rows + block_rows / 8, (nc + nparts - 1) / nparts);
-  std::vector<int32_t> label(A.ptr.size() - 1, -1);
+  std::vector<int32_t> label;
+  resize_parallel(label, A.ptr.size() - 1);
+  parallel_ranges((int64_t)label.size(), 1 << 18, [&](int64_t b, int64_t e) { std::fill(label.begin() + b, label.begin() + e, -1); });
   PhaseTimer pt;
   {
     // The input numbering may be arbitrary (the bench grid's is scrambled): every sweep of the partitioner would miss the
     // cache on every cell.  One breadth-first renumbering first (neighbours end up close in memory), the bisections run on the
     // renumbered graph of the owned cells, the labels are mapped back.
-    std::vector<int32_t> ord, newid(nc, -1);
-    ord.reserve(nc);
+    std::vector<int32_t> ord, newid;
+    resize_parallel(ord, (size_t)nc);  // (touches the pages)
+    ord.clear();
+    resize_parallel(newid, (size_t)nc);
+    parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { std::fill(newid.begin() + b, newid.begin() + e, -1); });
     int64_t first_piece = 0;  // cells of the first connected piece: its last cell is a far end of the graph
     for (int64_t s0 = 0; s0 < nc; ++s0) {
       if (newid[s0] >= 0) continue;
@@ -202,7 +209,8 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
       if (s0 == 0) first_piece = (int64_t)ord.size();
     }
     pt.lap("  blocks: renumber");
-    std::vector<int64_t> ptr2(nc + 1, 0);
+    std::vector<int64_t> ptr2;
+    resize_parallel(ptr2, (size_t)nc + 1);
     parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
       for (int64_t i = b; i < e; ++i) {
         const int32_t c = ord[i];
@@ -212,7 +220,8 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
       }
     });
     for (int64_t i = 0; i < nc; ++i) ptr2[i + 1] += ptr2[i];
-    std::vector<int32_t> nbr2(ptr2[nc]);
+    std::vector<int32_t> nbr2;
+    resize_parallel(nbr2, (size_t)ptr2[nc]);
     parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
       for (int64_t i = b; i < e; ++i) {
         const int32_t c = ord[i];
@@ -221,13 +230,15 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
           if (A.nbr[k] < nc) nbr2[w++] = newid[A.nbr[k]];
       }
     });
-    std::vector<int32_t> lab2(nc, 0), cells(nc);
-    std::iota(cells.begin(), cells.end(), 0);
+    std::vector<int32_t> lab2, cells;
+    resize_parallel(lab2, (size_t)nc);
+    resize_parallel(cells, (size_t)nc);
+    parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { std::iota(cells.begin() + b, cells.begin() + e, (int32_t)b); });
     PGraph G{nc, ptr2.data(), nbr2.data(), nullptr};
     pt.lap("  blocks: graph");
     partition_bisect(G, std::move(cells), nparts, 0.04, max_part, lab2, (int32_t)(first_piece - 1));
     pt.lap("  blocks: bisection");
-    for (int64_t i = 0; i < nc; ++i) label[ord[i]] = lab2[i];
+    parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) label[ord[i]] = lab2[i]; });
   }
   std::vector<int32_t> cnt(nparts + 1, 0);
   for (int64_t c = 0; c < nc; ++c) cnt[label[c] + 1]++;
@@ -236,9 +247,11 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
   perm.resize(nc);
   std::vector<int32_t> cur(block_ptr.begin(), block_ptr.end() - 1);
   for (int64_t c = 0; c < nc; ++c) perm[cur[label[c]]++] = (int32_t)c;
-  const int64_t nall = (int64_t)A.ptr.size() - 1;
+  // (the blocks are disjoint: one distance array serves all threads; centre_bfs_order resets the entries of its own cells)
+  std::vector<int32_t> dist;
+  resize_parallel(dist, A.ptr.size() - 1);
   parallel_ranges(nparts, 8, [&](int64_t b0, int64_t b1) {
-    std::vector<int32_t> bq, dist(nall, -1);
+    std::vector<int32_t> bq;
     for (int64_t b = b0; b < b1; ++b)
       centre_bfs_order(A, label, (int32_t)b, perm.data() + block_ptr[b], block_ptr[b + 1] - block_ptr[b], dist, bq);
   });
@@ -460,7 +473,8 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
     d->nhf = 2 * nf;
     d->N = block_n;
     PhaseTimer pt;
-    d->Nhost.assign(N, N + 2 * nf);
+    resize_parallel(d->Nhost, (size_t)(2 * nf));
+    parallel_ranges(2 * nf, 1 << 18, [&](int64_t b, int64_t e) { std::copy(N + b, N + e, d->Nhost.begin() + b); });
     Adj A = build_adjacency(nc, nf, N);
     pt.lap("adjacency");
     if (n_owned <= 0 || n_owned > nc) n_owned = nc;
@@ -485,26 +499,31 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
       for (int64_t i = n_owned; i < nc; ++i)
         if (pat->perm[i] < n_owned) JH_THROW("partition must keep the ghost cells (>= n_owned) as the last device rows");
     if (!ident) {
-      pat->iperm.resize(nc);
-      for (int64_t i = 0; i < nc; ++i) pat->iperm[pat->perm[i]] = (int32_t)i;
+      resize_parallel(pat->iperm, (size_t)nc);
+      parallel_ranges(nc, 1 << 16, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) pat->iperm[pat->perm[i]] = (int32_t)i; });
     }
     // device CSR: row i = host cell perm[i]; columns mapped to device numbering, ascending; diagonal present
-    pat->rowptr.resize(nc + 1);
+    resize_parallel(pat->rowptr, (size_t)nc + 1);
     pat->rowptr[0] = 0;
-    for (int64_t i = 0; i < nc; ++i) {
-      int64_t h = ident ? i : pat->perm[i];
-      pat->rowptr[i + 1] = pat->rowptr[i] + (int32_t)(A.ptr[h + 1] - A.ptr[h]) + 1;
-    }
+    parallel_ranges(nc, 1 << 16, [&](int64_t b, int64_t e) {
+      for (int64_t i = b; i < e; ++i) {
+        const int64_t h = ident ? i : pat->perm[i];
+        pat->rowptr[i + 1] = (int32_t)(A.ptr[h + 1] - A.ptr[h]) + 1;
+      }
+    });
+    for (int64_t i = 0; i < nc; ++i) pat->rowptr[i + 1] += pat->rowptr[i];
     pat->nnzb = pat->rowptr[nc];
     d->nnzb = pat->nnzb;
-    pat->col.resize(pat->nnzb);
-    pat->diag.resize(nc);
-    d->nz_face.resize(pat->nnzb);
+    resize_parallel(pat->col, (size_t)pat->nnzb);
+    resize_parallel(pat->diag, (size_t)nc);
+    resize_parallel(d->nz_face, (size_t)pat->nnzb);
     // host CSR (host numbering) rowptr to compute host slots: row h has (distinct neighbours of h) + 1 entries, ascending host cols
-    std::vector<int64_t> hrp(nc + 1, 0);
+    std::vector<int64_t> hrp;
+    resize_parallel(hrp, (size_t)nc + 1);
     bool multigraph = false;
     {
-      std::vector<int32_t> ucount(nc);
+      std::vector<int32_t> ucount;
+      resize_parallel(ucount, (size_t)nc);
       std::vector<char> dup_in_range;
       parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
         std::vector<int32_t> nb;
@@ -520,7 +539,7 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
       }
     }
     pat->nnzb_host = hrp[nc];
-    if (!ident || multigraph) pat->nz_hslot.resize(pat->nnzb);
+    if (!ident || multigraph) resize_parallel(pat->nz_hslot, (size_t)pat->nnzb);
     if (multigraph) pat->shadow_flag.assign(pat->nnzb, 0);
     // rows are independent: sorted device columns, signed face ids, diagonal slot, host slots -- on all host cores
     parallel_ranges(nc, 4096, [&](int64_t r_begin, int64_t r_end) {
