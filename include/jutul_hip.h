@@ -34,6 +34,7 @@ typedef struct jh_csr_s *jh_csr;         /* StaticSparsityMatrixCSR on the devic
 typedef struct jh_vec_s *jh_vec;         /* r_buffer / dx_buffer-like device vector (default.jl:188-226)    */
 typedef struct jh_law_s *jh_law;         /* ConservationLaw + ConservationLawTPFAStorage (conservation.jl:101-135) */
 typedef struct jh_ilu_s *jh_ilu;         /* ILUFactorCSR / ParallelILUFactorCSR (ilu0.jl:190-203, par_ilu0.jl:2-5) */
+typedef struct jh_subdomain_s *jh_subdomain; /* one rank's share of a partitioned grid (dd/subdomains.jl:77-182)            */
 typedef struct jh_krylov_s *jh_krylov;   /* GenericKrylov(:bicgstab) workspace (linsolve/krylov.jl:27-58)   */
 
 /* ---- errors / context ------------------------------------------------------------------------------- */
@@ -326,6 +327,24 @@ int32_t jh_halo_ipc_enable(jh_tpfa d, int32_t enable);
  * the host-side subdomain logic: any partitioner can be used instead. */
 int32_t jh_partition_graph(int64_t nc, int64_t nf, const int64_t *N, const double *face_weights, int64_t nparts, double imbalance,
                            int64_t *out);
+/* Recursive coordinate bisection of nc points (X: point-major, dim = 1..3 coordinates each) into nparts compact parts,
+ * out[c] in 1..nparts -- the build-side partitioner when centroids are at hand (role of partitioning.jl:29-51). */
+int32_t jh_partition_rcb(int64_t nc, int32_t dim, const double *X, int64_t nparts, int64_t *out);
+/* The rank-local subdomain PArraySimulator builds from a partition vector (ext/JutulPartitionedArraysExt/interface.jl:38-63,
+ * submap_cells with buffer = 0, dd/subdomains.jl:77-182): local cells = [owned, ascending global id ..., ghosts ...], the
+ * faces with both cells local, the local neighbourship and the halo plan.  rank is 1-based like the partition ids.
+ * ghost_order 0: ghosts by ascending global id (the reference's order); 1: by (owning rank, global id), so that every
+ * neighbour's ghosts are consecutive local cells (jh_halo_create then receives straight into the vectors).
+ * sizes[5] = n_owned, n_local, local faces, neighbours, total send cells (total receive cells = n_local - n_owned).
+ * jh_subdomain_get copies out (any pointer may be NULL): cells[n_local] and faces[...] are 1-based global ids, N_local the
+ * local pairs [l0, r0, l1, r1, ...] (1-based), neighbors 0-based ranks ascending, send/recv_ptr[neighbours + 1] offsets into
+ * send/recv_idx (1-based local cells).  Host work on all cores, no device needed. */
+int32_t jh_subdomain_create(int64_t nc, int64_t nf, const int64_t *N, const int64_t *partition, int64_t rank, int32_t ghost_order,
+                            jh_subdomain *out);
+int32_t jh_subdomain_sizes(jh_subdomain s, int64_t *sizes);
+int32_t jh_subdomain_get(jh_subdomain s, int64_t *cells, int64_t *faces, int64_t *N_local, int32_t *neighbors, int64_t *send_ptr,
+                         int64_t *send_idx, int64_t *recv_ptr, int64_t *recv_idx);
+int32_t jh_subdomain_destroy(jh_subdomain s);
 /* consistent!(v) (ext/.../linalg.jl:46, krylov.jl:54,75; interface.jl:200): owner values -> ghosts */
 int32_t jh_halo_exchange(jh_tpfa d, jh_vec v);
 int32_t jh_halo_exchange_state(jh_law L);

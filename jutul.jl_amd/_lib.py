@@ -121,6 +121,11 @@ SIGNATURES = {
     "jh_halo_exchange_state": [H],
     "jh_allreduce": [H, F64P, C.c_int32, C.c_int32],
     "jh_partition_graph": [C.c_int64, C.c_int64, I64P, F64P, C.c_int64, C.c_double, I64P],
+    "jh_partition_rcb": [C.c_int64, C.c_int32, F64P, C.c_int64, I64P],
+    "jh_subdomain_create": [C.c_int64, C.c_int64, I64P, I64P, C.c_int64, C.c_int32, C.POINTER(H)],
+    "jh_subdomain_sizes": [H, I64P],
+    "jh_subdomain_get": [H, I64P, I64P, I64P, C.POINTER(C.c_int32), I64P, I64P, I64P, I64P],
+    "jh_subdomain_destroy": [H],
 }
 
 

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libjutul_hip.so")
 SOURCES = ["jh_setup.cpp", "jh_api.cpp", "jh_comm.cpp", "jh_kernels.hip", "jh_assembly.hip", "jh_ilu.hip",
-           "jh_krylov.hip", "jh_halo.hip", "jh_custom.cpp", "jh_sell.hip", "jh_partition.cpp"]
+           "jh_krylov.hip", "jh_halo.hip", "jh_custom.cpp", "jh_sell.hip", "jh_partition.cpp", "jh_subdomain.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-I/opt/rocm/include"]
 

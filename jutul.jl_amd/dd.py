@@ -109,27 +109,18 @@ def process_partition(N, partition, weights=None):
 def partition_rcb(centroids, nparts):
     """Recursive coordinate bisection into `nparts` (any integer) compact parts; 1-based part ids.
     Build-side stand-in for MetisPartitioner (partitioning.jl:29-51; Metis.jl is an un-vendored C library):
-    the partition vector is an INPUT to the hot path, any valid vector works."""
+    the partition vector is an INPUT to the hot path, any valid vector works.  Runs inside libjutul_hip.so on all host
+    cores (jh_partition_rcb; no GPU needed)."""
+    from . import _lib
     X = np.asarray(centroids, dtype=np.float64)
+    if X.ndim == 1:
+        X = X[:, None]
     if X.shape[0] in (1, 2, 3) and X.shape[1] > 3:
         X = X.T
-    n = X.shape[0]
-    part = np.zeros(n, dtype=np.int64)
-
-    def rec(idx, k, first):
-        if k == 1:
-            part[idx] = first
-            return
-        kl = k // 2
-        ext = X[idx].max(axis=0) - X[idx].min(axis=0)
-        ax = int(np.argmax(ext))
-        nl = int(round(len(idx) * kl / k))
-        order = np.argpartition(X[idx, ax], nl - 1) if 0 < nl < len(idx) else np.arange(len(idx))
-        rec(idx[order[:nl]], kl, first)
-        rec(idx[order[nl:]], k - kl, first + kl)
-
-    rec(np.arange(n), int(nparts), 1)
-    return part
+    X = np.ascontiguousarray(X)
+    out = np.zeros(X.shape[0], dtype=np.int64)
+    _lib.check(_lib.load().jh_partition_rcb(X.shape[0], X.shape[1], _lib.pf(X), int(nparts), _lib.pi(out)))
+    return out
 
 
 # ---- distributed numbering (ext/JutulPartitionedArraysExt/utils.jl) --------------------------------------------------------
@@ -186,39 +177,34 @@ def local_subdomain(N, p, rank, ghost_order="global"):
     dd/subdomains.jl:77-182): cells = [owned (findall order) ..., ghosts (ascending global id) ...]; faces kept iff
     both cells are local.  `rank` is 1-based.  All returned index arrays are 1-based.
     ghost_order="owner" sorts the ghosts by (owning rank, global id) instead: every neighbour's ghosts are then consecutive
-    local cells and the device library receives them straight into the vectors (no unpack kernel)."""
-    N = np.asarray(N, dtype=np.int64)
-    p = np.asarray(p, dtype=np.int64)
-    nc = p.size
-    l, r = N[0] - 1, N[1] - 1
-    mine = p == rank
-    il, ir = mine[l], mine[r]
-    owned = np.flatnonzero(mine)
-    ghosts = np.unique(np.concatenate([r[il & ~ir], l[ir & ~il]]))
-    if ghost_order == "owner":
-        ghosts = ghosts[np.lexsort((ghosts, p[ghosts]))]
-    elif ghost_order != "global":
+    local cells and the device library receives them straight into the vectors (no unpack kernel).
+    Built inside libjutul_hip.so on all host cores (jh_subdomain_*; no GPU needed)."""
+    import ctypes as C
+    from . import _lib
+    if ghost_order not in ("global", "owner"):
         raise ValueError("ghost_order must be 'global' or 'owner'")
-    n_owned = owned.size
-    g2l = np.full(nc, -1, dtype=np.int64)
-    g2l[owned] = np.arange(n_owned)
-    g2l[ghosts] = n_owned + np.arange(ghosts.size)
-    keep = (g2l[l] >= 0) & (g2l[r] >= 0)
-    faces = np.flatnonzero(keep)
-    N_local = np.stack([g2l[l[keep]], g2l[r[keep]]]) + 1
-    # halo plan
-    gp = p[ghosts]
-    nbr = np.unique(gp)
-    recv = [n_owned + np.flatnonzero(gp == s) + 1 for s in nbr]
-    # cells I own that are ghosts on rank s: owned endpoints of faces crossing to s (ascending global id)
-    cell_a = np.concatenate([l[il & ~ir], r[ir & ~il]])
-    rank_b = np.concatenate([p[r[il & ~ir]], p[l[ir & ~il]]])
-    send = []
-    for s in nbr:
-        c = np.unique(cell_a[rank_b == s])
-        send.append(g2l[c] + 1)
-    return dict(cells=np.concatenate([owned, ghosts]) + 1, n_owned=n_owned, n_local=n_owned + ghosts.size, faces=faces + 1,
-                N=np.ascontiguousarray(N_local), neighbors=(nbr - 1).astype(np.int32), send=send, recv=recv)
+    L = _lib.load()
+    N = np.asarray(N, dtype=np.int64)
+    p = _lib.i64(p)
+    Nf = np.ascontiguousarray(np.asfortranarray(N).T.reshape(-1))
+    h = C.c_void_p()
+    _lib.check(L.jh_subdomain_create(p.size, N.shape[1], _lib.pi(Nf), _lib.pi(p), int(rank), 1 if ghost_order == "owner" else 0, C.byref(h)))
+    try:
+        sz = np.zeros(5, dtype=np.int64)
+        _lib.check(L.jh_subdomain_sizes(h, _lib.pi(sz)))
+        n_owned, n_local, nfl, nn, nsend = (int(v) for v in sz)
+        cells = np.empty(n_local, dtype=np.int64)
+        faces = np.empty(nfl, dtype=np.int64)
+        Nl = np.empty(2 * nfl, dtype=np.int64)
+        nbr = np.empty(nn, dtype=np.int32)
+        sp, rp = np.empty(nn + 1, dtype=np.int64), np.empty(nn + 1, dtype=np.int64)
+        si, ri = np.empty(nsend, dtype=np.int64), np.empty(n_local - n_owned, dtype=np.int64)
+        _lib.check(L.jh_subdomain_get(h, _lib.pi(cells), _lib.pi(faces), _lib.pi(Nl), _lib.pi32(nbr), _lib.pi(sp), _lib.pi(si),
+                                      _lib.pi(rp), _lib.pi(ri)))
+    finally:
+        L.jh_subdomain_destroy(h)
+    return dict(cells=cells, n_owned=n_owned, n_local=n_local, faces=faces, N=np.ascontiguousarray(Nl.reshape(nfl, 2).T),
+                neighbors=nbr, send=[si[sp[k]:sp[k + 1]] for k in range(nn)], recv=[ri[rp[k]:rp[k + 1]] for k in range(nn)])
 
 
 class HostExchange:
