@@ -264,6 +264,8 @@ static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block
   perm.clear();
   perm.reserve(nc_all);
   block_ptr.assign(1, 0);
+  // JH_BLOCK_ORDER (development switch): unset / "bisect" = blocks by graph bisection (the default, above); "onion", "layers",
+  // "bfs", "center" = round 1's blocks grown along the rim of the assigned region, with the in-block order named below
   static const bool onion = [] { const char *e = getenv("JH_BLOCK_ORDER"); return e && std::string(e) != "bisect"; }();
   if (!onion) blocks_by_bisection(A, nc, block_rows, perm, block_ptr);
   std::vector<int32_t> blk(nc_all, -1);
@@ -272,7 +274,7 @@ static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block
   size_t cand_head = 0;
   std::vector<int32_t> q;
   q.reserve(block_rows);
-  // Order inside a block (JH_BLOCK_ORDER): "bfs" = growth order; "layers" (default) = by BFS layer from the seed and, inside a
+  // Order inside an onion block: "bfs" = growth order; "layers" / "onion" = by BFS layer from the seed and, inside a
   // layer, by a greedy colouring of the layer's own adjacencies.  ILU(0) depends on the ordering only through the orientation
   // of the edges (which endpoint is eliminated first); growth order chains the cells of a layer one after the other (a
   // 512-cell block has ~65 dependency levels), colouring the layer keeps every cross-layer orientation and leaves

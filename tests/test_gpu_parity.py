@@ -327,6 +327,42 @@ def test_ilu0_device_blocks_on_tpfa_jacobian(ja, ctx, oracle):
     assert F.info()["nblocks"] == len(bp) - 1
 
 
+def test_device_blocks_come_from_graph_bisection(ja, ctx):
+    """JH_REORDER_BLOCKS: the device blocks (= block-Jacobi ILU(0) partition, the job Metis does for the reference,
+    precond/ilu.jl:37-60) are a valid partition into round(nc / block_rows) connected-looking compact blocks, none above the
+    size cap (block_rows + 1/8), ghost cells of a rank-local subdomain stay the last device rows, and the cut is the one
+    of compact blocks (well below what blocks grown along the rim of the assigned region give: 18 % on this lattice)."""
+    g = ja.tet_lattice_mesh(22, 20, 18)
+    nc, N = g["nc"], g["N"]
+    rows = 256
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, reorder="blocks", block_rows=rows)
+    perm, bp = disc.ordering()
+    assert np.array_equal(np.sort(perm), np.arange(1, nc + 1))
+    sizes = np.diff(bp)
+    assert bp[0] == 0 and bp[-1] == nc and sizes.min() >= 1 and sizes.max() <= rows + rows // 8
+    assert len(sizes) == (nc + rows // 2) // rows
+    blk = np.zeros(nc, dtype=np.int64)
+    blk[perm - 1] = np.repeat(np.arange(len(sizes)), sizes)
+    cut = (blk[N[0] - 1] != blk[N[1] - 1]).mean()
+    assert cut < 0.165, cut
+    # the blocks are connected (bisection of a connected lattice with breadth-first grown sides) up to the few cells the
+    # refinement moves across a cut without their neighbours
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csg
+    same = blk[N[0] - 1] == blk[N[1] - 1]
+    G = sp.coo_matrix((np.ones(int(same.sum())), (N[0][same] - 1, N[1][same] - 1)), shape=(nc, nc))
+    ncomp, _ = csg.connected_components(G, directed=False)
+    assert ncomp <= len(sizes) + max(2, len(sizes) // 16), (ncomp, len(sizes))
+    # rank-local subdomain: owned cells in blocks, ghosts last
+    from jutul_amd import dd
+    part = dd.partition_rcb(g["cell_centroids"], 2)
+    sub = dd.local_subdomain(N, part, 1)
+    d2 = ja.TwoPointPotentialFlowHardCoded(ctx, sub["N"], sub["n_local"], reorder="blocks", block_rows=rows, n_owned=sub["n_owned"])
+    perm2, bp2 = d2.ordering()
+    assert np.array_equal(np.sort(perm2), np.arange(1, sub["n_local"] + 1))
+    assert perm2[sub["n_owned"]:].min() > sub["n_owned"] and perm2[: sub["n_owned"]].max() <= sub["n_owned"]
+
+
 # ---- a-14: BiCGStab ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("side", ["right", "left"])
 @pytest.mark.parametrize("bs", [1, 2])
