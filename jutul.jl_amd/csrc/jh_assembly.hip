@@ -105,41 +105,6 @@ __device__ __forceinline__ void flux_scalar(double Us, double Uo, double T, doub
     dother = f.d[1];
   }
 }
-// Two-phase half-face flux (immiscible, SPU upwind; flux.jl:335-405) of phase ph with its partials w.r.t. (p_self, sw_self,
-// p_other, sw_other).  This IS the Dual<4> evaluation `T * (upwind(m_self, m_other) * dphi)` written out with the structurally
-// zero partials dropped (x*0 + y = y in IEEE arithmetic: same bits, a third of the vector instructions -- the generic form was
-// bound by fp64 issue, 89 % of the issue slots, profiles/r02_twophase_counters_*), and with exp(c (p - p_ref)) of both cells
-// handed in: it is evaluated once per CELL by the row lanes (the reference's secondary-variable pattern,
-// variable_evaluation.jl) instead of four times per entry.
-__device__ __forceinline__ void flux_twophase(int ph, const LawPar &par, double T, double gz, double psv, double sws, double pov,
-                                              double swo, double es, double eo, double &q, double d[4]) {
-  const double c = par.comp[ph], r0 = par.rho0[ph], imu = 1.0 / par.mu[ph];
-  const double rs = r0 * es, drs = r0 * (es * c);  // density and d/dp (density(), dexp)
-  const double ro = r0 * eo, dro = r0 * (eo * c);
-  const double ravg = 0.5 * (rs + ro);             // face_average
-  const double dphi = (psv - pov) + gz * ravg;     // two_point_potential_drop
-  const double dphi_ps = 1.0 + gz * (0.5 * drs), dphi_po = -1.0 + gz * (0.5 * dro);
-  const double sg = ph == 0 ? 1.0 : -1.0;          // d s_phase / d sw
-  if (dphi < 0.0) {                                // SPU upwind: the other cell's mobility
-    const double so = ph == 0 ? swo : 1.0 - swo;
-    const double so2 = so * so, dso2 = sg * so + so * sg;
-    const double mo = imu * (so2 * ro), mo_p = imu * (so2 * dro), mo_s = imu * (dso2 * ro);
-    q = T * (mo * dphi);
-    d[0] = T * (mo * dphi_ps);
-    d[1] = T * 0.0;
-    d[2] = T * (mo_p * dphi + mo * dphi_po);
-    d[3] = T * (mo_s * dphi);
-  } else {
-    const double ss = ph == 0 ? sws : 1.0 - sws;
-    const double ss2 = ss * ss, dss2 = sg * ss + ss * sg;
-    const double ms = imu * (ss2 * rs), ms_p = imu * (ss2 * drs), ms_s = imu * (dss2 * rs);
-    q = T * (ms * dphi);
-    d[0] = T * (ms_p * dphi + ms * dphi_ps);
-    d[1] = T * (ms_s * dphi);
-    d[2] = T * (ms * dphi_po);
-    d[3] = T * 0.0;
-  }
-}
 // ---- the kernel -------------------------------------------------------------------------------------------------
 template <int KIND>
 __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
@@ -158,10 +123,6 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
   __shared__ double xs[(TILE_ROWS + 2 * WIN) * N];  // primary variables of rows [w0, w0 + wn)
   __shared__ int32_t rp[TILE_ROWS + 1];
   __shared__ uint8_t rowof[TNNZ];
-  // two-phase: exp(c_ph (p - p_ref)) of the window's cells, one evaluation per CELL.  Lives in qv's storage until the entry
-  // lanes have picked their values up (a separate 4 KB array costs the fifth resident workgroup per CU: 0.52 -> 0.575 ms)
-  static_assert(KIND != JH_LAW_TWOPHASE || (TILE_ROWS + 2 * WIN) * 2 <= TNNZ * N, "ex must fit into qv");
-  double *ex = qv;
   const int t = xcd_tile_a(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int4 td = reinterpret_cast<const int4 *>(tile_row)[t];  // tile descriptor (Pattern::tile_desc): one load, not a chain
@@ -186,12 +147,6 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
   __syncthreads();
   if (tid < nrows)
     for (int j = rp[tid]; j < rp[tid + 1]; ++j) rowof[j] = (uint8_t)tid;
-  if (KIND == JH_LAW_TWOPHASE)
-    for (int i = tid; i < wn; i += TILE_THREADS) {
-      const double p = xs[i * 2];
-      ex[i * 2] = exp(par.comp[0] * (p - par.p_ref));
-      ex[i * 2 + 1] = exp(par.comp[1] * (p - par.p_ref));
-    }
   __syncthreads();
   // ---- phase 1: one lane per CSR entry -------------------------------------------------------------------
   // The off-diagonal blocks stay in registers until phase 3 so that every nzval line of the tile is written once,
@@ -199,24 +154,6 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
   // cells, measured with WRITE_SIZE).
   double off[KPT][NN];
   bool isdiag[KPT];
-  double e_s[KIND == JH_LAW_TWOPHASE ? KPT : 1][2], e_o[KIND == JH_LAW_TWOPHASE ? KPT : 1][2];
-  if (KIND == JH_LAW_TWOPHASE) {
-#pragma unroll
-    for (int kk = 0; kk < KPT; ++kk) {
-      const int k = tid + kk * TILE_THREADS;
-      if (k < cnt) {
-        const int lr = rowof[k], c = cidx[kk];
-        const unsigned cw = (unsigned)(c - w0);
-        const bool inl = cw < (unsigned)wn;
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-          e_s[kk][ph] = ex[(own + lr) * 2 + ph];
-          e_o[kk][ph] = inl ? ex[cw * 2 + ph] : exp(par.comp[ph] * (X[(size_t)c * 2] - par.p_ref));
-        }
-      }
-    }
-    __syncthreads();  // ex (= qv) is overwritten from here on
-  }
 #pragma unroll
   for (int kk = 0; kk < KPT; ++kk) {
     const int k = tid + kk * TILE_THREADS;
@@ -244,17 +181,25 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
       off[kk][0] = dother_;
     } else {
       const double gz = gnz ? gnz[base + k] : 0.0;
-      const double psv = xs[(own + lr) * 2], sws = xs[(own + lr) * 2 + 1];
-      const double pov = inl ? xs[cw * 2] : X[(size_t)c * 2], swo = inl ? xs[cw * 2 + 1] : X[(size_t)c * 2 + 1];
+      Dual<4> ps = dvar<4>(xs[(own + lr) * 2], 0), ss_w = dvar<4>(xs[(own + lr) * 2 + 1], 1);
+      Dual<4> po = dvar<4>(inl ? xs[cw * 2] : X[(size_t)c * 2], 2);
+      Dual<4> so_w = dvar<4>(inl ? xs[cw * 2 + 1] : X[(size_t)c * 2 + 1], 3);
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph) {
-        double q, d[4];
-        flux_twophase(ph, par, T, gz, psv, sws, pov, swo, e_s[kk][ph], e_o[kk][ph], q, d);
-        qv[k * 2 + ph] = q;
-        dsv[k * 4 + 0 * 2 + ph] = d[0];  // (e=ph, d=0) column-major
-        dsv[k * 4 + 1 * 2 + ph] = d[1];
-        off[kk][(0 * 2 + ph) % NN] = d[2];
-        off[kk][(1 * 2 + ph) % NN] = d[3];
+        Dual<4> rs = density(par, ph, ps), ro = density(par, ph, po);
+        Dual<4> ravg = 0.5 * (rs + ro);
+        Dual<4> dphi = (ps - po) + gz * ravg;
+        Dual<4> ss = ph == 0 ? ss_w : dconst<4>(1.0) - ss_w;
+        Dual<4> so = ph == 0 ? so_w : dconst<4>(1.0) - so_w;
+        Dual<4> ms = (1.0 / par.mu[ph]) * ((ss * ss) * rs);
+        Dual<4> mo = (1.0 / par.mu[ph]) * ((so * so) * ro);
+        Dual<4> up = (dphi.v < 0.0) ? mo : ms;  // SPU upwind (flux.jl:382-405)
+        Dual<4> q = T * (up * dphi);
+        qv[k * 2 + ph] = q.v;
+        dsv[k * 4 + 0 * 2 + ph] = q.d[0];  // (e=ph, d=0) column-major
+        dsv[k * 4 + 1 * 2 + ph] = q.d[1];
+        off[kk][(0 * 2 + ph) % NN] = q.d[2];
+        off[kk][(1 * 2 + ph) % NN] = q.d[3];
       }
     }
   }
