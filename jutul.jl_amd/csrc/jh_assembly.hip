@@ -126,7 +126,7 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
   const int t = xcd_tile_a(blockIdx.x, ntiles);
   if (t >= ntiles) return;
   const int4 td = reinterpret_cast<const int4 *>(tile_row)[t];  // tile descriptor (Pattern::tile_desc): one load, not a chain
-  const int r0 = td.x, nrows = td.y, r1 = r0 + nrows, base = td.z;
+  const int r0 = td.x, nrows = td.y, base = td.z;
   const int cnt = td.w;  // TPFA rows are short: cnt <= TILE_NNZ is guaranteed by the host (checked)
   const int tid = threadIdx.x;
   constexpr int KPT = TNNZ / TILE_THREADS;  // entries per lane
