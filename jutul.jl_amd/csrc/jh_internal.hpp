@@ -351,7 +351,8 @@ int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x,
 // jh_sell.hip: jagged-slice SpMV with the same fused-dot contract; A->jval must be fresh (sell_refresh)
 constexpr int JDS_KMAX = 8;
 bool sell_refresh(jh_csr A);  // false: the matrix has no jagged form (block size > 1 or long rows) -> CSR tile kernels
-int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done);
+int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done,
+                bool reduce_now = true);
 void spmv_dot_reduce(jh_context ctx, const SpmvDot *dot, int nparts, const double *done);
 void ensure_partials(jh_context ctx, size_t min_stride);
 void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max, const double *done = nullptr,

@@ -261,8 +261,15 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   auto spmv = [&](double *in, double *out, const SpmvDot *dot, bool packed = false) {
     if (dist) halo_exchange(disc, in, P.bs, packed, true);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
     K->mark(0, st);
-    if (jagged) k_spmv_sell(K->A, in, out, 1.0, 0.0, dot, done);
-    else k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done);  // dot->allreduce: summed over the ranks in there
+    if (jagged) {
+      // the event pair brackets the product kernel alone (what rocprofv3 reports for it); the second stage of its fused dot,
+      // with the all-reduce over the ranks, follows
+      const int nparts = k_spmv_sell(K->A, in, out, 1.0, 0.0, dot, done, false);
+      K->mark(0, st);
+      if (dot && dot->mode) spmv_dot_reduce(ctx, dot, nparts, done);
+      return;
+    }
+    k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done);  // dot->allreduce: summed over the ranks in there
     K->mark(0, st);
   };
   K->cur_it = 0;

@@ -205,7 +205,8 @@ bool sell_refresh(jh_csr A) {
   return true;
 }
 
-int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done) {
+// reduce_now = false: the caller launches the second stage of the fused dot itself (spmv_dot_reduce with the returned count)
+int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done, bool reduce_now) {
   jh_context ctx = A->ctx;
   const Pattern &P = *A->pat;
   const auto &J = P.jag;
@@ -228,7 +229,7 @@ int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta,
     if (mode == 0) JH_JDS(8, 0); else if (mode == 1) JH_JDS(8, 1); else JH_JDS(8, 2);
   }
 #undef JH_JDS
-  if (mode) spmv_dot_reduce(ctx, dot, (int)grid.x, done);
+  if (mode && reduce_now) spmv_dot_reduce(ctx, dot, (int)grid.x, done);
   return (int)grid.x;
 }
 
