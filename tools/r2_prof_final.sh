@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+bash tools/collect_profiles.sh r02f > gpurun_out/prof_f.log 2>&1
+PMC_PASSES="fetch write sq_time sq_inst tcc tcp" bash tools/pmc_passes.sh r02f > gpurun_out/pmc_f.log 2>&1
+tail -2 gpurun_out/prof_f.log | cut -c1-300
