@@ -33,6 +33,7 @@ extern "C" int32_t jh_context_create(int32_t device_id, jh_context *out) {
     JH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     JH_HIP(hipEventCreate(&c->ev0));
     JH_HIP(hipEventCreate(&c->ev1));
+    for (auto &e : c->ev_step) JH_HIP(hipEventCreate(&e));
     c->scalars.alloc(32);
     JH_HIP(hipMemsetAsync(c->scalars.p, 0, 32 * sizeof(double), c->stream));
     JH_HIP(hipHostMalloc((void **)&c->h_scalars, 32 * sizeof(double), hipHostMallocDefault));
@@ -50,6 +51,7 @@ extern "C" int32_t jh_context_destroy(jh_context ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto e : ctx->ev_step) if (e) (void)hipEventDestroy(e);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     if (ctx->h_pub) (void)hipHostFree(ctx->h_pub);
     if (ctx->comm_stream) {

@@ -160,6 +160,7 @@ struct jh_context_s {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_step[6] = {};  // jh_newton_step: factor / solve / update brackets, read once at the end of the step
   // reduction scratch: partial sums [NSLOT][max_blocks], device scalars, pinned host mirror
   jh::DevBuf<double> partials;
   size_t partial_stride = 0;

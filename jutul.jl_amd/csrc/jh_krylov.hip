@@ -657,35 +657,37 @@ extern "C" int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_
     // force_solve: 0 = solve unless converged (check_before_solve, simulator.jl:435-441); 1 = always solve
     // (iteration <= min_nonlinear_iterations, :484); -1 = assemble + check only (solve = false past max_iter, :566-570)
     if (force_solve < 0 || (conv && force_solve == 0)) return;
-    // -- linear solve
-    JH_HIP(hipEventRecord(e0, st));
+    // -- linear solve.  The host does not wait between the phases (every wait is an idle gap on the device): the event pairs are
+    // read once at the end of the step
+    hipEvent_t *ev = ctx->ev_step;
+    JH_HIP(hipEventRecord(ev[0], st));
     if (M) ilu_factor(M);
-    JH_HIP(hipEventRecord(e1, st));
-    JH_HIP(hipEventSynchronize(e1));
-    JH_HIP(hipEventElapsedTime(&ms, e0, e1));
-    rep->precond_ms = ms;
-    JH_HIP(hipEventRecord(e0, st));
+    JH_HIP(hipEventRecord(ev[1], st));
+    JH_HIP(hipEventRecord(ev[2], st));
     std::vector<double> h((size_t)itmax + 2, 0.0);
     int64_t iters = 0;
     // dx receives the solution x, then is negated in place
     int status = jh::bicgstab(K, M, M ? side : JH_SIDE_NONE, r->d.p, dx->d.p, rtol, atol, itmax, &iters, h.data(), (int64_t)h.size());
     k_negate(st, dx->d.p, dx->d.p, dx->len);  // update_dx_from_vector!: dx = -x (default.jl:444-446)
-    JH_HIP(hipEventRecord(e1, st));
-    JH_HIP(hipEventSynchronize(e1));
-    JH_HIP(hipEventElapsedTime(&ms, e0, e1));
-    rep->linear_solve_ms = ms;
+    JH_HIP(hipEventRecord(ev[3], st));
     rep->linear_iterations = iters;
     rep->linear_status = status;
     rep->lin_res0 = h[0];
     rep->lin_res = h[(size_t)std::min<int64_t>(iters, (int64_t)h.size() - 1)];
-    if (status != 0 && rep->lin_res / rep->lin_res0 > 1.0)
-      JH_THROW("Bad linear solve: residual increased (linsolve/krylov.jl:161-166)");
+    const bool bad = status != 0 && rep->lin_res / rep->lin_res0 > 1.0;
     // -- update (update_primary_variables!, models.jl:928-953)
-    JH_HIP(hipEventRecord(e0, st));
-    k_update_primary(L, dx->d.p, 1.0, nullptr);
-    JH_HIP(hipEventRecord(e1, st));
-    JH_HIP(hipEventSynchronize(e1));
-    JH_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (!bad) {
+      JH_HIP(hipEventRecord(ev[4], st));
+      k_update_primary(L, dx->d.p, 1.0, nullptr);
+      JH_HIP(hipEventRecord(ev[5], st));
+    }
+    JH_HIP(hipEventSynchronize(bad ? ev[3] : ev[5]));
+    JH_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    rep->precond_ms = ms;
+    JH_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
+    rep->linear_solve_ms = ms;
+    if (bad) JH_THROW("Bad linear solve: residual increased (linsolve/krylov.jl:161-166)");
+    JH_HIP(hipEventElapsedTime(&ms, ev[4], ev[5]));
     rep->update_ms = ms;
   });
 }
