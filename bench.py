@@ -251,6 +251,7 @@ def main():
     law.set_state0(U_loc)
     if src_cells:
         law.set_sources(src_cells, source_values(np, args.law, src_sign))
+    law.set_update_limits(update_limits(np, args.law))
     prec = ja.ILUZeroPreconditioner(partition="blocks")
     ks = ja.GenericKrylov("bicgstab", preconditioner=prec, relative_tolerance=args.rtol, max_iterations=200 if N == 2 else 100,
                           precond_side=args.precond_side)
@@ -402,6 +403,38 @@ def initial_state(np, law, nc):
     return 1.0 + 0.1 * np.random.default_rng(3).random(nc)
 
 
+def update_limits(np, law):
+    """Per-variable update limits [N, 5] = scale, abs_max, rel_max, minimum, maximum (variables/utils.jl:110-174), NaN = unset:
+    the saturation carries Jutul's defaults for Saturations (absolute increment limit 0.2, bounds [0, 1]); None: no limits."""
+    if law != "twophase":
+        return None
+    nan = float("nan")
+    return np.array([[nan, nan, nan, nan, nan], [nan, 0.2, nan, 0.0, 1.0]])
+
+
+def apply_update(np, U, dx, lim):
+    """U + choose_increment(dx): scale -> abs -> rel -> lower -> upper (variables/utils.jl:146-174); U, dx flat [nc, N]."""
+    if lim is None:
+        return U + dx
+    N = lim.shape[0]
+    V, D = U.reshape(-1, N).copy(), dx.reshape(-1, N).copy()
+    for e in range(N):
+        scale, amax, rmax, lo, hi = lim[e]
+        v, d = V[:, e], D[:, e]
+        if scale == scale:
+            d = d * scale
+        if amax == amax:
+            d = np.sign(d) * np.minimum(np.abs(d), amax)
+        if rmax == rmax:
+            d = np.sign(d) * np.minimum(np.abs(d), rmax * np.abs(v))
+        if lo == lo:
+            d = np.maximum(d, lo - v)
+        if hi == hi:
+            d = np.minimum(d, hi - v)
+        V[:, e] = v + d
+    return V.reshape(-1)
+
+
 def source_values(np, law, signs):
     if law == "twophase":
         return np.array([[0.01 * s, 0.01 * s] for s in signs]).reshape(-1)
@@ -472,6 +505,7 @@ def cpu_baseline(args, nc_gpu):
     nz, r = osys.assemble(law, U, U0, m["volumes"], T, src_cells=[1, nc], src_values=src)
     F = o.ILU0(nc, N, osys.rowptr, osys.colidx, nz, partition=part)
     itmax = 200 if N == 2 else 100
+    lim = update_limits(np, args.law)
 
     def step():
         nonlocal U, U0
@@ -479,7 +513,7 @@ def cpu_baseline(args, nc_gpu):
         F.refactor(nz)
         x, st = o.bicgstab(nc, N, osys.rowptr, osys.colidx, nz, r, prec=F, side=args.precond_side, rtol=args.rtol, atol=1e-12,
                            itmax=itmax)
-        U = U - x        # dx = -x (update_dx_from_vector!), U <- U + dx
+        U = apply_update(np, U, -x, lim)  # dx = -x (update_dx_from_vector!), U <- U + choose_increment(dx)
         U0 = U.copy()    # state0 <- state
         return st["iterations"]
 

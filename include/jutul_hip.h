@@ -184,6 +184,9 @@ int32_t jh_convergence(jh_law L, jh_vec r, int64_t n_owned, double *err);
 /* update_primary_variables! (models.jl:928-953, variables/utils.jl:110-174): X += clamp-chain(w*dx) with
  * per-variable scale / abs_max / rel_max / minimum / maximum (5*N doubles, NaN = unset; NULL = no limits). */
 int32_t jh_update_primary(jh_law L, jh_vec dx, double w, const double *limits);
+/* The limits jh_newton_step applies in its update (the variables' minimum / maximum / absolute / relative increment limits,
+ * variables/utils.jl:110-174; e.g. Saturations: abs_max 0.2, minimum 0, maximum 1): same 5*N layout, NULL = none (default). */
+int32_t jh_law_set_update_limits(jh_law L, const double *limits);
 
 /* ---- a-11..a-13: ILU(0) ----------------------------------------------------------------------------------- */
 /* ilu0_csr(A) (StaticCSR/ilu0.jl:213-221) when partition == NULL and nparts <= 1; ilu0_csr(A, partition)

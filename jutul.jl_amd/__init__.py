@@ -468,6 +468,16 @@ class ConservationLaw(_Handle):
         lim = f64(limits) if limits is not None else None
         check(_L().jh_update_primary(self.h, dx.h, float(w), pf(lim)))
 
+    def set_update_limits(self, limits):
+        """Limits applied by Simulator.perform_step's update (the variables' minimum / maximum / absolute / relative increment
+        limits, variables/utils.jl:110-174): [N, 5] = scale, abs_max, rel_max, minimum, maximum per primary variable, NaN =
+        unset; None removes them."""
+        lim = f64(limits).reshape(-1) if limits is not None else None
+        if lim is not None and lim.size != 5 * self.N:
+            raise ValueError("limits must hold 5 values per primary variable")
+        check(_L().jh_law_set_update_limits(self.h, pf(lim)))
+        self._update_limits = lim
+
     def synchronize_ghosts(self):
         check(_L().jh_halo_exchange_state(self.h))
 
@@ -743,7 +753,7 @@ class Simulator:
         rep.linear_iterations, rep.linear_status = out["iterations"], out["status"]
         rep.lin_res0, rep.lin_res = out["residuals"][0], out["residuals"][-1]
         ctx.timer_start()
-        law.update_primary_variables(sys_.dx)
+        law.update_primary_variables(sys_.dx, limits=getattr(law, "_update_limits", None))
         rep.update_ms = ctx.timer_stop_ms()
         return rep
 

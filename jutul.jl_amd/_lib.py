@@ -83,6 +83,7 @@ SIGNATURES = {
     "jh_law_set_sources": [H, C.c_int64, I64P, F64P],
     "jh_assemble": [H, C.c_double, H, H],
     "jh_convergence": [H, H, C.c_int64, F64P],
+    "jh_law_set_update_limits": [H, F64P],
     "jh_update_primary": [H, H, C.c_double, F64P],
     "jh_ilu0_create": [H, I64P, C.c_int64, C.POINTER(H)],
     "jh_ilu0_destroy": [H],

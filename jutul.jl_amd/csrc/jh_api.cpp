@@ -468,6 +468,17 @@ extern "C" int32_t jh_update_primary(jh_law L, jh_vec dx, double w, const double
     JH_HIP(hipGetLastError());
   });
 }
+extern "C" int32_t jh_law_set_update_limits(jh_law L, const double *limits) {
+  return guard([&] {
+    if (!L) JH_THROW("null argument");
+    JH_HIP(hipSetDevice(L->ctx->device));
+    JH_HIP(hipStreamSynchronize(L->ctx->stream));
+    if (!limits) { L->limits.release(); return; }
+    std::vector<double> h(limits, limits + 5 * L->N);
+    L->limits.upload(h, L->ctx->stream);
+    JH_HIP(hipStreamSynchronize(L->ctx->stream));
+  });
+}
 extern "C" int32_t jh_halo_exchange(jh_tpfa d, jh_vec v) {
   return guard([&] {
     if (!d || !v) JH_THROW("null argument");

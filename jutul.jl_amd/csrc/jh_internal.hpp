@@ -296,6 +296,7 @@ struct jh_law_s {
   int kind = 0, N = 1;
   double par[7] = {1, 1, 0, 0, 1, 1, 0};
   jh::DevBuf<double> X, X0;  // [N, nc] device order
+  jh::DevBuf<double> limits; // 5*N update limits for jh_newton_step (jh_law_set_update_limits); empty: none
   jh::DevBuf<double> Tnz;    // per device nnz: T_f off-diagonal, accumulation coefficient on the diagonal
   jh::DevBuf<double> gnz;    // per device nnz: signed gdz (self -> other); empty when no gravity
   bool has_gdz = false;

@@ -678,7 +678,7 @@ extern "C" int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_
     // -- update (update_primary_variables!, models.jl:928-953)
     if (!bad) {
       JH_HIP(hipEventRecord(ev[4], st));
-      k_update_primary(L, dx->d.p, 1.0, nullptr);
+      k_update_primary(L, dx->d.p, 1.0, L->limits.n ? L->limits.p : nullptr);
       JH_HIP(hipEventRecord(ev[5], st));
     }
     JH_HIP(hipEventSynchronize(bad ? ev[3] : ev[5]));

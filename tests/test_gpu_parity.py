@@ -503,6 +503,45 @@ def test_update_primary_limits(ja, ctx, oracle):
     assert np.allclose(law.get_state(), v + dx, rtol=1e-15)
 
 
+def test_newton_step_applies_the_laws_update_limits(ja, ctx, oracle):
+    """Simulator.perform_step (jh_newton_step) applies the limits stored on the law (jh_law_set_update_limits: the variables'
+    minimum / maximum / increment limits of update_primary_variables!, variables/utils.jl:110-174) -- both on the fused path and
+    on the general one; without limits the plain Newton update."""
+    g, rng = tet_case(ja, (5, 4, 4), seed=21)
+    nc = g["nc"]
+    nan = np.nan
+    lim = np.array([[nan, 0.004, nan, nan, nan], [nan, 0.05, nan, 0.0, 1.0]])
+    out = {}
+    for mode in ("none", "fused", "general"):
+        disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, block_n=2, reorder="blocks")
+        law = ja.ConservationLaw(disc, "twophase", rho0=(1.0, 0.8), compressibility=(1e-3, 2e-3), viscosity=(1.0, 2.0), p_ref=1.0)
+        law.set_face_trans(g["Tn"]); law.set_volumes(g["volumes"])
+        U0 = np.stack([1.0 + 0.05 * rng.random(nc), rng.uniform(0.02, 0.98, nc)]).T.reshape(-1) if "U0" not in out else out["U0"]
+        out["U0"] = U0
+        law.set_state(U0); law.set_state0(U0)
+        law.set_sources([1, nc], [0.5, 0.5, -0.5, -0.5])
+        if mode != "none":
+            law.set_update_limits(lim)
+        ks = ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"), relative_tolerance=1e-10,
+                              max_iterations=200, **({"true_residual": True} if mode == "general" else {}))
+        sim = ja.Simulator(law, ks)
+        assert sim._needs_general_path() == (mode == "general")
+        sim.perform_step(0.5, 1)
+        out[mode] = law.get_state().reshape(nc, 2)
+        out[mode + "_dx"] = sim.lsys.dx.download().reshape(nc, 2)
+    V = out["U0"].reshape(nc, 2)
+    assert np.allclose(out["none"], V + out["none_dx"], rtol=1e-13, atol=1e-14)
+    assert np.abs(out["none_dx"][:, 1]).max() > 0.05          # the limits below do bind
+    for mode in ("fused", "general"):
+        d = out[mode + "_dx"].copy()
+        d[:, 0] = np.sign(d[:, 0]) * np.minimum(np.abs(d[:, 0]), 0.004)
+        d[:, 1] = np.sign(d[:, 1]) * np.minimum(np.abs(d[:, 1]), 0.05)
+        d[:, 1] = np.minimum(np.maximum(d[:, 1], 0.0 - V[:, 1]), 1.0 - V[:, 1])
+        assert np.allclose(out[mode], V + d, rtol=1e-13, atol=1e-14), mode
+        assert out[mode][:, 1].min() >= 0.0 and out[mode][:, 1].max() <= 1.0
+    assert np.allclose(out["fused"], out["general"], rtol=1e-6, atol=1e-8)
+
+
 # ---- size-independent properties at a larger size ---------------------------------------------------------------------------------
 def test_medium_tet_mesh_end_to_end_properties(ja, ctx, oracle):
     """~100k cells: (i) J*1 == vol/dt row sums, (ii) conservation: sum(r) == sum(acc), (iii) block-Jacobi ILU
