@@ -225,7 +225,12 @@ struct Pattern {
     DevBuf<int32_t> d_base;  // [nslices + 1] first entry of every slice
     DevBuf<uint8_t> d_cnt;   // [nslices * 16] byte j: rows of the slice with more than j entries
     DevBuf<uint8_t> d_perm;  // [nslices * 64] lane -> row offset inside the slice
-    DevBuf<int32_t> d_col;   // [nent] column ids, jagged order
+    DevBuf<int32_t> d_col;   // [nent] column ids, jagged order (matrices below 3M rows)
+    // 16-bit column codes (larger matrices; exactly one of d_col / d_col16 is filled): code < JDS_FAR: column = window origin of the slice + code; else entry code - JDS_FAR of
+    // the slice's list of far columns
+    DevBuf<uint16_t> d_col16;  // [nent + 64]
+    DevBuf<int32_t> d_win;     // [2 * nslices] window origin (may be negative), first far entry
+    DevBuf<int32_t> d_far;     // far columns of all slices (+ padding: lanes past a diagonal's count decode, too)
     DevBuf<int32_t> d_src;   // [nent] CSR slot each jagged entry is copied from
   } jag;
   void build_tiles();
@@ -352,6 +357,8 @@ int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x,
            const SpmvDot *dot = nullptr, const double *done = nullptr, const SpmvRange *rng = nullptr);
 // jh_sell.hip: jagged-slice SpMV with the same fused-dot contract; A->jval must be fresh (sell_refresh)
 constexpr int JDS_KMAX = 8;
+constexpr int JDS_FAR = 0xE000;   // first 16-bit column code that is an index into the slice's far list
+constexpr int JDS_BACK = 0x7000;  // the slice's column window starts this many rows before its first row
 bool sell_refresh(jh_csr A);  // false: the matrix has no jagged form (block size > 1 or long rows) -> CSR tile kernels
 int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done,
                 bool reduce_now = true);

@@ -32,10 +32,18 @@ void Pattern::build_jagged() {
   const int32_t ns = (int32_t)((n + 63) / 64);
   std::vector<int32_t> base(ns + 1, 0), jc(nnzb + 64, 0), src(nnzb + 64, 0);  // + 64: lanes past a diagonal's count load too
   std::vector<uint8_t> cnt((size_t)ns * 16, 0), perm((size_t)ns * 64, 0);
+  // 16-bit column codes: a slice's columns lie almost all in a window around its rows (the device order keeps neighbours close);
+  // the few outside go to a per-slice list
+  std::vector<uint16_t> jc16(nnzb + 64, 0);
+  std::vector<int32_t> win((size_t)ns * 2, 0), far;
   int64_t pos = 0;
   int lanes[64];
   for (int32_t s = 0; s < ns; ++s) {
     const int64_t r0 = (int64_t)s * 64;
+    const int64_t cb = r0 - JDS_BACK;
+    const size_t far0 = far.size();
+    win[(size_t)s * 2] = (int32_t)cb;
+    win[(size_t)s * 2 + 1] = (int32_t)far0;
     const int nr = (int)std::min<int64_t>(64, n - r0);
     std::iota(lanes, lanes + nr, 0);
     std::stable_sort(lanes, lanes + nr, [&](int a, int b) {
@@ -48,7 +56,14 @@ void Pattern::build_jagged() {
       for (int l = 0; l < nr; ++l) {
         const int64_t row = r0 + lanes[l];
         if (rowptr[row + 1] - rowptr[row] > j) {
-          jc[pos] = col[rowptr[row] + j];
+          const int32_t cj = col[rowptr[row] + j];
+          jc[pos] = cj;
+          if (cj >= cb && cj - cb < JDS_FAR) {
+            jc16[pos] = (uint16_t)(cj - cb);
+          } else {
+            jc16[pos] = (uint16_t)(JDS_FAR + (far.size() - far0));  // (a slice has at most 512 entries)
+            far.push_back(cj);
+          }
           src[pos] = rowptr[row] + j;
           ++pos;
           ++c;
@@ -67,7 +82,18 @@ void Pattern::build_jagged() {
   jag.d_base.upload(base, st);
   jag.d_cnt.upload(cnt, st);
   jag.d_perm.upload(perm, st);
-  jag.d_col.upload(jc, st);
+  // 16-bit codes pay where the product streams from HBM for long (10M rows: 0.177 instead of 0.181-0.188 ms); on a small matrix
+  // the extra pipeline stage costs more than the bytes save (1.25M rows: 28.5 instead of 27.1 us)
+  const char *force = getenv("JH_SPMV_COL");  // "16" / "32": development / test switch (read when the layout is built)
+  const bool col16 = force ? atoi(force) == 16 : n >= 3000000;
+  if (col16) {
+    far.resize(far.size() + (0x10000 - JDS_FAR), 0);  // any code of any slice decodes to a valid position
+    jag.d_col16.upload(jc16, st);
+    jag.d_win.upload(win, st);
+    jag.d_far.upload(far, st);
+  } else {
+    jag.d_col.upload(jc, st);
+  }
   jag.d_src.upload(src, st);
   JH_HIP(hipStreamSynchronize(st));
   jag.usable = true;
@@ -188,6 +214,119 @@ __global__ __launch_bounds__(256) void spmv_jds_kernel(const int32_t *__restrict
   }
 }
 
+// The same product with 16-bit column codes (Pattern::Jagged::d_col16): 10 instead of 12 bytes per entry.  One more pipeline
+// stage: the codes of slice i+2 are in flight, those of slice i+1 are decoded (window origin + code, or -- a few percent of
+// the entries -- a load from the slice's far list) while slice i gathers x and accumulates.  Lanes past a diagonal's count hold
+// another entry's code: clamped into [0, nrows) / padded far list, so every gather address is valid.
+template <int KU>
+struct JRaw {
+  unsigned short c16[KU];
+  double val[KU];
+  int prow;
+};
+struct JDesc16 {
+  int base, cb, fo;
+  uint4 c;
+};
+template <int KU, int DOT>
+__global__ __launch_bounds__(256) void spmv_jds16_kernel(const int32_t *__restrict__ base, const uint4 *__restrict__ cnt16,
+                                                         const uint8_t *__restrict__ perm, const uint16_t *__restrict__ jcol,
+                                                         const int2 *__restrict__ win, const int32_t *__restrict__ far,
+                                                         const double *__restrict__ jval, int nslices, int nrows,
+                                                         const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
+                                                         const double *__restrict__ dw, int dot_rows, double *__restrict__ part,
+                                                         size_t pstride, const double *done) {
+  if (done && *done != 0.0) return;
+  __shared__ double tr[4][64];
+  __shared__ double red[8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsup = (nslices + 3) / 4;
+  const int chunk = (nsup + NUM_XCD - 1) / NUM_XCD;
+  const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, wgs = gridDim.x / NUM_XCD;
+  const int stride = wgs * 4;
+  const int s_end = min(nslices, 4 * min(nsup, (xcd + 1) * chunk));
+  const int s_loop_end = 4 * min(nsup, (xcd + 1) * chunk);  // uniform over the workgroup (the barrier below)
+  double d0 = 0.0, d1 = 0.0;
+  auto ldesc = [&](int s, JDesc16 &D) {
+    if (s < s_end) { D.base = base[s]; D.c = cnt16[s]; const int2 wf = win[s]; D.cb = wf.x; D.fo = wf.y; }
+    else { D.base = 0; D.c = make_uint4(0, 0, 0, 0); D.cb = 0; D.fo = 0; }
+  };
+  auto lraw = [&](int s, const JDesc16 &D, JRaw<KU> &E) {
+    int off = D.base;
+#define JH_LRAW(J)                                                                                                       \
+    if (J < KU) { /* unconditional: lanes past the count read the next diagonal's entries (arrays padded by 64), unused */ \
+      E.c16[J < KU ? J : 0] = __builtin_nontemporal_load(jcol + off + lane);                                             \
+      E.val[J < KU ? J : 0] = __builtin_nontemporal_load(jval + off + lane);                                             \
+      off += jcount<J>(D.c);                                                                                             \
+    }
+    JH_LRAW(0) JH_LRAW(1) JH_LRAW(2) JH_LRAW(3) JH_LRAW(4) JH_LRAW(5) JH_LRAW(6) JH_LRAW(7)
+#undef JH_LRAW
+    E.prow = (int)perm[(size_t)min(s, nslices - 1) * 64 + lane];
+  };
+  auto decode = [&](const JDesc16 &D, const JRaw<KU> &R, JEnt<KU> &E) {
+#pragma unroll
+    for (int j = 0; j < KU; ++j) {
+      const int code = (int)R.c16[j];
+      int c = min(max(D.cb + code, 0), nrows - 1);
+      if (code >= JDS_FAR) c = far[D.fo + code - JDS_FAR];
+      E.col[j] = c;
+      E.val[j] = R.val[j];
+    }
+    E.prow = R.prow;
+  };
+  int s = 4 * (xcd * chunk + wg) + w;
+  JDesc16 dc, dn, dnn, dnnn;
+  JRaw<KU> rn, rnn;
+  JEnt<KU> ec, en;
+  ldesc(s, dc);
+  ldesc(s + stride, dn);
+  ldesc(s + 2 * stride, dnn);
+  lraw(s, dc, rn);
+  decode(dc, rn, ec);
+  lraw(s + stride, dn, rn);
+  for (; s - w < s_loop_end; s += stride) {
+    ldesc(s + 3 * stride, dnnn);
+    lraw(s + 2 * stride, dnn, rnn);
+    decode(dn, rn, en);  // (its far-list loads complete during this slice's gathers)
+    __syncthreads();  // keeps the four wavefronts on neighbouring slices
+    double xg[KU];
+#define JH_GATH(J) if (J < KU) xg[J < KU ? J : 0] = x[ec.col[J < KU ? J : 0]];
+    JH_GATH(0) JH_GATH(1) JH_GATH(2) JH_GATH(3) JH_GATH(4) JH_GATH(5) JH_GATH(6) JH_GATH(7)
+#undef JH_GATH
+    double acc = 0.0;
+#define JH_ACC(J) if (J < KU) { const double t = acc + ec.val[J < KU ? J : 0] * xg[J < KU ? J : 0]; acc = (lane < jcount<J>(dc.c)) ? t : acc; }
+    JH_ACC(0) JH_ACC(1) JH_ACC(2) JH_ACC(3) JH_ACC(4) JH_ACC(5) JH_ACC(6) JH_ACC(7)
+#undef JH_ACC
+    const int nr = (s < s_end) ? min(64, nrows - s * 64) : 0;
+    if (lane < nr) tr[w][ec.prow] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < nr) {
+      const int row = s * 64 + lane;
+      const double a = tr[w][lane];
+      const double yv = (beta == 0.0) ? alpha * a : alpha * a + beta * y[row];
+      y[row] = yv;
+      if (DOT && row < dot_rows) { d0 += yv * dw[row]; if (DOT == 2) d1 += yv * yv; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    dc = dn; dn = dnn; dnn = dnnn;
+    ec = en;
+    rn = rnn;
+  }
+  if (DOT) {  // one partial per workgroup, reduced in a fixed order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); if (DOT == 2) d1 += __shfl_down(d1, off, 64); }
+    if (lane == 0) { red[w] = d0; red[4 + w] = d1; }
+    __syncthreads();
+    if (tid == 0) {
+      part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+      if (DOT == 2) part[pstride + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+  }
+}
+
 }  // namespace
 
 // Copies the current values of A into the jagged-slice order; true if the Krylov loop can multiply with k_spmv_sell.
@@ -223,12 +362,23 @@ int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta,
 #define JH_JDS(KU, DV)                                                                                                          \
   hipLaunchKernelGGL((spmv_jds_kernel<KU, DV>), grid, block, 0, ctx->stream, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), \
                      J.d_perm.p, J.d_col.p, A->jval.p, J.nslices, (int)P.n, x, y, alpha, beta, dw, drows, ctx->partials.p, ctx->partial_stride, done)
-  if (J.kmax <= 5) {
+#define JH_JDS16(KU, DV)                                                                                                        \
+  hipLaunchKernelGGL((spmv_jds16_kernel<KU, DV>), grid, block, 0, ctx->stream, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), \
+                     J.d_perm.p, J.d_col16.p, reinterpret_cast<const int2 *>(J.d_win.p), J.d_far.p, A->jval.p, J.nslices, (int)P.n, x, y, \
+                     alpha, beta, dw, drows, ctx->partials.p, ctx->partial_stride, done)
+  if (J.d_col.n == 0) {  // 16-bit column codes (default)
+    if (J.kmax <= 5) {
+      if (mode == 0) JH_JDS16(5, 0); else if (mode == 1) JH_JDS16(5, 1); else JH_JDS16(5, 2);
+    } else {
+      if (mode == 0) JH_JDS16(8, 0); else if (mode == 1) JH_JDS16(8, 1); else JH_JDS16(8, 2);
+    }
+  } else if (J.kmax <= 5) {
     if (mode == 0) JH_JDS(5, 0); else if (mode == 1) JH_JDS(5, 1); else JH_JDS(5, 2);
   } else {
     if (mode == 0) JH_JDS(8, 0); else if (mode == 1) JH_JDS(8, 1); else JH_JDS(8, 2);
   }
 #undef JH_JDS
+#undef JH_JDS16
   if (mode && reduce_now) spmv_dot_reduce(ctx, dot, (int)grid.x, done);
   return (int)grid.x;
 }

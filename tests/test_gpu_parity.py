@@ -223,6 +223,40 @@ def test_spmv_jagged_slice_layout_matches_csr_bitwise(ja, ctx, oracle, dims, reo
     assert relerr(yb, oracle.spmv(nc, 1, rowptr, colidx, nz2, x)) < RTOL
 
 
+@pytest.mark.parametrize("case", ["lattice", "far", "tiny"])
+def test_spmv_jagged_16bit_column_codes(ja, ctx, oracle, case, monkeypatch):
+    """Large matrices store the jagged-slice columns as 16-bit codes (window origin of the slice + code, or an index into the
+    slice's list of far columns): the same bits as the CSR kernel, also with columns far outside every window, on the first
+    slices (window origin negative), the last ragged slice, and a matrix smaller than one window."""
+    monkeypatch.setenv("JH_SPMV_COL", "16")   # (the default switches at 3M rows)
+    rng = np.random.default_rng(12)
+    if case == "lattice":
+        g = ja.tet_lattice_mesh(13, 11, 9)
+        N, nc, reorder = g["N"], g["nc"], "blocks"
+    elif case == "tiny":
+        N, nc, reorder = ja.cartesian_neighbors((7, 3, 1)), 21, "none"
+    else:   # a ring plus random long-range pairs: most rows reach 60 000+ rows away, host order kept
+        nc, reorder = 150_001, "none"
+        ring = np.stack([np.arange(1, nc + 1), np.roll(np.arange(1, nc + 1), -1)])
+        perm = rng.permutation(nc)
+        a, b = perm[: nc // 2] + 1, perm[nc // 2: 2 * (nc // 2)] + 1
+        far = np.stack([a, b])[:, np.abs(a - b) > 1]
+        N = np.concatenate([ring[:, :-1], far], axis=1)
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, reorder=reorder, block_rows=128)
+    A = ja.StaticSparsityMatrixCSR(disc)
+    rowptr, colidx = disc.pattern()
+    nz = rng.standard_normal(A.nnzb)
+    A.nzval = nz
+    x, y0 = rng.standard_normal(nc), rng.standard_normal(nc)
+    for alpha, beta in [(1.0, 0.0), (-2.0, 1.0)]:
+        ya = ja.mul_(ja.DeviceVector(disc, y0), A, ja.DeviceVector(disc, x), alpha, beta).download()
+        yb = ja.mul_(ja.DeviceVector(disc, y0), A, ja.DeviceVector(disc, x), alpha, beta, jagged=True).download()
+        assert np.array_equal(ya, yb)
+        assert relerr(yb, oracle.spmv(nc, 1, rowptr, colidx, nz, x, y0, alpha, beta)) < RTOL
+    if case == "far":
+        assert (np.abs(colidx - np.repeat(np.arange(1, nc + 1), np.diff(rowptr))) > 57344).mean() > 0.05   # the far list is exercised
+
+
 def test_spmv_jagged_rejects_blocks_and_long_rows(ja, ctx, oracle):
     nc, rowptr, colidx, nz, rng = random_csr(oracle, (4, 4, 3), 2, seed=4)
     A = ja.StaticSparsityMatrixCSR(context=ctx, n=nc, bs=2, rowptr=rowptr, colidx=colidx, nzval=nz)
