@@ -460,7 +460,7 @@ def measured_traffic(kernel, args, cells, world):
     null with the reason."""
     import glob
     names = {"ilu0_apply": ["ilu_apply_jds_kernel<1, 1, 4>", "ilu_apply_jds_kernel<1, 2, 4>"],
-             "spmv": ["spmv_jds_kernel<5, 1>", "spmv_jds_kernel<5, 2>"], "assembly": ["assemble_pipe_kernel<0>"],
+             "spmv": ["spmv_jds16_kernel<5, 1>", "spmv_jds16_kernel<5, 2>"], "assembly": ["assemble_pipe_kernel<0>"],
              "ilu0_factor": ["ilu_factor_prog_kernel<1>"]}
     if world != 1 or args.law != "poisson" or cells != 10_025_988:
         return None, "PMC passes are committed for the default 1-GPU 10M-cell poisson workload only"
