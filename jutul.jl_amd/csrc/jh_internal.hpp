@@ -64,19 +64,10 @@ static inline void parallel_ranges(int64_t n, int64_t min_per_thread, F &&fn) {
   for (auto &e : err) if (e) std::rethrow_exception(e);
 }
 
-// v.resize(n) for a large array of a trivial type, with the pages first touched by all host cores: a fresh allocation costs a page
-// fault per 4 KiB (about 1 s per GB on one core), which is most of what the big set-up arrays cost when one thread zero-fills them
+// v.resize(n) for the large set-up arrays.  (Touching the pages of the fresh allocation from all host cores before the
+// zero-fill was measured on the GPU box: no gain -- page faults are not what the set-up waits for -- so this is a plain resize.)
 template <class T>
 static inline void resize_parallel(std::vector<T> &v, size_t n) {
-  static_assert(std::is_trivially_copyable<T>::value, "trivial element types only");
-  if (n > v.capacity() && n * sizeof(T) >= ((size_t)8 << 20)) {
-    v.reserve(n);
-    char *base = reinterpret_cast<char *>(v.data());
-    const int64_t pages = (int64_t)((n * sizeof(T) + 4095) / 4096);
-    parallel_ranges(pages, 2048, [&](int64_t b, int64_t e) {
-      for (int64_t pg = b; pg < e; ++pg) *reinterpret_cast<volatile char *>(base + pg * 4096) = 0;
-    });
-  }
   v.resize(n);
 }
 

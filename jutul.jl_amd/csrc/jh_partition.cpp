@@ -46,6 +46,11 @@ struct Bisector {
   }
 
   inline double weight(int64_t k) const { return G.w ? G.w[k] : 1.0; }
+  // Labels of cells that belong to another job may change under our eyes (that job runs on another thread); they can never equal
+  // one of OUR labels (every job owns a private label range), so any value read is as good as any other -- relaxed atomics
+  // make that a defined read.
+  inline int32_t lab_of(int32_t c) const { return __atomic_load_n(&label[c], __ATOMIC_RELAXED); }
+  inline void set_lab(int32_t c, int32_t l) { __atomic_store_n(&label[c], l, __ATOMIC_RELAXED); }
 
   // breadth-first order of the n cells c[] (label lab) from `start` into o[] (restarts cover disconnected pieces); returns the
   // last cell reached from the first start (a far end of that piece).  levels (optional): the positions in o[] where a
@@ -73,7 +78,7 @@ struct Bisector {
         const int32_t v = o[head++];
         for (int64_t k = G.ptr[v]; k < G.ptr[v + 1]; ++k) {
           const int32_t w = G.nbr[k];
-          if (w < G.n && label[w] == lab && mark[w] != st) { mark[w] = st; o[tail++] = w; }
+          if (w < G.n && lab_of(w) == lab && mark[w] != st) { mark[w] = st; o[tail++] = w; }
         }
       }
       if (first) { far = o[tail - 1]; first = false; }
@@ -87,23 +92,23 @@ struct Bisector {
   void fm_refine(int32_t a, int32_t b, int64_t ncells, const int32_t *near_cut, int64_t n_near, int64_t &na, int64_t &nb,
                  int64_t max_a, int64_t max_b, int64_t min_a, int64_t min_b) {
     auto gain_of = [&](int32_t v) {  // reduction of the cut weight if v changes side
-      const int32_t mine = label[v], other = mine == a ? b : a;
+      const int32_t mine = lab_of(v), other = mine == a ? b : a;
       double g = 0.0;
       for (int64_t k = G.ptr[v]; k < G.ptr[v + 1]; ++k) {
         const int32_t o = G.nbr[k];
         if (o >= G.n) continue;
-        const int32_t lo = label[o];
+        const int32_t lo = lab_of(o);
         if (lo == other) g += weight(k);
         else if (lo == mine) g -= weight(k);
       }
       return g;
     };
     auto on_cut = [&](int32_t v) {
-      const int32_t mine = label[v];
+      const int32_t mine = lab_of(v);
       for (int64_t k = G.ptr[v]; k < G.ptr[v + 1]; ++k) {
         const int32_t o = G.nbr[k];
         if (o >= G.n) continue;
-        const int32_t lo = label[o];
+        const int32_t lo = lab_of(o);
         if ((lo == a || lo == b) && lo != mine) return true;
       }
       return false;
@@ -125,9 +130,9 @@ struct Bisector {
         if (locked[v] == st) continue;
         const double gn = gain_of(v);
         if (gn != g) { pq.push({gn, v}); continue; }  // stale entry: re-queue with the current gain
-        const bool from_a = label[v] == a;
+        const bool from_a = lab_of(v) == a;
         if (from_a ? (nb + 1 > max_b || na - 1 < min_a) : (na + 1 > max_a || nb - 1 < min_b)) continue;  // would break the balance
-        label[v] = from_a ? b : a;
+        set_lab(v, from_a ? b : a);
         if (from_a) { --na; ++nb; } else { ++na; --nb; }
         locked[v] = st;
         moved.push_back(v);
@@ -136,13 +141,13 @@ struct Bisector {
         if (total < best - 50.0 * std::max(1.0, std::fabs(g))) break;  // far below the best prefix: give up this pass
         for (int64_t k = G.ptr[v]; k < G.ptr[v + 1]; ++k) {
           const int32_t o = G.nbr[k];
-          if (o < G.n && (label[o] == a || label[o] == b) && locked[o] != st) pq.push({gain_of(o), o});
+          if (o < G.n && (lab_of(o) == a || lab_of(o) == b) && locked[o] != st) pq.push({gain_of(o), o});
         }
       }
       for (size_t i = moved.size(); i > best_len; --i) {  // roll back to the best prefix
         const int32_t v = moved[i - 1];
-        const bool in_a = label[v] == a;
-        label[v] = in_a ? b : a;
+        const bool in_a = lab_of(v) == a;
+        set_lab(v, in_a ? b : a);
         if (in_a) { --na; ++nb; } else { ++na; --nb; }
       }
       if (best_len == 0) break;
@@ -154,7 +159,7 @@ struct Bisector {
         if (mark[v] != st2) { mark[v] = st2; cand.push_back(v); }
         for (int64_t k = G.ptr[v]; k < G.ptr[v + 1]; ++k) {
           const int32_t o = G.nbr[k];
-          if (o < G.n && (label[o] == a || label[o] == b) && mark[o] != st2) { mark[o] = st2; cand.push_back(o); }
+          if (o < G.n && (lab_of(o) == a || lab_of(o) == b) && mark[o] != st2) { mark[o] = st2; cand.push_back(o); }
         }
       }
     }
@@ -182,9 +187,9 @@ struct Bisector {
     // take the first sweep)
     std::vector<int64_t> levels;
     int32_t far = job.start;
-    if (far < 0 || n <= hint_min || label[far] != la) far = bfs_order(la, c, n, c[0], o);
+    if (far < 0 || n <= hint_min || lab_of(far) != la) far = bfs_order(la, c, n, c[0], o);
     bfs_order(la, c, n, far, o, &levels);
-    for (int64_t i = target_a; i < n; ++i) label[o[i]] = lb;
+    for (int64_t i = target_a; i < n; ++i) set_lab(o[i], lb);
     int64_t na = target_a, nb = n - target_a;
     const int64_t max_a = std::min(cap_a, target_a + (int64_t)std::floor(imbalance * (double)target_a));
     const int64_t max_b = std::min(cap_b, (n - target_a) + (int64_t)std::floor(imbalance * (double)(n - target_a)));
@@ -199,13 +204,13 @@ struct Bisector {
     int64_t wa = 0, wb = na;
     for (int64_t i = 0; i < n; ++i) {
       const int32_t v = o[i];
-      if (label[v] == la) c[wa++] = v; else c[wb++] = v;
+      if (lab_of(v) == la) c[wa++] = v; else c[wb++] = v;
     }
     if (wa != na || wb != n) JH_THROW("partitioner: side counts are inconsistent (internal error)");
     A.lab = la; A.k = k1; A.off = job.off; A.n = na;
     B.lab = lb; B.k = k2; B.off = job.off + na; B.n = nb;
-    A.start = label[o[0]] == la ? o[0] : -1;  // where this sweep began / ended, unless the refinement moved the cell across
-    B.start = label[o[n - 1]] == lb ? o[n - 1] : -1;
+    A.start = lab_of(o[0]) == la ? o[0] : -1;  // where this sweep began / ended, unless the refinement moved the cell across
+    B.start = lab_of(o[n - 1]) == lb ? o[n - 1] : -1;
   }
 };
 
