@@ -70,6 +70,39 @@ def partition_graph(N, nc, nparts, face_weights=None, imbalance=0.03):
     return out
 
 
+def partition(N, num_coarse, weights=None, groups=None, n=None, group_by_weights=False, buffer_group=False, imbalance=0.03):
+    """partition(N, num_coarse, weights; groups, n, group_by_weights, buffer_group) (partitioning.jl:239-308): partition a
+    neighbourship with optional groups of cells that must not be divided (e.g. the cells a well perforates).
+    group_by_weights=False: every group is contracted into one vertex before partitioning and expanded afterwards (always
+    kept together); True: faces inside a group (buffer_group: touching a group) get 100x the largest weight instead, which
+    makes cutting them very expensive.  The partitioner is jh_partition_graph in the role of the reference's Metis."""
+    N = np.asarray(N, dtype=np.int64)
+    assert N.shape[0] == 2
+    nf = N.shape[1]
+    w = np.ones(nf) if weights is None else np.asarray(weights, dtype=np.float64).copy()
+    assert w.size == nf
+    n = int(N.max()) if n is None else int(n)
+    part = None
+    if groups is not None and not group_by_weights:
+        part = np.arange(1, n + 1)
+        for i, grp in enumerate(groups):
+            part[np.asarray(grp, dtype=np.int64) - 1] = n + 1 + i
+        part = compress_partition(part)
+        N = part[N - 1]
+        n_inner = int(part.max())
+    else:
+        n_inner = n
+    if groups is not None and group_by_weights:
+        heavy = 100.0 * w.max()
+        for grp in groups:
+            inl, inr = np.isin(N[0], grp), np.isin(N[1], grp)
+            w[(inl | inr) if buffer_group else (inl & inr)] = heavy
+    if num_coarse > n_inner:
+        raise ValueError("more coarse blocks than (contracted) cells")
+    p = partition_graph(N, n_inner, num_coarse, face_weights=w, imbalance=imbalance)
+    return p[part - 1] if part is not None else p
+
+
 def process_partition(N, partition, weights=None):
     """process_partition (partitioning.jl:128-160): split every coarse block into its connected components; the first
     component (the one containing the block's lowest cell) keeps the id, the others get max+1, max+2, ...

@@ -67,3 +67,27 @@ def test_degenerate_inputs(ja):
     part = dd.partition_graph(g["N"], g["nc"], 3)
     owned = np.concatenate([dd.local_subdomain(g["N"], part, r)["cells"][: dd.local_subdomain(g["N"], part, r)["n_owned"]] for r in (1, 2, 3)])
     assert np.array_equal(np.sort(owned), np.arange(1, g["nc"] + 1))
+
+
+def test_partition_with_groups_like_the_reference_tests(ja):
+    """test/partitioning.jl:13-53: every part used for np = 1..10 on a random symmetric graph; the 50-cell chain in 5 parts;
+    groups stay together in all three modes (contracted, heavy weights with and without buffer)."""
+    from jutul_amd import dd
+    rng = np.random.default_rng(4)
+    n = 100
+    ij = np.argwhere(np.triu(rng.random((n, n)) < 0.2, 1)) + 1          # sprand(100, 100, 0.2) + I, symmetrised
+    N = ij.T
+    for k in range(1, 11):
+        p = dd.partition(N, k, n=n)
+        assert p.min() == 1 and p.max() == k and all((p == i).any() for i in range(1, k + 1))
+    N = np.stack([np.arange(1, 50), np.arange(2, 51)])
+    p = dd.partition(N, 5)
+    assert p.size == 50 and p.min() == 1 and p.max() == 5 and all((p == i).any() for i in range(1, 6))
+    grps = [[3, 4, 5], [17, 19, 18]]
+    for kw in (dict(group_by_weights=False), dict(group_by_weights=True, buffer_group=True), dict(group_by_weights=True, buffer_group=False)):
+        p = dd.partition(N, 5, groups=grps, **kw)
+        assert p.size == 50 and p.min() == 1 and p.max() == 5
+        for g in grps:
+            assert len(set(p[np.array(g) - 1])) == 1, (kw, g, p[np.array(g) - 1])
+    with pytest.raises(ValueError):
+        dd.partition(N, 49, groups=[list(range(1, 11))])               # 41 contracted cells < 49 blocks
