@@ -202,7 +202,9 @@ int32_t jh_ilu0_apply(jh_ilu M, jh_vec b, jh_vec x);
 int32_t jh_ilu0_get_factor(jh_ilu M, double *lu);
 int32_t jh_ilu0_info(jh_ilu M, int64_t *nblocks, int64_t *max_block_rows, int64_t *max_levels);
 /* stats4: [0] strict-lower block entries kept in L, [1] strict-upper kept in U (fixed_block, ilu0.jl:13-54),
- * [2] execution blocks, [3] 1 if the LDS (block-Jacobi) kernels are used, 0 for the level-per-launch kernels */
+ * [2] execution blocks, [3] kernel selection: bit 0 = LDS (block-Jacobi) kernels (0: level-per-launch kernels), bit 1 = chunk-jagged
+ * layout, bit 2 = program-driven refactorisation available, bit 3 = pivot-only refactorisation in use (no elimination step
+ * updates an off-diagonal entry: triangle-free block patterns) */
 int32_t jh_ilu0_stats(jh_ilu M, int64_t *stats4);
 
 /* DiagonalPreconditioner family (precond/diagonal.jl): kind 1 = JacobiPreconditioner(w) D_i = w*inv(A_ii)

@@ -76,6 +76,11 @@ struct jh_ilu_s {
   std::vector<int32_t> jl_of_old, ju_of_old, jd_of_old;
   DevBuf<int32_t> d_jl_of_old, d_ju_of_old, d_jd_of_old;
   DevBuf<double> jl_val, ju_val, jdinv;  // factor values in chunk-jagged order
+  // pivot-only factorisation (ilu_factor_diag_kernel): no elimination step of any block updates an off-diagonal entry
+  bool diag_only = false;
+  int max_chunks = 0;                              // chunks of the largest block
+  DevBuf<int32_t> d_jt_map, d_jf_diag;             // per jagged L entry (i,k): A slot of (k,i) or -1; per forward lane: A slot of its pivot
+  DevBuf<uint16_t> d_jf_bslot;                     // per forward lane: the row's backward chunk lane inside the block
   // program-driven factorisation (ilu_factor_prog_kernel): per block the entry ranges and a 16-bit instruction stream
   bool prog = false;
   std::vector<int32_t> blk_lbase, blk_ubase, blk_prog;  // [nb + 1] first jagged L / U entry and first program word of every block
@@ -345,6 +350,98 @@ __global__ void ilu_factor_lds_kernel(IluDev F, const double *__restrict__ aval,
 //     then the row's pivot is inverted.
 // One workgroup per block: values gathered from A through the jagged maps, programs copied to LDS, rows of one dependency
 // level in parallel, barrier, next level; L, U and inverted pivots leave in the order the apply reads them.
+// one-byte diagonal count J of a chunk descriptor (chunk-jagged layout, see ilu_apply_jds_kernel)
+template <int J>
+__device__ __forceinline__ int jd_count(const int4 &d) {
+  const unsigned w = J < 4 ? (unsigned)d.y : (unsigned)d.z;
+  return (int)((w >> (8 * (J & 3))) & 0xffu);
+}
+// ILU(0) refactorisation when no elimination step updates an off-diagonal entry -- the pattern inside every block is
+// triangle-free: Cartesian and corner-point grids, the tet lattice.  Then U keeps A's entries, L_ik = A_ik inv(u_kk), and only
+// the pivots u_ii = A_ii - sum_k L_ik A_ki follow the elimination order (ilu0.jl:108-144 with every process_partial_row! update
+// landing on the diagonal): the recurrence of a forward triangular sweep.  One thread per row, addressed like the apply's
+// forward sweep (chunk, lane): its L entries, their partners A_ki and its own diagonal are loaded up front (coalesced through the
+// chunk-jagged maps), the inverted pivots live in LDS by block-local row, the levels are walked with one barrier each.  Same
+// operations in the same order as ilu_factor_prog_kernel, hence the same bits.
+template <int BS, int KU>
+__global__ __launch_bounds__(1024) void ilu_factor_diag_kernel(IluDev F, const double *__restrict__ aval, const int32_t *__restrict__ ubase,
+                                                               const int32_t *__restrict__ jl_map, const int32_t *__restrict__ jt_map,
+                                                               const int32_t *__restrict__ ju_map, const int32_t *__restrict__ jf_diag,
+                                                               const uint16_t *__restrict__ jf_bslot) {
+  extern __shared__ __attribute__((aligned(16))) double dv[];  // inverted pivots by block-local row
+  constexpr int BB = BS * BS;
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
+  const int c0 = F.chunk_ptr[b], nch = F.chunk_ptr[b + 1] - c0;
+  const int ch = tid >> 6;
+  const bool has_chunk = ch < nch;
+  // this thread's row
+  int4 D = make_int4(0, 0, 0, 0);
+  unsigned word = 0xffff0000u;
+  if (has_chunk) { D = F.jf_desc[c0 + ch]; word = F.jf_row[(size_t)(c0 + ch) * 64 + lane]; }
+  const int lt = (int)(word & 0xffffu), lev = (int)(word >> 16);
+  const bool has_row = lev != 0xffff;
+  const size_t fslot = (size_t)(c0 + ch) * 64 + lane;
+  Blk<BS> acc;
+  int bslot = 0;
+  if (has_row) { acc = blk_load<BS>(aval + (size_t)jf_diag[fslot] * BB); bslot = (int)jf_bslot[fslot]; }
+  int kcol[KU], pos[KU];
+  bool act[KU];
+  Blk<BS> av[KU], bv[KU];
+  {
+    int off = D.x;
+#define JH_FD(J)                                                                                       \
+    if (J < KU) {                                                                                      \
+      const int cnt = jd_count<(J < 8 ? J : 0)>(D);                                                    \
+      act[J < KU ? J : 0] = has_row && lane < cnt;                                                     \
+      pos[J < KU ? J : 0] = off + lane;                                                                \
+      if (act[J < KU ? J : 0]) {                                                                       \
+        kcol[J < KU ? J : 0] = (int)F.jl_col[off + lane];                                              \
+        av[J < KU ? J : 0] = blk_load<BS>(aval + (size_t)jl_map[off + lane] * BB);                     \
+        const int mt = jt_map[off + lane];                                                             \
+        if (mt >= 0) bv[J < KU ? J : 0] = blk_load<BS>(aval + (size_t)mt * BB);                        \
+        else { _Pragma("unroll") for (int i = 0; i < BB; ++i) bv[J < KU ? J : 0].a[i] = 0.0; }         \
+      }                                                                                                \
+      off += cnt;                                                                                      \
+    }
+    JH_FD(0) JH_FD(1) JH_FD(2) JH_FD(3) JH_FD(4) JH_FD(5) JH_FD(6) JH_FD(7)
+#undef JH_FD
+  }
+  // U is a copy of A's entries (jagged order), four at a time per thread
+  {
+    const int u0 = ubase[b], nu = ubase[b + 1] - u0;
+    for (int j0 = tid; j0 < nu; j0 += 4 * T) {
+      int m[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int j = j0 + u * T; m[u] = j < nu ? ju_map[u0 + j] : -1; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u * T;
+        if (j < nu) {
+#pragma unroll
+          for (int e = 0; e < BB; ++e) F.u_val[(size_t)(u0 + j) * BB + e] = m[u] >= 0 ? aval[(size_t)m[u] * BB + e] : 0.0;
+        }
+      }
+    }
+  }
+  const int lev0 = F.flev_off[b], nlev = F.flev_off[b + 1] - 1 - lev0;
+  for (int lv = 0; lv < nlev; ++lv) {
+    if (has_row && lev == lv) {
+#pragma unroll
+      for (int j = 0; j < KU; ++j) {
+        if (act[j]) {
+          const Blk<BS> lik = blk_mul<BS>(av[j], blk_load<BS>(dv + (size_t)kcol[j] * BB));  // nz_l * inv(A_kk)
+          blk_store<BS>(F.l_val + (size_t)pos[j] * BB, lik);
+          if (blk_nonzero<BS>(lik)) blk_sub<BS>(acc, blk_mul<BS>(lik, bv[j]));
+        }
+      }
+      const Blk<BS> di = blk_inv<BS>(acc);
+      blk_store<BS>(dv + (size_t)lt * BB, di);
+      blk_store<BS>(F.dinv + ((size_t)c0 * 64 + bslot) * BB, di);
+    }
+    __syncthreads();
+  }
+}
+
 template <int BS>
 __global__ void ilu_factor_prog_kernel(IluDev F, const double *__restrict__ aval, const int32_t *__restrict__ lbase,
                                        const int32_t *__restrict__ ubase, const int32_t *__restrict__ pbase,
@@ -784,11 +881,6 @@ struct JRow {
   double val[KU * BS * BS];
   double dinv[BS * BS];  // backward sweep only
 };
-template <int J>
-__device__ __forceinline__ int jd_count(const int4 &d) {
-  const unsigned w = J < 4 ? (unsigned)d.y : (unsigned)d.z;
-  return (int)((w >> (8 * (J & 3))) & 0xffu);
-}
 template <int BS, int KU, bool BWD>
 __device__ __forceinline__ void jds_load(const IluDev &F, const int4 &D, int chunk, int lane, JRow<BS, KU> &R) {
   constexpr int BB = BS * BS;
@@ -1293,7 +1385,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         for (int64_t b = 0; b <= nb; ++b) { M->blk_lbase[b] = M->l_ptr[M->blk_ptr[b]]; M->blk_ubase[b] = M->u_ptr[M->blk_ptr[b]]; }
         std::vector<std::vector<uint16_t>> progs(nb);  // factorisation program of every block (ilu_factor_prog_kernel)
         std::vector<int> blk_vals(nb, 0);
-        std::vector<char> blk_ok(nb, 1);
+        std::vector<char> blk_ok(nb, 1), blk_diag(nb, 1);  // blk_diag: every update of the block targets a pivot
+        std::vector<int32_t> jt_map(nlent, -1), jf_diag(M->j_nslots, -1);
+        std::vector<uint16_t> jf_bslot(M->j_nslots, 0);
         parallel_ranges(nb, 16, [&](int64_t bb0, int64_t bb1) {
           int lanes[64];
           std::vector<uint16_t> code;
@@ -1352,6 +1446,14 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
             prog.assign(2 * (size_t)nrb + 1, 0);  // row offsets (nrb + 1), pivot indices (nrb)
             code.clear();
             auto didx = [&](int32_t t) { return (uint16_t)(nl + nu + (M->jd_of_old[M->upos_of[t]] - dslot0)); };  // t: ilu row
+            for (int32_t c = 0; c < M->chunk_ptr[b + 1] - M->chunk_ptr[b]; ++c)  // pivot slot / backward lane of every forward lane
+              for (int l = 0; l < 64; ++l) {
+                const size_t fs = (size_t)(M->chunk_ptr[b] + c) * 64 + l;
+                if ((frow[fs] >> 16) == 0xffffu) continue;
+                const int32_t ip = M->upos_of[b0 + (int32_t)(frow[fs] & 0xffffu)];
+                jf_diag[fs] = M->d_map[ip];
+                jf_bslot[fs] = (uint16_t)(M->jd_of_old[ip] - dslot0);
+              }
             for (int32_t lt = 0; lt < nrb && blk_ok[b]; ++lt) {
               const int32_t t = b0 + lt, ipos = M->upos_of[t];
               prog[lt] = (uint16_t)code.size();
@@ -1369,12 +1471,14 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
                   int32_t tgt = -1;
                   if (j == lt) {
                     tgt = didx(t);
+                    jt_map[M->jl_of_old[p]] = M->u_map[q];  // the A slot of (k, i), partner of the L entry (i, k)
                   } else if (j < lt) {  // a later strict-L entry of this row (process_partial_row! on rem_l_pos, ilu0.jl:100-106)
                     for (int32_t p2 = p + 1; p2 < le; ++p2) if (M->l_col[p2] == j) { tgt = M->jl_of_old[p2] - l0; break; }
                   } else {
                     for (int32_t qi = us; qi < ue; ++qi) if (M->u_col[qi] == j) { tgt = nl + (M->ju_of_old[qi] - u0); break; }
                   }
                   if (tgt < 0) continue;  // (k, j) has no counterpart in row i: dropped fill, ILU(0)
+                  if (j != lt) blk_diag[b] = 0;
                   code.push_back((uint16_t)tgt);
                   code.push_back((uint16_t)(nl + (M->ju_of_old[q] - u0)));
                   ++nupd;
@@ -1399,6 +1503,19 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
             total += progs[b].size();
           }
           M->blk_prog[nb] = (int32_t)total;
+          {
+            bool all_diag = ok;
+            int mxc = 0;
+            for (int64_t b = 0; b < nb; ++b) { all_diag = all_diag && blk_diag[b]; mxc = std::max(mxc, M->chunk_ptr[b + 1] - M->chunk_ptr[b]); }
+            M->max_chunks = mxc;
+            M->diag_only = all_diag && mxc * 64 <= 1024 && !getenv("JH_ILU_NO_DIAG_FACTOR");
+            if (M->diag_only) {
+              hipStream_t sd = M->ctx->stream;
+              M->d_jt_map.upload(jt_map, sd); M->d_jf_diag.upload(jf_diag, sd); M->d_jf_bslot.upload(jf_bslot, sd);
+              M->d_blk_ubase.upload(M->blk_ubase, sd);
+            }
+            if (timing) fprintf(stderr, "[jutul_hip setup] ilu0: pivot-only factorisation %s (largest block: %d chunks)\n", M->diag_only ? "on" : "off", mxc);
+          }
           size_t bytes = sizeof(double) * P.bs * P.bs * (size_t)max_vals + sizeof(uint16_t) * (size_t)max_words;
           bytes = (bytes + 15) & ~(size_t)15;
           if (ok && total < (size_t)INT32_MAX && bytes <= 160 * 1024 - 512 && !getenv("JH_ILU_NO_PROG")) {
@@ -1486,14 +1603,15 @@ extern "C" int32_t jh_ilu0_info(jh_ilu M, int64_t *nblocks, int64_t *max_block_r
   });
 }
 
-// stats[0] strict-lower entries kept, [1] strict-upper entries kept, [2] execution blocks, [3] 1 = LDS mode
+// stats[0] strict-lower entries kept, [1] strict-upper entries kept, [2] execution blocks, [3] bit 0 = LDS mode, bit 1 = chunk-jagged
+// layout, bit 2 = program-driven factorisation available, bit 3 = pivot-only factorisation in use
 extern "C" int32_t jh_ilu0_stats(jh_ilu M, int64_t *stats4) {
   return guard([&] {
     if (!M || !stats4) JH_THROW("null argument");
     stats4[0] = (int64_t)M->l_col.size();
     stats4[1] = (int64_t)M->u_col.size();
     stats4[2] = (int64_t)M->blk_ptr.size() - 1;
-    stats4[3] = M->lds_mode ? 1 : 0;
+    stats4[3] = (M->lds_mode ? 1 : 0) | (M->jag ? 2 : 0) | (M->jag && M->prog ? 4 : 0) | (M->jag && M->prog && M->diag_only ? 8 : 0);
   });
 }
 
@@ -1561,6 +1679,18 @@ void ilu_factor(jh_ilu M) {
     IluDev F = dev_view(M);
     F.l_val = M->jl_val.p; F.u_val = M->ju_val.p; F.dinv = M->jdinv.p;
     const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
+    if (M->diag_only) {  // every elimination update lands on a pivot: the sweep-shaped kernel
+      const int dthreads = 64 * M->max_chunks;
+      const size_t dlds = sizeof(double) * (size_t)M->max_block_rows * M->bs * M->bs;
+#define JH_DIAG(BSV, KUV) hipLaunchKernelGGL((ilu_factor_diag_kernel<BSV, KUV>), dim3((unsigned)nb), dim3(dthreads), dlds, s, F, aval, \
+                                              M->d_blk_ubase.p, M->d_jl_map.p, M->d_jt_map.p, M->d_ju_map.p, M->d_jf_diag.p, M->d_jf_bslot.p)
+#define JH_DIAGK(BSV) do { if (M->jag_ku == 4) JH_DIAG(BSV, 4); else JH_DIAG(BSV, 8); } while (0)
+      switch (M->bs) { case 1: JH_DIAGK(1); break; case 2: JH_DIAGK(2); break; case 3: JH_DIAGK(3); break; }
+#undef JH_DIAGK
+#undef JH_DIAG
+      M->factored = true;
+      return;
+    }
     static const int pthreads = getenv("JH_ILU_FACTOR_THREADS") ? atoi(getenv("JH_ILU_FACTOR_THREADS")) : 512;
 #define JH_PROG(BSV)                                                                                                             \
     do {                                                                                                                          \

@@ -397,6 +397,51 @@ def test_device_blocks_come_from_graph_bisection(ja, ctx):
     assert perm2[sub["n_owned"]:].min() > sub["n_owned"] and perm2[: sub["n_owned"]].max() <= sub["n_owned"]
 
 
+@pytest.mark.parametrize("bs", [1, 2])
+@pytest.mark.parametrize("grid", ["bipartite", "triangles"])
+def test_ilu0_factor_kernels_pivot_only_and_program(ja, ctx, oracle, grid, bs):
+    """The refactorisation picks its kernel from the pattern: on a triangle-free pattern (Cartesian / tet-lattice grids) no
+    elimination step updates an off-diagonal entry and the sweep-shaped pivot-only kernel runs; a pattern with triangles (a
+    Cartesian grid with one diagonal per cell pair) needs the general program-driven kernel.  Both give the oracle's ILU(0)
+    (ilu0.jl:108-144) on the device-ordered matrix to 1e-11, scalar and 2x2 blocks, after a refactorisation with new values."""
+    import scipy.sparse as sp
+    dims = (13, 11, 1)
+    N = ja.cartesian_neighbors(dims)
+    nc = int(np.prod(dims))
+    if grid == "triangles":
+        idx = np.arange(1, nc + 1).reshape(dims[1], dims[0])
+        diag = np.stack([idx[:-1, :-1].ravel(), idx[1:, 1:].ravel()])
+        N = np.concatenate([N, diag], axis=1)
+    rng = np.random.default_rng(31 + bs)
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, block_n=bs, reorder="blocks", block_rows=64)
+    A = ja.StaticSparsityMatrixCSR(disc)
+    rowptr, colidx = disc.pattern()
+    perm, bp = disc.ordering()
+    part = np.zeros(nc, dtype=np.int64)
+    for b in range(len(bp) - 1):
+        part[perm[bp[b]: bp[b + 1]] - 1] = b + 1
+    F = ja.ILUZeroPreconditioner(partition="blocks")
+    for trial in range(2):
+        nzb = rng.standard_normal((A.nnzb, bs, bs)) * 0.2
+        rows = np.repeat(np.arange(nc), np.diff(rowptr))
+        dg = colidx - 1 == rows
+        nzb[dg] += 4.0 * np.eye(bs)
+        A.nzval = nzb.transpose(0, 2, 1).reshape(-1)   # blocks column-major in the flat buffer
+        F.update_preconditioner(A)
+        info = F.info()
+        assert info["jagged"] and info["factor_kernel"] == ("pivot-only" if grid == "bipartite" else "program"), info
+        # oracle on the device-ordered scalar expansion is not needed: compare the action M^-1 b, which pins L, U and the pivots
+        Ab = sp.bsr_matrix((nzb, colidx - 1, rowptr - 1), shape=(nc * bs, nc * bs)).tocsr()
+        p0 = perm - 1
+        pe = (p0[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+        Ap = sp.bsr_matrix(Ab[pe][:, pe], blocksize=(bs, bs))
+        Ap.sort_indices()
+        Fo = oracle.ILU0(nc, bs, Ap.indptr + 1, Ap.indices + 1, np.ascontiguousarray(Ap.data.transpose(0, 2, 1)).reshape(-1), partition=part[p0])
+        b = rng.standard_normal(nc * bs)
+        x = F.apply(A.new_vector(), A.new_vector(b)).download()
+        assert relerr(x[pe], Fo.apply(b[pe])) < 1e-10, (grid, bs, trial)
+
+
 # ---- a-14: BiCGStab ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("side", ["right", "left"])
 @pytest.mark.parametrize("bs", [1, 2])
