@@ -105,6 +105,24 @@ template <int BS> __device__ __forceinline__ void blk_store(double *p, const Blk
 #pragma unroll
   for (int i = 0; i < BS * BS; ++i) p[i] = b.a[i];
 }
+// 2x2 blocks are 32-byte aligned in every value array (hipMalloc'ed bases, 32-byte entries): two 16-byte accesses instead of four
+template <int BS> __device__ __forceinline__ Blk<BS> blk_load_al(const double *p) {
+  if (BS == 2) {
+    Blk<BS> r;
+    const double2 lo = reinterpret_cast<const double2 *>(p)[0], hi = reinterpret_cast<const double2 *>(p)[1];
+    r.a[0] = lo.x; r.a[1] = lo.y; r.a[2 % (BS * BS)] = hi.x; r.a[3 % (BS * BS)] = hi.y;
+    return r;
+  }
+  return blk_load<BS>(p);
+}
+template <int BS> __device__ __forceinline__ void blk_store_al(double *p, const Blk<BS> &b) {
+  if (BS == 2) {
+    reinterpret_cast<double2 *>(p)[0] = make_double2(b.a[0], b.a[1]);
+    reinterpret_cast<double2 *>(p)[1] = make_double2(b.a[2 % (BS * BS)], b.a[3 % (BS * BS)]);
+    return;
+  }
+  blk_store<BS>(p, b);
+}
 template <int BS> __device__ __forceinline__ Blk<BS> blk_mul(const Blk<BS> &A, const Blk<BS> &B) {
   Blk<BS> C;
 #pragma unroll
@@ -383,7 +401,7 @@ __global__ __launch_bounds__(1024) void ilu_factor_diag_kernel(IluDev F, const d
   const size_t fslot = (size_t)(c0 + ch) * 64 + lane;
   Blk<BS> acc;
   int bslot = 0;
-  if (has_row) { acc = blk_load<BS>(aval + (size_t)jf_diag[fslot] * BB); bslot = (int)jf_bslot[fslot]; }
+  if (has_row) { acc = blk_load_al<BS>(aval + (size_t)jf_diag[fslot] * BB); bslot = (int)jf_bslot[fslot]; }
   int kcol[KU], pos[KU];
   bool act[KU];
   Blk<BS> av[KU], bv[KU];
@@ -396,9 +414,9 @@ __global__ __launch_bounds__(1024) void ilu_factor_diag_kernel(IluDev F, const d
       pos[J < KU ? J : 0] = off + lane;                                                                \
       if (act[J < KU ? J : 0]) {                                                                       \
         kcol[J < KU ? J : 0] = (int)F.jl_col[off + lane];                                              \
-        av[J < KU ? J : 0] = blk_load<BS>(aval + (size_t)jl_map[off + lane] * BB);                     \
+        av[J < KU ? J : 0] = blk_load_al<BS>(aval + (size_t)jl_map[off + lane] * BB);                     \
         const int mt = jt_map[off + lane];                                                             \
-        if (mt >= 0) bv[J < KU ? J : 0] = blk_load<BS>(aval + (size_t)mt * BB);                        \
+        if (mt >= 0) bv[J < KU ? J : 0] = blk_load_al<BS>(aval + (size_t)mt * BB);                        \
         else { _Pragma("unroll") for (int i = 0; i < BB; ++i) bv[J < KU ? J : 0].a[i] = 0.0; }         \
       }                                                                                                \
       off += cnt;                                                                                      \
@@ -413,13 +431,16 @@ __global__ __launch_bounds__(1024) void ilu_factor_diag_kernel(IluDev F, const d
       int m[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) { const int j = j0 + u * T; m[u] = j < nu ? ju_map[u0 + j] : -1; }
+      Blk<BS> v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (m[u] >= 0) v[u] = blk_load_al<BS>(aval + (size_t)m[u] * BB);
+        else { _Pragma("unroll") for (int e = 0; e < BB; ++e) v[u].a[e] = 0.0; }
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = j0 + u * T;
-        if (j < nu) {
-#pragma unroll
-          for (int e = 0; e < BB; ++e) F.u_val[(size_t)(u0 + j) * BB + e] = m[u] >= 0 ? aval[(size_t)m[u] * BB + e] : 0.0;
-        }
+        if (j < nu) blk_store_al<BS>(F.u_val + (size_t)(u0 + j) * BB, v[u]);
       }
     }
   }
@@ -430,13 +451,13 @@ __global__ __launch_bounds__(1024) void ilu_factor_diag_kernel(IluDev F, const d
       for (int j = 0; j < KU; ++j) {
         if (act[j]) {
           const Blk<BS> lik = blk_mul<BS>(av[j], blk_load<BS>(dv + (size_t)kcol[j] * BB));  // nz_l * inv(A_kk)
-          blk_store<BS>(F.l_val + (size_t)pos[j] * BB, lik);
+          blk_store_al<BS>(F.l_val + (size_t)pos[j] * BB, lik);
           if (blk_nonzero<BS>(lik)) blk_sub<BS>(acc, blk_mul<BS>(lik, bv[j]));
         }
       }
       const Blk<BS> di = blk_inv<BS>(acc);
       blk_store<BS>(dv + (size_t)lt * BB, di);
-      blk_store<BS>(F.dinv + ((size_t)c0 * 64 + bslot) * BB, di);
+      blk_store_al<BS>(F.dinv + ((size_t)c0 * 64 + bslot) * BB, di);
     }
     __syncthreads();
   }
