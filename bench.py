@@ -461,7 +461,7 @@ def measured_traffic(kernel, args, cells, world):
     import glob
     names = {"ilu0_apply": ["ilu_apply_jds_kernel<1, 1, 4>", "ilu_apply_jds_kernel<1, 2, 4>"],
              "spmv": ["spmv_jds16_kernel<5, 1>", "spmv_jds16_kernel<5, 2>"], "assembly": ["assemble_pipe_kernel<0>"],
-             "ilu0_factor": ["ilu_factor_prog_kernel<1>"]}
+             "ilu0_factor": ["ilu_factor_diag_kernel<1, 4>"]}
     if world != 1 or args.law != "poisson" or cells != 10_025_988:
         return None, "PMC passes are committed for the default 1-GPU 10M-cell poisson workload only"
     want = kernel_source_hash()
