@@ -397,7 +397,7 @@ def test_device_blocks_come_from_graph_bisection(ja, ctx):
     assert perm2[sub["n_owned"]:].min() > sub["n_owned"] and perm2[: sub["n_owned"]].max() <= sub["n_owned"]
 
 
-@pytest.mark.parametrize("bs", [1, 2])
+@pytest.mark.parametrize("bs", [1, 2, 3])
 @pytest.mark.parametrize("grid", ["bipartite", "triangles"])
 def test_ilu0_factor_kernels_pivot_only_and_program(ja, ctx, oracle, grid, bs):
     """The refactorisation picks its kernel from the pattern: on a triangle-free pattern (Cartesian / tet-lattice grids) no
