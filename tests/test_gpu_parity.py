@@ -398,7 +398,7 @@ def test_device_blocks_come_from_graph_bisection(ja, ctx):
 
 
 @pytest.mark.parametrize("bs", [1, 2, 3])
-@pytest.mark.parametrize("grid", ["bipartite", "triangles"])
+@pytest.mark.parametrize("grid", ["bipartite", "bipartite7", "triangles"])
 def test_ilu0_factor_kernels_pivot_only_and_program(ja, ctx, oracle, grid, bs):
     """The refactorisation picks its kernel from the pattern: on a triangle-free pattern (Cartesian / tet-lattice grids) no
     elimination step updates an off-diagonal entry and the sweep-shaped pivot-only kernel runs; a pattern with triangles (a
@@ -412,6 +412,11 @@ def test_ilu0_factor_kernels_pivot_only_and_program(ja, ctx, oracle, grid, bs):
         idx = np.arange(1, nc + 1).reshape(dims[1], dims[0])
         diag = np.stack([idx[:-1, :-1].ravel(), idx[1:, 1:].ravel()])
         N = np.concatenate([N, diag], axis=1)
+    elif grid == "bipartite7":   # degree-7 bipartite graph: up to 7 strict-lower / strict-upper entries in a row (8-diagonal kernels)
+        h = 600
+        nc = 2 * h
+        a = np.arange(h)
+        N = np.concatenate([np.stack([a + 1, (a + o) % h + h + 1]) for o in (0, 1, 5, 17, 40, 111, 290)], axis=1)
     rng = np.random.default_rng(31 + bs)
     disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, block_n=bs, reorder="blocks", block_rows=64)
     A = ja.StaticSparsityMatrixCSR(disc)
@@ -429,7 +434,7 @@ def test_ilu0_factor_kernels_pivot_only_and_program(ja, ctx, oracle, grid, bs):
         A.nzval = nzb.transpose(0, 2, 1).reshape(-1)   # blocks column-major in the flat buffer
         F.update_preconditioner(A)
         info = F.info()
-        assert info["jagged"] and info["factor_kernel"] == ("pivot-only" if grid == "bipartite" else "program"), info
+        assert info["jagged"] and info["factor_kernel"] == ("program" if grid == "triangles" else "pivot-only"), info
         # oracle on the device-ordered scalar expansion is not needed: compare the action M^-1 b, which pins L, U and the pivots
         Ab = sp.bsr_matrix((nzb, colidx - 1, rowptr - 1), shape=(nc * bs, nc * bs)).tocsr()
         p0 = perm - 1
