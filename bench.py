@@ -56,6 +56,10 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cells", type=int, default=0, help="0 = 10M (configs[4]); 5M for --law twophase (configs[3])")
     ap.add_argument("--law", default="poisson", choices=["poisson", "compressible", "twophase"])
+    # lattice: Kuhn-split tet lattice (the headline grid).  delaunay: Delaunay tets of graded random points (odd cycles in the
+    # dual graph, varying valence / cell size).  polyhedral: median dual of that tet mesh (~15 faces per cell, rows of 6..50 entries)
+    ap.add_argument("--mesh", default="lattice", choices=["lattice", "delaunay", "polyhedral"])
+    ap.add_argument("--grading", type=float, default=2.0, help="--mesh delaunay / polyhedral: point density grading (1 = uniform)")
     ap.add_argument("--block-rows", type=int, default=0,
                     help="rows per block-Jacobi ILU(0) block; 0 = the library default for the rank-local size (512, 256 below 2M cells)")
     ap.add_argument("--rtol", type=float, default=1e-3)
@@ -69,6 +73,15 @@ def parse_args(argv=None):
     # the same side for every N keeps the scaling series one algorithm; Jutul's IterativeSolverConfig default is :right
     # (linsolve/utils.jl:25), its MPI extension hard-codes M = prec, i.e. left (ext/.../krylov.jl:60): --precond-side left
     ap.add_argument("--precond-side", default="right", choices=["left", "right"])
+    # fused: one jh_newton_step per Newton iteration (the library's own perform_step!).  seams: per Newton iteration exactly the
+    # entry points julia/JutulHIP.jl issues behind Jutul's dispatch seams (update_equation! -> apply_forces! ->
+    # update_linearized_system_equation! -> convergence_criterion -> linear_solve! -> update_primary_variables! ->
+    # update_after_step! [-> get_output_state]) through its call-for-call twin jutul.jl_amd/julia_mirror.py -- what simulate!
+    # would get through the binding
+    ap.add_argument("--path", default="fused", choices=["fused", "seams"])
+    ap.add_argument("--report-every", type=int, default=1,
+                    help="--path seams: get_output_state (device -> host copy of the state, models.jl:1048-1058) after every n-th "
+                         "step inside the timed region; 0 = never.  Every time step of the bench is a report step of simulate!")
     args = ap.parse_args(argv)
     if args.cells <= 0:
         args.cells = 5_000_000 if args.law == "twophase" else 10_000_000
@@ -168,8 +181,7 @@ def main():
     t_setup = time.time()
     setup = {}
     t0 = time.time()
-    nx, ny, nz = dims_for_cells(args.cells)
-    mesh = ja.tet_lattice_mesh(nx, ny, nz)
+    mesh, mesh_desc = make_mesh(ja, args)
     setup["mesh_s"] = time.time() - t0
     nc_g, nf_g = mesh["nc"], mesh["nf"]
     N = 2 if args.law == "twophase" else 1
@@ -271,10 +283,60 @@ def main():
         if cinfo["mailbox"] != mailbox or disc.halo_info()["push"] != push:
             fatal(f"rank {rank}: communication paths differ from what was negotiated ({cinfo}, {disc.halo_info()})")
 
-    def step():
+    def step_fused():
         rep = sim.perform_step(args.dt, 1)  # iteration 1 always solves (min_nonlinear_iterations = 1)
         law.update_state0()
         return rep
+
+    seams = None
+    if args.path == "seams":
+        if world > 1 or force_dist:
+            fatal("--path seams times the single-GPU binding sequence (the distributed hooks add jh_halo_exchange_state / jh_unit_diagonalize)")
+        from types import SimpleNamespace
+        from jutul_amd.julia_mirror import JuliaMirror
+        m = JuliaMirror()
+        m.copy_output = False  # Jutul's own copy(state0[k]) is host work of the reference itself, not of the binding
+        st = m.adopt(disc, law, sim.lsys)
+        krylov = dict(preconditioner=dict(handle=prec.h), storage=ks._workspace(sim.lsys.jac), solver="bicgstab")
+        host_state0 = [np.ascontiguousarray(U_loc.reshape(-1, N)[:, e]) for e in range(N)]  # storage.state0[k]
+        src_v = np.asarray(source_values(np, args.law, src_sign), dtype=np.float64).reshape(-1, N)
+        lim = update_limits(np, args.law)
+        cfg = ks.config
+        seams = dict(mirror=m, storage=st, n=0, outputs=0, t_out=0.0)
+
+        def step_seams(report=True, timers=False):
+            seams["n"] += 1
+            tm = {}
+
+            def timed(key, fn):
+                if not timers:
+                    return fn()
+                ctx.timer_start()
+                out = fn()
+                tm[key] = ctx.timer_stop_ms()
+                return out
+            m.update_equation(st, U_loc, U_loc, args.dt)                 # uploads on the first call only
+            d = m.get_diagonal_entries(st)                                # apply_forces!
+            for c, v in zip(src_cells, src_v):
+                for e in range(N):
+                    d.add(int(c), float(v[e]), e + 1)
+            timed("assembly_ms", lambda: m.update_linearized_system_equation(st))
+            err = m.convergence_criterion(st)
+            timed("precond_ms", lambda: m.update_preconditioner(krylov["preconditioner"], st)) if timers else None
+            ok, its, hist = timed("linear_solve_ms", lambda: m.linear_solve(st, krylov, rtol=cfg.tolerance("relative"), atol=cfg.tolerance("absolute"),
+                                                                           max_iterations=int(cfg.max_iterations), side=ja.SIDE[cfg.precond_side]))
+            if timers:
+                tm["linear_solve_ms"] -= tm["precond_ms"]  # linear_solve! refactors again inside
+            timed("update_ms", lambda: m.update_primary_variables(st, limits=lim))
+            m.update_after_step(st)
+            if report and args.report_every > 0 and seams["n"] % args.report_every == 0:
+                t_o = time.perf_counter()
+                m.get_output_state(st, host_state0)  # synchronous: permute on the device, DMA into the page-locked state0[k]
+                seams["t_out"] += time.perf_counter() - t_o
+                seams["outputs"] += 1
+            return SimpleNamespace(linear_iterations=its, error=err, assembly_ms=tm.get("assembly_ms", 0.0), precond_ms=tm.get("precond_ms", 0.0),
+                                   linear_solve_ms=tm.get("linear_solve_ms", 0.0), update_ms=tm.get("update_ms", 0.0))
+    step = step_seams if seams else step_fused
 
     def barrier():
         torch.cuda.synchronize()
@@ -284,6 +346,8 @@ def main():
 
     barrier()  # ranks finish their setup seconds apart
     wreps = [step() for _ in range(args.warmup)]
+    if seams:
+        seams["outputs"], seams["t_out"] = 0, 0.0
     ks.profile(enable=args.profile_stride or (8 if world == 1 else 32), reset=True)  # HIP-event pairs around every n-th iteration's SpMV / ILU launches
     barrier()
     t0 = time.perf_counter()
@@ -291,12 +355,33 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = ks.profile(enable=False, reset=True)
+    X_end = law.get_state().reshape(-1, N)  # (before the extra, untimed steps below)
+    seams_extra = None
+    if seams:
+        # per-phase device times from a few extra steps with event pairs around the calls (not inside the timed region: every
+        # timer read is a host wait)
+        n_out, t_out = seams["outputs"], seams["t_out"]
+        treps = [step_seams(report=False, timers=True) for _ in range(5)]
+        for i_, r_ in enumerate(reps):
+            t_ = treps[i_ % len(treps)]
+            r_.assembly_ms, r_.precond_ms, r_.linear_solve_ms, r_.update_ms = t_.assembly_ms, t_.precond_ms, t_.linear_solve_ms, t_.update_ms
+        el_no = elapsed - t_out
+        seams_extra = {"report_every": args.report_every, "output_states_downloaded": n_out,
+                       "output_ms_per_download": round(t_out / max(n_out, 1) * 1e3, 3),
+                       "value_without_output": round(args.steps / el_no, 4), "ms_per_step_without_output": round(el_no / args.steps * 1e3, 3),
+                       "entry_points_per_newton_iteration": ["jh_assemble", "jh_convergence", "jh_ilu0_factor", "jh_krylov_set_min_iterations",
+                                                             "jh_bicgstab", "jh_vec_negate_into", "jh_increment_norm", "jh_update_primary",
+                                                             "jh_law_change_report", "jh_law_update_state0"]
+                                                            + (["jh_law_get_variable x%d (every %d step(s))" % (N, args.report_every)] if args.report_every else []),
+                       "note": "value = Newton iterations/s through the seam sequence of julia/JutulHIP.jl (jutul.jl_amd/julia_mirror.py) incl. the "
+                               "device->host state copy of get_output_state at every report step (value_without_output: the same loop minus the "
+                               "host time spent in those copies); state, state0 and dx stay in HBM between iterations"}
+        m.unregister(host_state0) if st.registered else None
     timeouts = ctx.comm_info()["timeouts"]
     if world > 1:
         tt = torch.tensor([elapsed, float(timeouts)], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, timeouts = float(tt[0]), int(tt[1])
-    X_end = law.get_state().reshape(-1, N)
     state_ok = bool(np.isfinite(X_end).all())
     if N == 2:
         state_ok = state_ok and bool((X_end[:, 1] > -1e-6).all() and (X_end[:, 1] < 1 + 1e-6).all())
@@ -312,6 +397,7 @@ def main():
     # ---- roofline of the dominant kernel (rank 0's share of the grid) --------------------------------------------
     n_loc, nhf_loc, nnz_loc = disc.nc, disc.nhf, disc.nnzb
     info = prec.info()
+    sinfo = sim.lsys.jac.spmv_info()
     lin_its = [int(r.linear_iterations) for r in reps]
     asm_ms = float(np.mean([r.assembly_ms for r in reps]))
     fac_ms = float(np.mean([r.precond_ms for r in reps]))
@@ -362,11 +448,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.law} TPFA conservation law ({N} primary variable{'s' if N > 1 else ''}/cell), {nc_g}-cell "
-                                   f"Kuhn-split tet lattice ({nx}x{ny}x{nz}x6, scrambled numbering), nf={nf_g}, 1 Newton iteration/step: "
+                                   f"{mesh_desc}, nf={nf_g}, 1 Newton iteration/step: "
                                    f"assembly + block-Jacobi ILU(0) factor + BiCGStab(rtol={args.rtol})",
-                       "cells": nc_g, "faces": nf_g, "law": args.law, "block_n": N, "dt": args.dt,
+                       "cells": nc_g, "faces": nf_g, "mesh": args.mesh, "law": args.law, "block_n": N, "dt": args.dt,
                        "block_rows": args.block_rows or (256 if disc.nc < 2_000_000 else 512),
                        "parallelism": f"dd{world}" if world > 1 else "single", "precond_side": ks.config.precond_side,
+                       "path": args.path, "seams": seams_extra,
                        "launcher": os.environ.get("JH_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
                        "ranks_seen": ranks_seen, "devices_used": devices_used, "rccl_ranks": cinfo["rccl_ranks"],
                        "scalar_allreduce": ("mailbox" if mailbox else "rccl") if world > 1 else None,
@@ -374,6 +461,10 @@ def main():
                        "halo": ("host-callback (test mode)" if host_halo else "rccl") if world > 1 else None,
                        "comm_timeouts": timeouts, "comm_timeout_s": cinfo["timeout_s"],
                        "ilu_blocks": info["nblocks"], "ilu_max_levels": info["max_levels"],
+                       "ilu_kept_fraction": round(kept / max(1, nnz_loc - n_loc), 4),  # couplings inside the block-Jacobi blocks
+                       "kernels_selected": {"spmv": ("jagged-slice, 16-bit column codes" if sinfo["col16"] else "jagged-slice, 32-bit columns") if sinfo["jagged"] else "CSR tile kernel",
+                                            "ilu0_apply": "chunk-jagged" if info["jagged"] else "row-major (LDS)" if info["lds_mode"] else "level-per-launch",
+                                            "ilu0_factor": info["factor_kernel"], "longest_row": sinfo["longest_row"]},
                        "linear_iterations_per_step": round(float(np.mean(lin_its)), 2),
                        "linear_iterations_first_steps": its_all[:8], "state_norm": state_norm,
                        "setup_s": round(t_setup, 1), "setup_phases_s": {k: round(v, 2) for k, v in setup.items()},
@@ -393,6 +484,18 @@ def main():
         ctx.comm_finalize()
     if world > 1:
         dist.destroy_process_group()
+
+
+def make_mesh(ja, args, cells=None):
+    cells = cells or args.cells
+    if args.mesh == "delaunay":
+        m = ja.delaunay_tet_mesh(max(64, int(cells / 6.7)), grading=args.grading)
+        return m, f"Delaunay tet mesh of {m['points']} graded random points (grading {args.grading}, scrambled numbering)"
+    if args.mesh == "polyhedral":
+        m = ja.polyhedral_dual_mesh(max(64, cells), grading=args.grading)
+        return m, f"polyhedral median-dual grid of a Delaunay tet mesh ({m['points']} graded random points, grading {args.grading}, scrambled numbering)"
+    nx, ny, nz = dims_for_cells(cells)
+    return ja.tet_lattice_mesh(nx, ny, nz), f"Kuhn-split tet lattice ({nx}x{ny}x{nz}x6, scrambled numbering)"
 
 
 def initial_state(np, law, nc):
@@ -488,8 +591,7 @@ def cpu_baseline(args, nc_gpu):
     from jutul_amd import dd
     from oracle import oracle as o
     o.build()
-    nx, ny, nz = dims_for_cells(args.cpu_cells)
-    m = ja.tet_lattice_mesh(nx, ny, nz)
+    m, _ = make_mesh(ja, args, args.cpu_cells)
     nc = m["nc"]
     N = 2 if args.law == "twophase" else 1
     T = m["T"] / m["T"].mean()

@@ -136,6 +136,10 @@ int32_t jh_spmv(jh_csr A, jh_vec x, jh_vec y, double alpha, double beta);
  * Same accumulation order, hence the same bits as jh_spmv.  Scalar matrices with at most 8 entries per row; error otherwise.
  * Exposed so that the parity tests can check the layout on its own. */
 int32_t jh_spmv_jagged(jh_csr A, jh_vec x, jh_vec y, double alpha, double beta);
+/* Which product the Krylov loop uses for this matrix, for the host to report: out6 = [0] 1 = jagged-slice kernels (0 = CSR tile
+ * kernel: block size > 1 or a row longer than the jagged layout holds), [1] 1 = 16-bit column codes (matrices of 3M rows and more),
+ * [2] longest row (block entries), [3] 64-row slices, [4] CSR tiles, [5] entries of the far-column lists (incl. padding). */
+int32_t jh_spmv_info(jh_csr A, int64_t *out6);
 /* krylov_scale_system! / apply_scaling_to_linearized_system! (linsolve/krylov.jl:194, default.jl:325-385):
  * kind 0 :none, 1 :diagonal (J <- diag(1/|A_ii[j,j]|) J, r likewise), 2 :dt (J <- dt J, r <- dt r).  In place. */
 int32_t jh_scale_system(jh_csr A, jh_vec r, int32_t kind, double dt);
@@ -169,11 +173,22 @@ int32_t jh_law_set_data(jh_law L, int32_t which, const double *host);
 int32_t jh_law_set_state(jh_law L, const double *X);   /* primary variables [N, nc]                      */
 int32_t jh_law_set_state0(jh_law L, const double *X0); /* previous-step state (state0)                   */
 int32_t jh_law_get_state(jh_law L, double *X);
+/* One primary variable as Jutul stores it -- state[k] / state0[k], a contiguous Float64 array over the cells (host numbering):
+ * which 0 = state, 1 = state0; e = 0-based index of the variable.  get_output_state (models.jl:1048-1058) copies state0[k] at
+ * every report step: this call is the device -> host transfer behind it (straight into the host array, no staging pass on
+ * the host).  With the target registered (jh_host_register) the copy is one DMA at PCIe speed. */
+int32_t jh_law_get_variable(jh_law L, int32_t which, int32_t e, double *out);
+/* hipHostRegister / hipHostUnregister of a host array the caller keeps alive (Jutul's state0[k] arrays live as long as the
+ * simulator storage): page-locks it so that uploads / downloads are DMA transfers instead of pageable copies. */
+int32_t jh_host_register(void *ptr, int64_t bytes);
+int32_t jh_host_unregister(void *ptr);
 int32_t jh_law_update_state0(jh_law L);                /* state0 <- state (update_after_step!, models.jl:983-1011) */
 int32_t jh_law_reset_state(jh_law L);                  /* state <- state0 (timestep cut)                 */
 /* forces: PoissonSource-style cell sources added to the residual (models.jl:889-901; variable_poisson.jl:78-84).
  * cells 1-based [n], values [N, n]. */
 int32_t jh_law_set_sources(jh_law L, int64_t n, const int64_t *cells, const double *values);
+/* (forces are re-applied in every Newton iteration, models.jl:889-901: handing over the list of the previous call again is
+ * recognised and costs neither an upload nor a synchronisation) */
 /* update_equation! (conservation.jl:572-626) + update_linearized_system_equation! (conservation.jl:298-430)
  * fused: one pass over the CSR-ordered half-faces; writes every nzval slot of A and r. dt <= 0 selects the
  * stationary Poisson variant. */
@@ -184,6 +199,14 @@ int32_t jh_convergence(jh_law L, jh_vec r, int64_t n_owned, double *err);
 /* update_primary_variables! (models.jl:928-953, variables/utils.jl:110-174): X += clamp-chain(w*dx) with
  * per-variable scale / abs_max / rel_max / minimum / maximum (5*N doubles, NaN = unset; NULL = no limits). */
 int32_t jh_update_primary(jh_law L, jh_vec dx, double w, const double *limits);
+/* increment_norm (models.jl:955-965) on the device: out[2e] = sum |dx[e, cell]|, out[2e + 1] = max |dx[e, cell]| over the first
+ * n_owned cells (<= 0: all) for every primary variable e -- what update_primary_variables! reports, without dx leaving HBM.  The
+ * sums propagate NaN / Inf, so `check = true` (check_increment) is isfinite(out[2e]). */
+int32_t jh_increment_norm(jh_law L, jh_vec dx, int64_t n_owned, double *out);
+/* variable_change_report(state[k], state0[k], pvar) (models.jl:1023-1038) on the device, called by update_after_step!
+ * (models.jl:983-1011) BEFORE state0 <- state: out[4e..4e+3] = sum |x - x0|, max |x - x0|, sum |x|, max |x| of primary
+ * variable e over the first n_owned cells (<= 0: all). */
+int32_t jh_law_change_report(jh_law L, int64_t n_owned, double *out);
 /* The limits jh_newton_step applies in its update (the variables' minimum / maximum / absolute / relative increment limits,
  * variables/utils.jl:110-174; e.g. Saturations: abs_max 0.2, minimum 0, maximum 1): same 5*N layout, NULL = none (default). */
 int32_t jh_law_set_update_limits(jh_law L, const double *limits);

@@ -23,11 +23,11 @@ import numpy as np
 from . import _lib
 from ._lib import JutulHIPError, NewtonReport, check, f64, i64, pf, pi, pi32
 from .discretization import compute_face_gdz, compute_face_trans, compute_half_face_trans, half_face_map  # noqa: F401
-from .meshgen import cartesian_neighbors, tet_lattice_mesh  # noqa: F401
+from .meshgen import cartesian_neighbors, delaunay_tet_mesh, polyhedral_dual_mesh, tet_lattice_mesh  # noqa: F401
 
 __all__ = ["HIPContext", "LocalCommGroup", "TwoPointPotentialFlowHardCoded", "DeviceVector", "StaticSparsityMatrixCSR", "ConservationLaw",
            "ILUZeroPreconditioner", "JacobiPreconditioner", "SPAI0Preconditioner", "IterativeSolverConfig", "GenericKrylov", "LinearizedSystem", "linear_solve", "scale_system",
-           "Simulator", "JutulHIPError", "mul_", "ilu0_csr", "ldiv_", "tet_lattice_mesh", "cartesian_neighbors"]
+           "Simulator", "JutulHIPError", "mul_", "ilu0_csr", "ldiv_", "tet_lattice_mesh", "delaunay_tet_mesh", "polyhedral_dual_mesh", "cartesian_neighbors"]
 
 REORDER = {"none": 0, "blocks": 1}
 LAYOUT = {"equation_major": 0, "entity_major": 1, "block_major": 2}  # JutulMatrixLayout (core_types.jl:101-165)
@@ -386,6 +386,12 @@ class StaticSparsityMatrixCSR(_Handle):
     def new_vector(self, values=None):
         return DeviceVector(self.disc if self.disc is not None else self, values)
 
+    def spmv_info(self):
+        """Which product the Krylov loop multiplies with: dict(jagged, col16, longest_row, slices, tiles, far_entries)."""
+        o = np.zeros(6, dtype=np.int64)
+        check(_L().jh_spmv_info(self.h, pi(o)))
+        return dict(jagged=bool(o[0]), col16=bool(o[1]), longest_row=int(o[2]), slices=int(o[3]), tiles=int(o[4]), far_entries=int(o[5]))
+
 
 def mul_(y, A, x, alpha=1.0, beta=0.0, jagged=False):
     """mul!(y, A, x, alpha, beta) (StaticCSR/mat.jl:24-39).  jagged=True: through the jagged-slice layout of the Krylov loop."""
@@ -467,6 +473,19 @@ class ConservationLaw(_Handle):
     def update_primary_variables(self, dx, w=1.0, limits=None):
         lim = f64(limits) if limits is not None else None
         check(_L().jh_update_primary(self.h, dx.h, float(w), pf(lim)))
+
+    def increment_norm(self, dx, n_owned=0):
+        """increment_norm (models.jl:955-965) on the device: [(sum |dx_e|, max |dx_e|) for every primary variable e]."""
+        out = np.zeros(2 * self.N)
+        check(_L().jh_increment_norm(self.h, dx.h, int(n_owned), pf(out)))
+        return [(out[2 * e], out[2 * e + 1]) for e in range(self.N)]
+
+    def change_report(self, n_owned=0):
+        """variable_change_report(state, state0) (models.jl:1023-1038) on the device, per primary variable:
+        dict(dx=(sum, max) of |x - x0|, x=(sum, max) of |x|)."""
+        out = np.zeros(4 * self.N)
+        check(_L().jh_law_change_report(self.h, int(n_owned), pf(out)))
+        return [dict(dx=(out[4 * e], out[4 * e + 1]), x=(out[4 * e + 2], out[4 * e + 3])) for e in range(self.N)]
 
     def set_update_limits(self, limits):
         """Limits applied by Simulator.perform_step's update (the variables' minimum / maximum / absolute / relative increment

@@ -69,6 +69,7 @@ SIGNATURES = {
     "jh_vec_download_layout": [H, C.c_int32, F64P],
     "jh_spmv": [H, H, H, C.c_double, C.c_double],
     "jh_spmv_jagged": [H, H, H, C.c_double, C.c_double],
+    "jh_spmv_info": [H, I64P],
     "jh_scale_system": [H, H, C.c_int32, C.c_double],
     "jh_unit_diagonalize": [H, H, C.c_int64],
     "jh_law_create": [H, C.c_int32, F64P, C.POINTER(H)],
@@ -78,6 +79,9 @@ SIGNATURES = {
     "jh_law_set_state": [H, F64P],
     "jh_law_set_state0": [H, F64P],
     "jh_law_get_state": [H, F64P],
+    "jh_law_get_variable": [H, C.c_int32, C.c_int32, F64P],
+    "jh_host_register": [C.c_void_p, C.c_int64],
+    "jh_host_unregister": [C.c_void_p],
     "jh_law_update_state0": [H],
     "jh_law_reset_state": [H],
     "jh_law_set_sources": [H, C.c_int64, I64P, F64P],
@@ -85,6 +89,8 @@ SIGNATURES = {
     "jh_convergence": [H, H, C.c_int64, F64P],
     "jh_law_set_update_limits": [H, F64P],
     "jh_update_primary": [H, H, C.c_double, F64P],
+    "jh_increment_norm": [H, H, C.c_int64, F64P],
+    "jh_law_change_report": [H, C.c_int64, F64P],
     "jh_ilu0_create": [H, I64P, C.c_int64, C.POINTER(H)],
     "jh_ilu0_destroy": [H],
     "jh_ilu0_factor": [H],

@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 
 #include "jh_internal.hpp"
 
@@ -34,11 +35,13 @@ extern "C" int32_t jh_context_create(int32_t device_id, jh_context *out) {
     JH_HIP(hipEventCreate(&c->ev0));
     JH_HIP(hipEventCreate(&c->ev1));
     for (auto &e : c->ev_step) JH_HIP(hipEventCreate(&e));
-    c->scalars.alloc(32);
-    JH_HIP(hipMemsetAsync(c->scalars.p, 0, 32 * sizeof(double), c->stream));
-    JH_HIP(hipHostMalloc((void **)&c->h_scalars, 32 * sizeof(double), hipHostMallocDefault));
+    c->scalars.alloc(jh::JH_NSCALARS);
+    JH_HIP(hipMemsetAsync(c->scalars.p, 0, jh::JH_NSCALARS * sizeof(double), c->stream));
+    JH_HIP(hipHostMalloc((void **)&c->h_scalars, jh::JH_NSCALARS * sizeof(double), hipHostMallocDefault));
     JH_HIP(hipHostMalloc((void **)&c->h_pub, 2 * jh::JH_PUB_LEN * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->h_pub, 0, 2 * jh::JH_PUB_LEN * sizeof(double));
+    JH_HIP(hipHostMalloc((void **)&c->h_rd, jh::JH_NSCALARS * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_rd, 0, jh::JH_NSCALARS * sizeof(double));
     JH_HIP(hipStreamSynchronize(c->stream));
     *out = c.release();
   });
@@ -54,6 +57,7 @@ extern "C" int32_t jh_context_destroy(jh_context ctx) {
     for (auto e : ctx->ev_step) if (e) (void)hipEventDestroy(e);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     if (ctx->h_pub) (void)hipHostFree(ctx->h_pub);
+    if (ctx->h_rd) (void)hipHostFree(ctx->h_rd);
     if (ctx->comm_stream) {
       (void)hipStreamSynchronize(ctx->comm_stream);
       (void)hipEventDestroy(ctx->ev_halo_ready);
@@ -308,6 +312,21 @@ extern "C" int32_t jh_spmv_jagged(jh_csr A, jh_vec x, jh_vec y, double alpha, do
     JH_HIP(hipGetLastError());
   });
 }
+extern "C" int32_t jh_spmv_info(jh_csr A, int64_t *out6) {
+  return guard([&] {
+    if (!A || !out6) JH_THROW("null argument");
+    Pattern &P = *A->pat;
+    if (!P.jag.built) P.build_jagged();
+    int32_t kmax = 0;
+    for (int64_t i = 0; i < P.n; ++i) kmax = std::max(kmax, P.rowptr[i + 1] - P.rowptr[i]);
+    out6[0] = (P.jag.usable && !getenv("JH_SPMV_NO_JAGGED")) ? 1 : 0;
+    out6[1] = (P.jag.usable && P.jag.d_col.n == 0) ? 1 : 0;
+    out6[2] = kmax;
+    out6[3] = P.jag.usable ? P.jag.nslices : 0;
+    out6[4] = P.ntiles;
+    out6[5] = P.jag.usable ? (int64_t)P.jag.d_far.n : 0;
+  });
+}
 extern "C" int32_t jh_scale_system(jh_csr A, jh_vec r, int32_t kind, double dt) {
   return guard([&] {
     if (!A || !r) JH_THROW("null argument");
@@ -400,6 +419,33 @@ extern "C" int32_t jh_law_get_state(jh_law L, double *X) {
     download_cells(L->ctx, *L->disc->pat, X, L->X.p, L->disc->nc, L->N);
   });
 }
+extern "C" int32_t jh_law_get_variable(jh_law L, int32_t which, int32_t e, double *out) {
+  return guard([&] {
+    if (!L || !out) JH_THROW("null argument");
+    if (which < 0 || which > 1) JH_THROW("which must be 0 (state) or 1 (state0)");
+    if (e < 0 || e >= L->N) JH_THROW("no such primary variable");
+    jh_context ctx = L->ctx;
+    const Pattern &P = *L->disc->pat;
+    const int64_t nc = L->disc->nc;
+    JH_HIP(hipSetDevice(ctx->device));
+    ctx->ensure_stage(nc);
+    k_component_out(ctx->stream, ctx->stage.p, which ? L->X0.p : L->X.p, P.perm.empty() ? nullptr : P.d_perm.p, nc, L->N, e);
+    JH_HIP(hipMemcpyAsync(out, ctx->stage.p, nc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+  });
+}
+extern "C" int32_t jh_host_register(void *ptr, int64_t bytes) {
+  return guard([&] {
+    if (!ptr || bytes <= 0) JH_THROW("bad host range");
+    JH_HIP(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+  });
+}
+extern "C" int32_t jh_host_unregister(void *ptr) {
+  return guard([&] {
+    if (!ptr) JH_THROW("null argument");
+    JH_HIP(hipHostUnregister(ptr));
+  });
+}
 extern "C" int32_t jh_law_update_state0(jh_law L) {
   return guard([&] { k_copy(L->ctx->stream, L->X0.p, L->X.p, (int64_t)L->X.n); });
 }
@@ -409,29 +455,40 @@ extern "C" int32_t jh_law_reset_state(jh_law L) {
 extern "C" int32_t jh_law_set_sources(jh_law L, int64_t n, const int64_t *cells, const double *values) {
   return guard([&] {
     if (!L) JH_THROW("null argument");
+    if (n < 0 || (n > 0 && (!cells || !values))) JH_THROW("bad source list");
     JH_HIP(hipSetDevice(L->ctx->device));
+    // forces are re-applied in every Newton iteration (update_equations_and_apply_forces!): an unchanged list costs nothing
+    if (L->src_set && (int64_t)L->h_src_cells.size() == n && std::equal(cells, cells + n, L->h_src_cells.begin()) &&
+        std::equal(values, values + n * L->N, L->h_src_vals.begin(), [](double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0; }))
+      return;
     const Pattern &P = *L->disc->pat;
     // pre-sum duplicates: the reference adds every source in sequence (variable_poisson.jl:78-84)
     std::vector<int32_t> cs;
     std::vector<double> vs;
-    std::vector<int64_t> where(L->disc->nc, -1);
+    std::unordered_map<int64_t, int64_t> where;  // host cell -> position in cs (work proportional to the list, not to nc)
+    where.reserve((size_t)n * 2);
     for (int64_t i = 0; i < n; ++i) {
       int64_t c = cells[i] - 1;
       if (c < 0 || c >= L->disc->nc) JH_THROW("source cell out of range");
-      if (where[c] < 0) {
-        where[c] = (int64_t)cs.size();
+      auto it = where.find(c);
+      if (it == where.end()) {
+        where.emplace(c, (int64_t)cs.size());
         cs.push_back(P.iperm.empty() ? (int32_t)c : P.iperm[c]);
         for (int e = 0; e < L->N; ++e) vs.push_back(values[i * L->N + e]);
       } else {
-        for (int e = 0; e < L->N; ++e) vs[where[c] * L->N + e] += values[i * L->N + e];
+        for (int e = 0; e < L->N; ++e) vs[it->second * L->N + e] += values[i * L->N + e];
       }
     }
+    JH_HIP(hipStreamSynchronize(L->ctx->stream));  // an assembly in flight may still read the old list
     L->nsrc = (int64_t)cs.size();
     if (L->nsrc) {
       L->src_cell.upload(cs, L->ctx->stream);
       L->src_val.upload(vs, L->ctx->stream);
       JH_HIP(hipStreamSynchronize(L->ctx->stream));
     }
+    L->h_src_cells.assign(cells, cells + n);
+    L->h_src_vals.assign(values, values + n * L->N);
+    L->src_set = true;
   });
 }
 extern "C" int32_t jh_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
@@ -477,6 +534,27 @@ extern "C" int32_t jh_law_set_update_limits(jh_law L, const double *limits) {
     std::vector<double> h(limits, limits + 5 * L->N);
     L->limits.upload(h, L->ctx->stream);
     JH_HIP(hipStreamSynchronize(L->ctx->stream));
+  });
+}
+extern "C" int32_t jh_increment_norm(jh_law L, jh_vec dx, int64_t n_owned, double *out) {
+  return guard([&] {
+    if (!L || !dx || !out) JH_THROW("null argument");
+    if (dx->len != L->disc->nc * L->N) JH_THROW("increment has wrong length");
+    JH_HIP(hipSetDevice(L->ctx->device));
+    if (n_owned <= 0 || n_owned > L->disc->nc) n_owned = L->disc->nc;
+    k_absstats(L->ctx, dx->d.p, nullptr, n_owned, L->N, S_STATS);
+    double h[12];
+    read_scalars(L->ctx, S_STATS, 4 * L->N, h);
+    for (int e = 0; e < L->N; ++e) { out[2 * e] = h[4 * e]; out[2 * e + 1] = h[4 * e + 1]; }
+  });
+}
+extern "C" int32_t jh_law_change_report(jh_law L, int64_t n_owned, double *out) {
+  return guard([&] {
+    if (!L || !out) JH_THROW("null argument");
+    JH_HIP(hipSetDevice(L->ctx->device));
+    if (n_owned <= 0 || n_owned > L->disc->nc) n_owned = L->disc->nc;
+    k_absstats(L->ctx, L->X.p, L->X0.p, n_owned, L->N, S_STATS);
+    read_scalars(L->ctx, S_STATS, 4 * L->N, out);
   });
 }
 extern "C" int32_t jh_halo_exchange(jh_tpfa d, jh_vec v) {

@@ -1529,7 +1529,10 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
             int mxc = 0;
             for (int64_t b = 0; b < nb; ++b) { all_diag = all_diag && blk_diag[b]; mxc = std::max(mxc, M->chunk_ptr[b + 1] - M->chunk_ptr[b]); }
             M->max_chunks = mxc;
-            M->diag_only = all_diag && mxc * 64 <= 1024 && !getenv("JH_ILU_NO_DIAG_FACTOR");
+            // the sweep kernel keeps the block's inverted pivots in dynamic LDS (8 * rows * bs^2 bytes): blocks beyond the 64 KB a launch
+            // gets without an opt-in (e.g. > 910 rows of 3x3 blocks from a caller's partition) take the program kernel
+            M->diag_only = all_diag && mxc * 64 <= 1024 && sizeof(double) * (size_t)M->max_block_rows * M->bs * M->bs <= 64 * 1024 &&
+                           !getenv("JH_ILU_NO_DIAG_FACTOR");
             if (M->diag_only) {
               hipStream_t sd = M->ctx->stream;
               M->d_jt_map.upload(jt_map, sd); M->d_jf_diag.upload(jf_diag, sd); M->d_jf_bslot.upload(jf_bslot, sd);
@@ -1709,6 +1712,7 @@ void ilu_factor(jh_ilu M) {
       switch (M->bs) { case 1: JH_DIAGK(1); break; case 2: JH_DIAGK(2); break; case 3: JH_DIAGK(3); break; }
 #undef JH_DIAGK
 #undef JH_DIAG
+      JH_HIP(hipGetLastError());  // a refused launch must not leave stale factors marked as fresh
       M->factored = true;
       return;
     }
@@ -1722,6 +1726,7 @@ void ilu_factor(jh_ilu M) {
     } while (0)
     switch (M->bs) { case 1: JH_PROG(1); break; case 2: JH_PROG(2); break; case 3: JH_PROG(3); break; }
 #undef JH_PROG
+    JH_HIP(hipGetLastError());
     M->factored = true;
     return;
   }

@@ -86,6 +86,8 @@ constexpr int TILE_THREADS = 256;  // 4 wavefronts
 constexpr int TILE_NNZ = 1024;     // block-nnz staged in LDS per workgroup
 constexpr int TILE_ROWS = 256;     // rows per tile (one row-reduce thread each; row id fits uint8)
 constexpr int NUM_XCD = 8;
+constexpr int JH_NSCALARS = 64;   // device scalars of a context
+constexpr int S_STATS = 32;       // [32, 44): k_absstats results (4 per variable, N <= 3)
 
 // ---- device buffer helper ----------------------------------------------------------------------------
 template <class T>
@@ -155,11 +157,13 @@ struct jh_context_s {
   // reduction scratch: partial sums [NSLOT][max_blocks], device scalars, pinned host mirror
   jh::DevBuf<double> partials;
   size_t partial_stride = 0;
-  jh::DevBuf<double> scalars;  // 32 doubles
-  double *h_scalars = nullptr; // pinned, 32 doubles
+  jh::DevBuf<double> scalars;  // JH_NSCALARS doubles: [0, 11) Krylov, [12, 15) convergence, [16, 32) limits / all-reduce staging, [20] S_DONE, [32, 48) absstats
+  double *h_scalars = nullptr; // pinned, JH_NSCALARS doubles
   jh::DevBuf<double> stage;    // staging for permuted uploads/downloads
   double *h_pub = nullptr;     // pinned + coherent: 2 records of JH_PUB_LEN doubles the solver loop publishes to (see jh_krylov.hip)
   uint64_t pub_seq = 0;        // sequence number of the last published record
+  double *h_rd = nullptr;      // pinned + coherent: JH_NSCALARS doubles read_scalars publishes to, [JH_NSCALARS - 1] = sequence number
+  uint64_t rd_seq = 0;
   jh::Comm *comm = nullptr;
   // second stream + events of the overlapped halo exchange (created on first use, jh_comm.cpp)
   hipStream_t comm_stream = nullptr;
@@ -299,6 +303,9 @@ struct jh_law_s {
   int64_t nsrc = 0;
   jh::DevBuf<int32_t> src_cell;
   jh::DevBuf<double> src_val;
+  std::vector<int64_t> h_src_cells;  // the list as last handed over (jh_law_set_sources skips an unchanged one)
+  std::vector<double> h_src_vals;
+  bool src_set = false;
   // JH_LAW_CUSTOM: the assembly kernel compiled at run time from the user's source (jh_custom.cpp)
   hipModule_t custom_module = nullptr;
   hipFunction_t custom_kernel = nullptr;
@@ -317,6 +324,7 @@ void k_axpby(hipStream_t s, double *y, double a, const double *x, double b, int6
 void k_negate(hipStream_t s, double *dst, const double *src, int64_t n);
 void k_permute_in(hipStream_t s, double *dst, const double *src_hostorder, const int32_t *perm, int64_t n, int bs);
 void k_permute_out(hipStream_t s, double *dst_hostorder, const double *src, const int32_t *perm, int64_t n, int bs);
+void k_component_out(hipStream_t s, double *dst_hostorder, const double *src, const int32_t *perm, int64_t n, int bs, int e);
 void k_gather_blocks(hipStream_t s, double *dst, const double *src, const int32_t *slot, int64_t nblk, int bb,
                      bool scatter);
 // dot products: result(s) land in ctx->scalars[slot..]; deterministic two-stage reduction
@@ -324,6 +332,7 @@ void k_dot(jh_context ctx, const double *a, const double *b, int64_t n, int slot
 void k_dot2(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, int slot);
 void k_dot2_to(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, double *out);
 void k_absmax_strided(jh_context ctx, const double *r, int64_t ncell, int bs, int slot);
+void k_absstats(jh_context ctx, const double *a, const double *b, int64_t ncell, int bs, int slot);  // 4 scalars per variable from `slot`
 double read_scalar(jh_context ctx, int slot);                  // sync + D2H
 void read_scalars(jh_context ctx, int slot, int count, double *out);
 // Optional dot-product epilogue of the SpMV: mode 1 -> sum(w .* y) ; mode 2 -> sum(y .* w), sum(y .* y); rows >= n_rows

@@ -75,6 +75,14 @@ void k_permute_in(hipStream_t s, double *dst, const double *src, const int32_t *
 void k_permute_out(hipStream_t s, double *dst, const double *src, const int32_t *perm, int64_t n, int bs) {
   if (n) hipLaunchKernelGGL(permute_out_kernel, dim3(grid_for(n * bs)), dim3(256), 0, s, dst, src, perm, n, bs);
 }
+// component e of a [bs, n] device-ordered vector -> contiguous host-ordered array of n doubles (perm == nullptr: same order)
+__global__ void component_out_kernel(double *dst, const double *src, const int32_t *perm, int64_t n, int bs, int e) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+    dst[perm ? (int64_t)perm[r] : r] = src[r * bs + e];
+}
+void k_component_out(hipStream_t s, double *dst, const double *src, const int32_t *perm, int64_t n, int bs, int e) {
+  if (n) hipLaunchKernelGGL(component_out_kernel, dim3(grid_for(n)), dim3(256), 0, s, dst, src, perm, n, bs, e);
+}
 void k_gather_blocks(hipStream_t s, double *dst, const double *src, const int32_t *slot, int64_t nblk, int bb, bool scatter) {
   if (nblk) hipLaunchKernelGGL(gather_blocks_kernel, dim3(grid_for(nblk * bb)), dim3(256), 0, s, dst, src, slot, nblk, bb, scatter);
 }
@@ -183,10 +191,81 @@ void k_absmax_strided(jh_context ctx, const double *r, int64_t ncell, int bs, in
   }
 }
 
+// Per variable e: sum|a - b|, max|a - b|, sum|a|, max|a| over the first ncell cells (b == nullptr: b = 0, so the two pairs
+// coincide) -- increment_norm (models.jl:955-965) and variable_change_report (models.jl:1023-1038) on the device.
+// Sums are NaN/Inf propagating, so a non-finite increment shows up in them (check_increment).
+__global__ __launch_bounds__(256) void absstats_partial_kernel(const double *a, const double *b, int64_t ncell, int bs, int e, double *part,
+                                                               size_t stride) {
+  __shared__ double sm[8];
+  double sd = 0, md = 0, sa = 0, ma = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < ncell; i += (int64_t)gridDim.x * blockDim.x) {
+    const double x = a[i * bs + e];
+    const double d = fabs(b ? x - b[i * bs + e] : x), v = fabs(x);
+    sd += d;
+    md = (d > md || d != d) ? d : md;
+    sa += v;
+    ma = (v > ma || v != v) ? v : ma;
+  }
+  const double r0 = block_reduce<false>(sd, sm), r1 = block_reduce<true>(md, sm), r2 = block_reduce<false>(sa, sm), r3 = block_reduce<true>(ma, sm);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = r0;
+    part[stride + blockIdx.x] = r1;
+    part[2 * stride + blockIdx.x] = r2;
+    part[3 * stride + blockIdx.x] = r3;
+  }
+}
+__global__ __launch_bounds__(FIN_THREADS) void absstats_final_kernel(const double *part, size_t stride, int nparts, double *out) {
+  final_reduce_body<false>(part, stride, nparts, 1, out);
+  final_reduce_body<true>(part + stride, stride, nparts, 1, out + 1);
+  final_reduce_body<false>(part + 2 * stride, stride, nparts, 1, out + 2);
+  final_reduce_body<true>(part + 3 * stride, stride, nparts, 1, out + 3);
+}
+void k_absstats(jh_context ctx, const double *a, const double *b, int64_t ncell, int bs, int slot) {
+  ensure_partials(ctx, 0);
+  int g = grid_for(ncell);
+  if (g > RED_BLOCKS) g = RED_BLOCKS;
+  for (int e = 0; e < bs; ++e) {
+    hipLaunchKernelGGL(absstats_partial_kernel, dim3(g), dim3(256), 0, ctx->stream, a, b, ncell, bs, e, ctx->partials.p, ctx->partial_stride);
+    hipLaunchKernelGGL(absstats_final_kernel, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, g,
+                       ctx->scalars.p + slot + 4 * e);
+  }
+}
+
+// Device scalars -> host.  A D2H copy + hipStreamSynchronize costs a DMA packet and an interrupt-driven wake-up per read;
+// the seam path reads scalars three times per Newton iteration (convergence, increment norms, change report).  Instead a
+// one-wavefront kernel stores the values into pinned, host-coherent memory followed by a sequence number, and the host spins
+// on that (the protocol of the Krylov loop's iteration records).  JH_READ_SYNC=1 restores the copy + synchronise.
+__global__ void publish_scalars_kernel(const double *sc, int count, double *dst, double seq) {
+  if ((int)threadIdx.x < count) __hip_atomic_store(dst + threadIdx.x, sc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(dst + (JH_NSCALARS - 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 void read_scalars(jh_context ctx, int slot, int count, double *out) {
-  JH_HIP(hipMemcpyAsync(ctx->h_scalars + slot, ctx->scalars.p + slot, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
-  JH_HIP(hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < count; ++i) out[i] = ctx->h_scalars[slot + i];
+  static const bool use_sync = getenv("JH_READ_SYNC") != nullptr;
+  if (use_sync || !ctx->h_rd || count >= JH_NSCALARS - 1) {
+    JH_HIP(hipMemcpyAsync(ctx->h_scalars + slot, ctx->scalars.p + slot, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < count; ++i) out[i] = ctx->h_scalars[slot + i];
+    return;
+  }
+  const double seq = (double)(++ctx->rd_seq);
+  hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->scalars.p + slot, count, ctx->h_rd, seq);
+  volatile double *r = ctx->h_rd;
+  for (uint64_t spin = 1;; ++spin) {
+    if (r[JH_NSCALARS - 1] == seq) break;
+    if ((spin & 0xffff) == 0) {  // the stream must still be busy, otherwise the kernel was lost (fault)
+      hipError_t q = hipStreamQuery(ctx->stream);
+      if (q == hipSuccess) {
+        if (r[JH_NSCALARS - 1] == seq) break;
+        JH_THROW("device scalars were not published");
+      } else if (q != hipErrorNotReady) {
+        JH_HIP(q);
+      }
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  for (int i = 0; i < count; ++i) out[i] = r[i];
 }
 double read_scalar(jh_context ctx, int slot) {
   double v;

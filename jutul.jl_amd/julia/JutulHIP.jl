@@ -8,20 +8,30 @@
 #
 # Host code stays Julia: `simulate!` drives time stepping / Newton control as before; the per-Newton hot calls go to the GPU:
 #   setup_equation_storage      conservation.jl:137       -> discretisation, law, Jacobian, vectors, face / cell data
-#   update_equation!            conservation.jl:572       -> state + state0 upload (state_pair, :549-555), sources reset
-#   get_diagonal_entries        conservation.jl:667-674   -> host accumulator the forces add into (apply_forces!, models.jl:889-901)
-#   update_linearized_system_equation!  conservation.jl:298 -> sources upload + ONE fused flux / accumulation / fill kernel
+#   update_equation!            conservation.jl:572       -> state / state0 upload ONLY when the host changed them, sources reset
+#   get_diagonal_entries        conservation.jl:667-674   -> sparse host accumulator the forces add into (apply_forces!, models.jl:889-901)
+#   update_linearized_system_equation!  conservation.jl:298 -> sources upload only when they changed + ONE fused flux / accumulation / fill kernel
 #   convergence_criterion       equations.jl:619-629      -> max |r_e| on the device (check_convergence, models.jl:830-883)
-#   linear_solve!               linsolve/krylov.jl:71-182 -> ILU(0) refactor + device BiCGStab / GMRES, dx = -x
-#   update_primary_variables!   models.jl:928-953         -> clamp chain on the device, state downloaded into storage.state
-#   update_after_step!          models.jl:983-1011        -> state0 <- state on the device
+#   linear_solve!               linsolve/krylov.jl:71-182 -> ILU(0) refactor + device BiCGStab / GMRES, dx = -x stays in HBM
+#   update_primary_variables!   models.jl:928-965         -> increment norms + clamp chain on the device
+#   update_after_step!          models.jl:983-1011        -> variable_change_report + state0 <- state on the device
+#   get_output_state            models.jl:1048-1058       -> the one place the state comes back to the host (report steps)
+#
+# State residency (the reference keeps dx and the primary variables as views into the LinearizedSystem buffers and never
+# copies them, models.jl:928-953,1105-1172; conservation.jl:549-555): after the first upload the DEVICE copy of the primary
+# variables is the state.  `device_state_valid` / `device_state0_valid` say whether the device copies equal what the host last
+# wrote (cleared by every host-side writer: reset_variables!, reset_previous_state!, invalidate_device_state!);
+# `host_state_stale` says the device has moved on (update_primary_variables!) and storage.state must be refreshed
+# (sync_host_state!) before host code reads it; get_output_state refreshes storage.state0 (what it copies), once per report step.  Per Newton iteration nothing
+# crosses PCIe except a handful of scalars.
 module JutulHIP
 
 using Jutul, LinearAlgebra
 import Jutul: JutulContext, GPUJutulContext, matrix_layout, float_type, index_type, transfer, synchronize,
               setup_equation_storage, update_equation!, update_linearized_system_equation!, align_to_jacobian!,
               declare_pattern, get_diagonal_entries, convergence_criterion, update_primary_variables!, update_after_step!,
-              reset_state_to_previous_state!, post_update_linearized_system!,
+              reset_state_to_previous_state!, post_update_linearized_system!, reset_variables!, reset_previous_state!,
+              get_output_state, setup_linearized_system!,
               linear_solve!, update_preconditioner!, apply!, operator_nrows, ConservationLaw,
               TwoPointPotentialFlowHardCoded, GenericKrylov, ILUZeroPreconditioner, linear_solve_return,
               BlockMajorLayout, EquationMajorLayout, SimulationModel, Cells
@@ -74,6 +84,7 @@ hip_face_trans(model, storage) = haskey(storage.parameters, :Transmissibilities)
 hip_face_gdz(model, storage) = haskey(storage.parameters, :TwoPointGravityDifference) ? storage.parameters[:TwoPointGravityDifference] : nothing
 hip_cell_volumes(model, storage) = haskey(storage.parameters, :FluidVolume) ? storage.parameters[:FluidVolume] : nothing
 hip_update_limits(model) = nothing                       # 5N doubles: scale, abs_max, rel_max, minimum, maximum per variable (NaN = unset)
+hip_download_increment(model) = false                    # true: linear_solve! also copies dx into sys.dx_buffer (adjoints, custom reports)
 
 # primary variables <-> the library's [N, nc] block-major layout (one scalar per cell and variable on this path)
 function pack_primary!(X::Matrix{Float64}, model, state)
@@ -85,9 +96,44 @@ end
 function unpack_primary!(state, model, X::Matrix{Float64})
     for (i, k) in enumerate(keys(Jutul.get_primary_variables(model)))
         v = state[k]
-        @. v = X[i, :]        # values only: the device owns the derivatives
+        # v may hold ForwardDiff Duals with seeded partials that Jutul's own secondary-variable evaluation expects: shift the
+        # VALUE and keep the partials, exactly like update_value does (v + dv, variables/utils.jl:169-174)
+        @inbounds for c in eachindex(v)
+            v[c] += X[i, c] - Jutul.value(v[c])
+        end
     end
     return state
+end
+
+# Sparse accumulator handed to apply_forces! as `get_diagonal_entries` (models.jl:889-901): forces do `d[c] += f.value` (N = 1)
+# or `d[e, c] += ...` on a handful of cells; remembering the touched cells makes the flush O(#sources) instead of an O(nc)
+# scan per Newton iteration.
+mutable struct SourceAccumulator <: AbstractMatrix{Float64}
+    N::Int
+    nc::Int
+    slot::Dict{Int, Int}          # cell -> column of `vals`
+    cells::Vector{Int64}
+    vals::Vector{Float64}         # N values per touched cell
+end
+SourceAccumulator(N, nc) = SourceAccumulator(N, nc, Dict{Int, Int}(), Int64[], Float64[])
+Base.size(a::SourceAccumulator) = (a.N, a.nc)
+Base.IndexStyle(::Type{SourceAccumulator}) = IndexCartesian()
+function Base.getindex(a::SourceAccumulator, e::Int, c::Int)
+    j = get(a.slot, c, 0)
+    return j == 0 ? 0.0 : a.vals[(j - 1) * a.N + e]
+end
+function Base.setindex!(a::SourceAccumulator, v, e::Int, c::Int)
+    j = get!(a.slot, c) do
+        push!(a.cells, c); append!(a.vals, zeros(a.N)); length(a.cells)
+    end
+    a.vals[(j - 1) * a.N + e] = v
+    return a
+end
+Base.getindex(a::SourceAccumulator, c::Int) = a[1, c]                 # vector use when N == 1 (variable_poisson.jl:78-84)
+Base.setindex!(a::SourceAccumulator, v, c::Int) = setindex!(a, v, 1, c)
+function reset!(a::SourceAccumulator)                                 # reset_sources! (conservation.jl:660-664)
+    empty!(a.slot); empty!(a.cells); empty!(a.vals)
+    return a
 end
 
 # ---- equation storage (seam: setup_equation_storage, conservation.jl:137) -------------------------------------------
@@ -101,9 +147,16 @@ mutable struct HIPConservationLawStorage
     N::Int
     n_owned::Int
     dt::Float64
-    X::Matrix{Float64}         # [N, nc] staging of the primary variables
-    sources::Matrix{Float64}   # [N, nc] what apply_forces! adds to the diagonal entries (values only)
+    X::Matrix{Float64}             # [N, nc] staging of the primary variables
+    sources::SourceAccumulator     # what apply_forces! adds to the diagonal entries (values only)
+    src_cells::Vector{Int64}       # the source list the device holds
+    src_vals::Vector{Float64}
     err::Vector{Float64}
+    device_state_valid::Bool       # device X  == what the host last wrote into storage.state
+    device_state0_valid::Bool      # device X0 == what the host last wrote into storage.state0
+    host_state_stale::Bool         # the device has updated X since storage.state was last refreshed
+    host_state0_stale::Bool        # the device has updated X0 (update_after_step!) since storage.state0 was last refreshed
+    registered::Bool               # storage.state0[k] arrays are page-locked (jh_host_register)
 end
 
 function setup_equation_storage(model::HIPModel,
@@ -139,7 +192,8 @@ function setup_equation_storage(model::HIPModel,
     @jh :jh_vec_create (Handle, Ref{Handle}) disc[] r
     @jh :jh_vec_create (Handle, Ref{Handle}) disc[] dx
     n_owned = ctx.n_owned > 0 ? ctx.n_owned : nc
-    return HIPConservationLawStorage(disc[], law[], jac[], r[], dx[], nc, ne, n_owned, NaN, zeros(ne, nc), zeros(ne, nc), zeros(ne))
+    return HIPConservationLawStorage(disc[], law[], jac[], r[], dx[], nc, ne, n_owned, NaN, zeros(ne, nc), SourceAccumulator(ne, nc), Int64[], Float64[],
+                                     zeros(ne), false, false, false, false, false)
 end
 
 # ---- linearized system (seam: setup_linearized_system!, models.jl:654-668; LinearizedSystem, linsolve/default.jl:34-42) -----
@@ -148,24 +202,37 @@ end
 # linear_solve! fills (its default `dx = sys.dx_buffer`, krylov.jl:79) and storage.views.primary_variables points into.
 struct HIPLinearizedSystem <: Jutul.JutulLinearSystem
     eq_s::HIPConservationLawStorage
+    jac::Handle                    # the device Jacobian (LinearizedSystem.jac, default.jl:34-42); host code gets values via jh_csr_get_values
+    jac_buffer::Nothing            # no host nzval: update_linearized_system! passes it on as `nzval = nothing`
     r_buffer::Vector{Float64}
-    dx_buffer::Vector{Float64}
+    dx_buffer::Vector{Float64}     # host mirror, filled only on request (hip_download_increment)
+    matrix_layout
 end
 
-function Jutul.setup_linearized_system!(storage, model::HIPModel)
-    eq_s = first(values(storage[:equations]))::HIPConservationLawStorage   # single conservation law per model on this path
+# the conservation law this path owns among the model's equations (other equations keep Jutul's host path and are rejected here)
+function hip_equation_storage(storage)
+    found = [v for v in values(storage[:equations]) if v isa HIPConservationLawStorage]
+    length(found) == 1 || error("JutulHIP: expected exactly one TPFA conservation law on the device, found $(length(found)) " *
+                                "among $(length(values(storage[:equations]))) equations")
+    length(values(storage[:equations])) == 1 || error("JutulHIP: models mixing the device conservation law with host equations are not supported")
+    return found[1]
+end
+
+function setup_linearized_system!(storage, model::HIPModel)
+    eq_s = hip_equation_storage(storage)
     n = eq_s.nc * eq_s.N
-    lsys = HIPLinearizedSystem(eq_s, zeros(n), zeros(n))
+    lsys = HIPLinearizedSystem(eq_s, eq_s.jac, nothing, zeros(n), zeros(n), matrix_layout(model.context))
     storage[:LinearizedSystem] = lsys
     return lsys
 end
 Jutul.align_equations_to_linearized_system!(storage, model::HIPModel; kwarg...) = nothing
 # update_linearized_system! hands `nzval = lsys.jac_buffer` and a residual view to every equation (models.jl:774-783): there
 # are no host buffers to fill on this path
-Jutul.update_linearized_system!(lsys::HIPLinearizedSystem, equations, eqs_storage, eqs_views, model::HIPModel; kwarg...) =
+function Jutul.update_linearized_system!(lsys::HIPLinearizedSystem, equations, eqs_storage, eqs_views, model::HIPModel; kwarg...)
     for key in keys(equations)
         update_linearized_system_equation!(nothing, nothing, model, equations[key], eqs_storage[key])
     end
+end
 
 # pattern / alignment: the library owns the device pattern; the host tables are available bit-exact if Jutul needs
 # them (conservation.jl:486-505, :143-216)
@@ -184,21 +251,34 @@ align_to_jacobian!(s::HIPConservationLawStorage, eq::ConservationLaw, jac, model
 
 # ---- assembly (seams: update_equation!, conservation.jl:572; update_linearized_system_equation!, :298) ---------------
 function update_equation!(s::HIPConservationLawStorage, law::ConservationLaw, storage, model, dt)
-    # state_pair (conservation.jl:549-555): the accumulation needs state AND state0
-    @jh :jh_law_set_state (Handle, Ptr{Float64}) s.law pack_primary!(s.X, model, storage.state)
-    @jh :jh_law_set_state0 (Handle, Ptr{Float64}) s.law pack_primary!(s.X, model, storage.state0)
-    fill!(s.sources, 0.0)                  # reset_sources! (conservation.jl:660-664)
+    # state_pair (conservation.jl:549-555): the accumulation needs state AND state0.  Both live on the device; they are
+    # uploaded only when the host has written them since (first iteration, restarts, user edits)
+    if !s.device_state_valid
+        @jh :jh_law_set_state (Handle, Ptr{Float64}) s.law pack_primary!(s.X, model, storage.state)
+        s.device_state_valid = true
+        s.host_state_stale = false
+    end
+    if !s.device_state0_valid
+        @jh :jh_law_set_state0 (Handle, Ptr{Float64}) s.law pack_primary!(s.X, model, storage.state0)
+        s.device_state0_valid = true
+        s.host_state0_stale = false
+    end
+    reset!(s.sources)                      # reset_sources! (conservation.jl:660-664)
     s.dt = dt
     return nothing  # the flux + fill are fused into one kernel launched by update_linearized_system_equation!
 end
 
 # apply_forces! (models.jl:889-901) adds every force to `get_diagonal_entries(eq, eq_s)`, e.g. `d[c] += f.value` for a
-# PoissonSource (variable_poisson.jl:78-84).  Here that array is a host accumulator; it reaches the device with the assembly.
-get_diagonal_entries(eq::ConservationLaw, s::HIPConservationLawStorage) = s.N == 1 ? vec(s.sources) : s.sources
+# PoissonSource (variable_poisson.jl:78-84).  Here that array is a sparse host accumulator; it reaches the device with the
+# assembly, and only when it differs from the list the device already holds.
+get_diagonal_entries(eq::ConservationLaw, s::HIPConservationLawStorage) = s.sources
 
 function update_linearized_system_equation!(nz, r, model, law::ConservationLaw, s::HIPConservationLawStorage)
-    cells = Int64[c for c in 1:s.nc if any(!iszero, view(s.sources, :, c))]
-    @jh :jh_law_set_sources (Handle, Int64, Ptr{Int64}, Ptr{Float64}) s.law length(cells) cells s.sources[:, cells]
+    a = s.sources
+    if a.cells != s.src_cells || a.vals != s.src_vals
+        @jh :jh_law_set_sources (Handle, Int64, Ptr{Int64}, Ptr{Float64}) s.law length(a.cells) a.cells a.vals
+        s.src_cells = copy(a.cells); s.src_vals = copy(a.vals)
+    end
     @jh :jh_assemble (Handle, Float64, Handle, Handle) s.law s.dt s.jac s.r
     # host copies only if the caller insists on host buffers (parity / debugging); the solve reads device memory
     if !isnothing(nz)
@@ -207,6 +287,52 @@ function update_linearized_system_equation!(nz, r, model, law::ConservationLaw, 
     if !isnothing(r)
         @jh :jh_vec_download (Handle, Ptr{Float64}) s.r r
     end
+end
+
+# ---- host <-> device state hand-over ----------------------------------------------------------------------------------------
+# every host-side writer of the primary variables invalidates the device copy; the next update_equation! uploads it again
+function invalidate_device_state!(storage; state = true, state0 = true)
+    s = storage.LinearizedSystem.eq_s
+    state && (s.device_state_valid = false)
+    state0 && (s.device_state0_valid = false)
+    return storage
+end
+function reset_variables!(storage, model::HIPModel, new_vars; type = :state)      # models.jl:1079-1081 (simulator.jl:664-669)
+    invoke(reset_variables!, Tuple{Any, Jutul.JutulModel, Any}, storage, model, new_vars; type = type)
+    invalidate_device_state!(storage, state = type == :state, state0 = type == :state0)
+end
+function reset_previous_state!(storage, model::HIPModel, state0)                  # models.jl:1075-1077
+    invoke(reset_previous_state!, Tuple{Any, Jutul.JutulModel, Any}, storage, model, state0)
+    invalidate_device_state!(storage, state = false, state0 = true)
+end
+# device -> storage.state / storage.state0 (values only, partials kept): before any host code reads the primary variables
+function sync_host_state!(storage, model::HIPModel)
+    s = storage.LinearizedSystem.eq_s
+    if s.host_state_stale
+        @jh :jh_law_get_state (Handle, Ptr{Float64}) s.law s.X
+        unpack_primary!(storage.state, model, s.X)
+        s.host_state_stale = false
+    end
+    return storage
+end
+# get_output_state (models.jl:1048-1058) copies storage.state0[k] after a converged step (state0 == state there): the ONE regular
+# device -> host transfer of the state, once per report step.  state0 holds plain Float64 arrays ("state without AD"), so each
+# variable is DMA-ed straight into Jutul's own array (page-locked on first use); the Dual-valued storage.state stays stale
+# until host code asks for it (sync_host_state!).
+function get_output_state(storage, model::HIPModel)
+    s = storage.LinearizedSystem.eq_s
+    if s.host_state0_stale
+        for (i, k) in enumerate(keys(Jutul.get_primary_variables(model)))
+            v0 = storage.state0[k]::Array{Float64}
+            if !s.registered
+                @jh :jh_host_register (Ptr{Cvoid}, Int64) pointer(v0) Int64(sizeof(v0))
+            end
+            @jh :jh_law_get_variable (Handle, Int32, Int32, Ptr{Float64}) s.law Int32(1) Int32(i - 1) v0
+        end
+        s.registered = true
+        s.host_state0_stale = false
+    end
+    return invoke(get_output_state, Tuple{Any, Jutul.JutulModel}, storage, model)
 end
 
 # ---- convergence (seam: convergence_criterion, equations.jl:619-629, called by check_convergence, models.jl:830-883) ------
@@ -293,7 +419,9 @@ function linear_solve!(sys::HIPLinearizedSystem, krylov::GenericKrylov, context:
     if bad && n > 0 && hist[n + 1] / hist[1] > 1.0
         error("Bad linear solve: final residual $(hist[n + 1]), rel. value $(hist[n + 1] / hist[1])")   # krylov.jl:161-166
     end
-    if !isnothing(dx)          # dx .= -x for everything downstream that reads the host increment (increment norms, reports)
+    # The increment stays in HBM: update_primary_variables! below applies it there and computes its norms there.  A host copy
+    # (the reference's `dx = sys.dx_buffer`, krylov.jl:79) is made only for callers that read it (hip_download_increment).
+    if !isnothing(dx) && hip_download_increment(model)
         @jh :jh_vec_download (Handle, Ptr{Float64}) s.dx dx
     end
     return linear_solve_return(solved, n, (residuals = hist[1:n + 1], solved = solved); prepare = t_prec)
@@ -302,17 +430,18 @@ end
 # ---- primary update (seam: update_primary_variables!, models.jl:928-953; choose_increment chain, variables/utils.jl:110-174)
 function update_primary_variables!(storage, model::HIPModel; relaxation = 1.0, check = false, kwarg...)
     s = storage.LinearizedSystem.eq_s
-    dxh = reshape(storage.LinearizedSystem.dx_buffer, s.N, s.nc)
-    if check && !all(isfinite, dxh)
+    norms = zeros(2 * s.N)         # increment_norm (models.jl:955-965) of every primary variable, reduced on the device
+    @jh :jh_increment_norm (Handle, Handle, Int64, Ptr{Float64}) s.law s.dx Int64(s.n_owned) norms
+    if check && !all(isfinite, norms)                      # check_increment: NaN / Inf propagate into the sums
         error("Primary variables recieved invalid updates.")
     end
     lim = hip_update_limits(model)
     @jh :jh_update_primary (Handle, Handle, Float64, Ptr{Float64}) s.law s.dx Float64(relaxation) (isnothing(lim) ? C_NULL : lim)
-    @jh :jh_law_get_state (Handle, Ptr{Float64}) s.law s.X
-    unpack_primary!(storage.state, model, s.X)
-    report = Dict{Symbol, Any}()   # increment_norm (models.jl:955-965)
-    for (i, k) in enumerate(keys(Jutul.get_primary_variables(model)))
-        report[k] = (sum = sum(abs, view(dxh, i, :)), max = maximum(abs, view(dxh, i, :)))
+    s.host_state_stale = true      # storage.state is refreshed on demand (sync_host_state!, get_output_state)
+    report = Dict{Symbol, Any}()
+    for (i, (k, p)) in enumerate(pairs(Jutul.get_primary_variables(model)))
+        scale = something(Jutul.variable_scale(p), 1.0)
+        report[k] = (sum = scale * norms[2i - 1], max = scale * norms[2i])
     end
     return report
 end
@@ -320,14 +449,28 @@ end
 # ---- end of a step (seams: update_after_step!, models.jl:983-1011; reset_state_to_previous_state!, :1068-1073) ----------
 function update_after_step!(storage, model::HIPModel, dt, forces; kwarg...)
     s = storage.LinearizedSystem.eq_s
+    rep4 = zeros(4 * s.N)          # variable_change_report (models.jl:1023-1038) before state0 <- state
+    @jh :jh_law_change_report (Handle, Int64, Ptr{Float64}) s.law Int64(s.n_owned) rep4
     @jh :jh_law_update_state0 (Handle,) s.law
-    rep = invoke(update_after_step!, Tuple{Any, Jutul.JutulModel, Any, Any}, storage, model, dt, forces; kwarg...)  # host state0 <- state
-    return rep
+    s.host_state0_stale = true
+    report = Jutul.OrderedDict{Symbol, Any}()
+    for (i, k) in enumerate(keys(Jutul.get_primary_variables(model)))
+        o = 4 * (i - 1)
+        report[k] = (dx = (sum = rep4[o + 1], max = rep4[o + 2]), x = (sum = rep4[o + 3], max = rep4[o + 4]), n = s.n_owned)
+    end
+    # the host copies follow at the next sync (get_output_state): state0 == state on both sides after a converged step
+    return report
 end
 function reset_state_to_previous_state!(storage, model::HIPModel)
     s = storage.LinearizedSystem.eq_s
-    @jh :jh_law_reset_state (Handle,) s.law
-    invoke(reset_state_to_previous_state!, Tuple{Any, Jutul.JutulModel}, storage, model)
+    if s.device_state0_valid
+        @jh :jh_law_reset_state (Handle,) s.law        # state <- state0 on the device (time-step cut)
+        s.device_state_valid = true
+        s.host_state_stale = true
+    else                                               # state0 was edited on the host and not uploaded yet: host path, upload later
+        invoke(reset_state_to_previous_state!, Tuple{Any, Jutul.JutulModel}, storage, model)
+        s.device_state_valid = false
+    end
 end
 
 # ---- distributed (seams: the PArraySimulator hooks, src/ext/partitionedarrays_ext.jl:3-33; ext/JutulPartitionedArraysExt) -------

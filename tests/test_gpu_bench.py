@@ -124,3 +124,19 @@ def test_bench_rccl_fallback_paths_two_devices():
     for d in (fast, slow):
         assert d["config"]["rccl_ranks"] == 2 and d["config"]["comm_timeouts"] == 0
         assert abs(d["config"]["state_norm"] - one["config"]["state_norm"]) <= 1e-5 * one["config"]["state_norm"]
+
+
+def test_bench_seam_path_matches_fused_path():
+    """--path seams: the per-Newton entry-point sequence of julia/JutulHIP.jl (through jutul.jl_amd/julia_mirror.py) reaches the
+    same state as the fused jh_newton_step path, reports the state downloads it made, and both law kinds run."""
+    base = [sys.executable, "bench.py", "--cells", "200000", "--steps", "4", "--warmup", "1", "--no-cpu"]
+    fused = run(base)
+    seams = run(base + ["--path", "seams"])
+    check(seams, 4, 1)
+    c = seams["config"]
+    assert c["path"] == "seams" and fused["config"]["path"] == "fused" and fused["config"]["seams"] is None
+    assert c["seams"]["output_states_downloaded"] == 4 and c["seams"]["value_without_output"] > 0
+    assert abs(c["state_norm"] - fused["config"]["state_norm"]) <= 1e-9 * fused["config"]["state_norm"]
+    assert c["linear_iterations_first_steps"] == fused["config"]["linear_iterations_first_steps"]
+    two = run(base + ["--path", "seams", "--law", "twophase", "--report-every", "2"])
+    assert two["config"]["seams"]["output_states_downloaded"] == 2 and two["config"]["block_n"] == 2

@@ -178,3 +178,91 @@ def test_1M_cells_eight_ranks_match_single_rank(ja):
         X[sub["cells"][: sub["n_owned"]] - 1] = Xl[: sub["n_owned"]]
         assert np.allclose(Xl[sub["n_owned"]:], X_ref[sub["cells"][sub["n_owned"]:] - 1], rtol=1e-7, atol=1e-9)
     assert np.abs(X - X_ref).max() <= 1e-7 * np.abs(X_ref).max()
+
+
+def test_3M_cells_oracle_parity_where_the_defaults_switch(ja, oracle):
+    """Oracle parity at a size where the library's defaults change code path: >= 3M rows -> 16-bit column codes in the jagged
+    SpMV (no environment override), >= 2M cells -> 512-row bisection blocks, ~100 tiles per XCD chunk.  Assembly, jh_spmv,
+    jh_spmv_jagged and one block-Jacobi ILU(0) factor + apply on the device blocks, each against the C oracle with a PER-ENTRY
+    bound |a - b| <= c * eps * sum |terms| (not scaled by the largest entry of the array): with a 400x transmissibility
+    contrast the smallest entries are pinned as tightly as the largest."""
+    import os
+    import scipy.sparse as sp
+    from bench import dims_for_cells
+    assert "JH_SPMV_COL" not in os.environ and "JH_SPMV_NO_JAGGED" not in os.environ
+    eps = np.finfo(np.float64).eps
+    ctx = ja.HIPContext(0)
+    g = ja.tet_lattice_mesh(*dims_for_cells(3_200_000))
+    nc, nf, N = g["nc"], g["nf"], g["N"]
+    assert nc >= 3_000_000
+    rng = np.random.default_rng(11)
+    T = g["T"] / g["T"].mean() * np.exp(rng.uniform(-3.0, 3.0, nf))      # 400x contrast between neighbouring faces
+    vol = g["volumes"]
+    U, U0 = 1.0 + rng.random(nc), 1.0 + rng.random(nc)
+    dt = 0.8
+    src_c, src_v = np.array([7, nc - 5]), np.array([0.75, -0.25])
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, reorder="blocks")     # library defaults: 512-row bisection blocks
+    perm, bp = disc.ordering()
+    assert 400 < nc / (len(bp) - 1) <= 576 and np.diff(bp).max() <= 576
+    law = ja.ConservationLaw(disc, "poisson")
+    law.set_face_trans(T)
+    law.set_volumes(vol)
+    law.set_state(U)
+    law.set_state0(U0)
+    law.set_sources(src_c, src_v)
+    lsys = ja.LinearizedSystem(disc)
+    law.update_equation_and_linearized_system(dt, lsys.jac, lsys.r)
+    info = lsys.jac.spmv_info()
+    assert info["jagged"] and info["col16"] and info["longest_row"] == 5, info
+    # ---- assembly: r_i = sum_f T_f (u_i - u_j) + vol_i (u_i - u0_i) / dt - src_i ; J_ii = sum_f T_f + vol_i / dt ; J_ij = -T_f
+    osys = oracle.TPFASystem(N, nc)
+    olaw = oracle.Law("poisson", dt)
+    nz_o, r_o = osys.assemble(olaw, U, U0, vol, T, src_cells=src_c, src_values=src_v)
+    rp, ci = osys.rowptr - 1, osys.colidx - 1
+    A = sp.csr_matrix((nz_o, ci, rp), shape=(nc, nc))
+    Aabs = abs(A)
+    src_abs = np.zeros(nc)
+    src_abs[src_c - 1] = np.abs(src_v)
+    Toff = Aabs - sp.diags(Aabs.diagonal())                         # |T_f| on the off-diagonal
+    term_r = Toff @ np.abs(U) + np.asarray(Toff.sum(axis=1)).ravel() * np.abs(U) + vol * (np.abs(U) + np.abs(U0)) / dt + src_abs
+    r = lsys.r.download()
+    assert np.all(np.abs(r - r_o) <= 8 * eps * term_r), float((np.abs(r - r_o) / term_r).max() / eps)
+    nz = lsys.jac.nzval
+    assert np.all(np.abs(nz - nz_o) <= 8 * eps * np.abs(nz_o)), float((np.abs(nz - nz_o) / np.abs(nz_o)).max() / eps)
+    assert np.abs(nz_o).min() < 1e-3 * np.abs(nz_o).max()           # the contrast is really there
+    # ---- SpMV: CSR tile kernel and the jagged kernel with its default 16-bit codes; bound (row length + 1) * eps * (|A| |x|)_i
+    x = rng.standard_normal(nc)
+    y_o = oracle.spmv(nc, 1, osys.rowptr, osys.colidx, nz_o, x)
+    bound = 6 * eps * (Aabs @ np.abs(x))
+    lsys.jac.nzval = nz_o                                           # the same matrix bits on both sides
+    dxv = ja.DeviceVector(disc, x)
+    y_csr = ja.mul_(ja.DeviceVector(disc), lsys.jac, dxv).download()
+    y_jag = ja.mul_(ja.DeviceVector(disc), lsys.jac, dxv, jagged=True).download()
+    assert np.all(np.abs(y_csr - y_o) <= bound) and np.all(np.abs(y_jag - y_o) <= bound)
+    assert np.array_equal(y_csr, y_jag)                             # same accumulation order -> same bits
+    # ---- block-Jacobi ILU(0) over the 512-row device blocks: componentwise backward error against the ORACLE's factors
+    F = ja.ILUZeroPreconditioner(partition="blocks").update_preconditioner(lsys.jac)
+    fi = F.info()
+    assert fi["nblocks"] == len(bp) - 1 and fi["jagged"]
+    p0 = perm - 1
+    part = np.zeros(nc, dtype=np.int64)
+    part[p0] = np.repeat(np.arange(1, len(bp)), np.diff(bp))
+    Ap = A[p0][:, p0].tocsr()                                       # the device's elimination order (see the small-size test)
+    Ap.sort_indices()
+    Fo = oracle.ILU0(nc, 1, Ap.indptr + 1, Ap.indices + 1, Ap.data, partition=part[p0])
+    lu = Fo.export(Ap.data.size)                                    # L multipliers | inv(U_ii) | U, zero outside the blocks
+    rows = np.repeat(np.arange(nc), np.diff(Ap.indptr))
+    lower, upper, dia = Ap.indices < rows, Ap.indices > rows, Ap.indices == rows
+    Lm = sp.csr_matrix((lu[lower], (rows[lower], Ap.indices[lower])), shape=(nc, nc)) + sp.identity(nc, format="csr")
+    Um = sp.csr_matrix((lu[upper], (rows[upper], Ap.indices[upper])), shape=(nc, nc)) + sp.diags(1.0 / lu[dia])
+    b = rng.standard_normal(nc)
+    xh = F.apply(lsys.jac.new_vector(), lsys.jac.new_vector(b)).download()[p0]
+    bp_ = b[p0]
+    resid = np.abs(Lm @ (Um @ xh) - bp_)
+    scale = abs(Lm) @ (abs(Um) @ np.abs(xh)) + np.abs(bp_)
+    nlev = fi["max_levels"]
+    assert np.all(resid <= 4 * nlev * eps * scale), float((resid / scale).max() / eps)
+    x_o = Fo.apply(bp_)
+    assert np.abs(xh - x_o).max() <= 1e-10 * np.abs(x_o).max()
+    kept = int(lower.sum() - (lu[lower] == 0).sum()), int(upper.sum() - (lu[upper] == 0).sum())
+    assert (fi["l_entries"], fi["u_entries"]) == kept, (fi, kept)

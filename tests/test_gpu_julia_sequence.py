@@ -1,9 +1,10 @@
 """The Julia binding (jutul.jl_amd/julia/JutulHIP.jl) cannot run in the build image (no Julia).  This test keeps it honest:
-it parses the `@jh :entry_point` calls of every function of the .jl file and then performs ONE perform_step! (simulator.jl:392-455)
-through ctypes with a Python mirror of those functions -- asserting that each mirror issues exactly the entry points its Julia
-twin lists, in the same order (branches the default path does not take are named explicitly) -- and compares the Newton update
-with the oracle's.  If the .jl file and the mirror diverge, or a seam is not wired (data upload, state0, forces, convergence,
-primary update, dx download), this fails."""
+it parses the `@jh :entry_point` calls of every function of the .jl file and then drives several perform_step!s
+(simulator.jl:392-455) through its Python twin (jutul.jl_amd/julia_mirror.py; the object bench.py --path seams times) --
+asserting that every invocation issues exactly the entry points its Julia twin lists, in the same order (branches the
+sequence does not take are named explicitly), that the state stays resident on the device (one upload, no per-iteration
+copies), and that the Newton updates equal the oracle's.  If the .jl file and the mirror diverge, or a seam is not wired,
+this fails."""
 import contextlib
 import ctypes as C
 import os
@@ -36,10 +37,10 @@ def parse_julia_calls():
 
 
 class Recorder:
-    """Stands in for the loaded library: logs (current Julia function, entry point) for every call."""
+    """Stands in for the loaded library: logs (Julia function, invocation number, entry point) for every call."""
 
     def __init__(self, lib):
-        self._lib, self.log, self.ctx = lib, [], None
+        self._lib, self.log, self.ctx, self.inv, self._n = lib, [], None, 0, 0
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
@@ -47,17 +48,27 @@ class Recorder:
             return fn
 
         def wrapped(*a):
-            self.log.append((self.ctx, name))
+            self.log.append((self.ctx, self.inv, name))
             return fn(*a)
         return wrapped
 
     @contextlib.contextmanager
     def julia(self, fname):
-        prev, self.ctx = self.ctx, fname
+        prev = (self.ctx, self.inv)
+        self._n += 1
+        self.ctx, self.inv = fname, self._n
         try:
             yield
         finally:
-            self.ctx = prev
+            self.ctx, self.inv = prev
+
+    def calls(self, fname):
+        """entry points of every invocation of one Julia function, in order: [[...], [...], ...]"""
+        out = {}
+        for fn, inv, name in self.log:
+            if fn == fname:
+                out.setdefault(inv, []).append(name)
+        return [out[k] for k in sorted(out)]
 
 
 def is_subsequence(sub, full):
@@ -65,26 +76,33 @@ def is_subsequence(sub, full):
     return all(any(x == y for y in it) for x in sub)
 
 
-# entry points of a Julia function that the DEFAULT perform_step! does not reach (named so that nothing is skipped silently)
-NOT_ON_DEFAULT_PATH = {
+# entry points of a Julia function that this test's perform_step! sequence does not reach (named so that nothing is skipped silently)
+NOT_REACHED = {
     "setup_equation_storage": {"jh_law_create_custom"},                 # physics as device source (generic-AD path)
     "update_linearized_system_equation!": {"jh_csr_get_values", "jh_vec_download"},  # host copies for callers that insist
-    "linear_solve!": {"jh_scale_system", "jh_vec_dot", "jh_gmres"},     # :diagonal/:dt scaling, relaxed tolerance, GMRES
+    "linear_solve!": {"jh_scale_system", "jh_vec_dot", "jh_gmres", "jh_vec_download"},  # scaling, relaxed tolerance, GMRES, hip_download_increment
 }
+STEP_FUNCTIONS = ("setup_equation_storage", "update_equation!", "update_linearized_system_equation!", "convergence_criterion",
+                  "update_preconditioner!", "linear_solve!", "update_primary_variables!", "update_after_step!",
+                  "reset_state_to_previous_state!", "sync_host_state!", "get_output_state")
 
 
 @pytest.mark.gpu
-def test_julia_binding_sequence_for_one_newton_step(oracle):
+def test_julia_binding_sequence_device_resident_state(oracle):
+    """Three Newton iterations over two time steps + a time-step cut + a host-side edit of the state, through the Python twin of
+    JutulHIP.jl (jutul.jl_amd/julia_mirror.py, the same object bench.py --path seams times): every invocation issues what its
+    Julia function lists, the state is uploaded ONCE, nothing but scalars comes back per iteration, and the trajectory equals
+    the oracle's."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
     import jutul_amd as ja
     from jutul_amd import _lib
-    from jutul_amd._lib import check, f64, i64, pf, pi
+    from jutul_amd.julia_mirror import JuliaMirror
     jl = parse_julia_calls()
-    for f in ("setup_equation_storage", "update_equation!", "update_linearized_system_equation!", "convergence_criterion",
-              "update_preconditioner!", "linear_solve!", "update_primary_variables!", "update_after_step!",
-              "reset_state_to_previous_state!", "setup_distributed!", "set_halo!", "post_update_linearized_system!"):
+    for f in STEP_FUNCTIONS + ("setup_distributed!", "set_halo!", "post_update_linearized_system!"):
         assert jl.get(f), f"JutulHIP.jl no longer defines {f} with @jh calls"
-    L = Recorder(_lib.load())
-    H = C.c_void_p
+    rec = Recorder(_lib.load())
+    m = JuliaMirror(rec)
 
     # ---- problem: compressible single-phase law with gravity, sources on two cells ---------------------------------------------
     g = ja.tet_lattice_mesh(7, 6, 5)
@@ -93,113 +111,102 @@ def test_julia_binding_sequence_for_one_newton_step(oracle):
     T = g["T"] / g["T"].mean()
     vol = g["volumes"]
     gdz = 0.01 * rng.standard_normal(nf)
-    par = f64([1.0, 1.0, 1e-2, 1e-2, 1.0, 1.0, 1.0])
-    state0 = 1.0 + 0.1 * rng.random(nc)
-    state = state0 + 0.01 * rng.standard_normal(nc)
+    par = [1.0, 1.0, 1e-2, 1e-2, 1.0, 1.0, 1.0]
+    state0 = 1.0 + 0.1 * rng.random(nc)           # storage.state0 (host)
+    state = state0 + 0.01 * rng.standard_normal(nc)  # storage.state (host)
     dt, tol = 0.7, 1e-3
-    forces = {3: 0.5, nc - 2: -0.5}                     # cell -> value, what apply_forces_to_equation! adds (d[c] += f.value)
-
+    forces = {3: 0.5, nc - 2: -0.5}               # cell -> value, what apply_forces_to_equation! adds (d[c] += f.value)
     ctx = ja.HIPContext(0)
-    # -- setup_equation_storage (conservation.jl:137)
-    with L.julia("setup_equation_storage"):
-        disc, law, jac, r, dx = H(), H(), H(), H(), H()
-        Nf = i64(np.asfortranarray(N).T.reshape(-1))
-        check(L.jh_tpfa_create(ctx.h, nc, nf, pi(Nf), 1, 1, None, 0, 0, C.byref(disc)))
-        check(L.jh_law_create(disc, 1, pf(par), C.byref(law)))
-        check(L.jh_law_set_data(law, 0, pf(f64(T))))
-        check(L.jh_law_set_data(law, 1, pf(f64(gdz))))
-        check(L.jh_law_set_data(law, 2, pf(f64(vol))))
-        check(L.jh_csr_create(disc, C.byref(jac)))
-        check(L.jh_vec_create(disc, C.byref(r)))
-        check(L.jh_vec_create(disc, C.byref(dx)))
-    sources = np.zeros(nc)                              # HIPConservationLawStorage.sources
-    # -- update_equation! (conservation.jl:572)
-    with L.julia("update_equation!"):
-        check(L.jh_law_set_state(law, pf(f64(state))))
-        check(L.jh_law_set_state0(law, pf(f64(state0))))
-        sources[:] = 0.0
-    # -- apply_forces! (models.jl:889-901): d = get_diagonal_entries(eq, eq_s); d[c] += f.value  (host accumulator, no ccall)
-    for c, v in forces.items():
-        sources[c - 1] += v
-    # -- update_linearized_system_equation! (conservation.jl:298)
-    with L.julia("update_linearized_system_equation!"):
-        cells = i64(np.flatnonzero(sources) + 1)
-        check(L.jh_law_set_sources(law, cells.size, pi(cells), pf(f64(sources[cells - 1]))))
-        check(L.jh_assemble(law, dt, jac, r))
-    # -- check_convergence -> convergence_criterion (equations.jl:619-629)
-    with L.julia("convergence_criterion"):
-        err = np.zeros(1)
-        check(L.jh_convergence(law, r, nc, pf(err)))
-    converged = bool(err[0] < tol)
-    # -- linear_solve! (krylov.jl:71-182), default GenericKrylov(:bicgstab, preconditioner = HIPILUZero())
-    ilu, ks = H(), H()
-    with L.julia("linear_solve!"):
-        with L.julia("update_preconditioner!"):
-            check(L.jh_ilu0_create(jac, None, -1, C.byref(ilu)))
-            check(L.jh_ilu0_factor(ilu))
-        check(L.jh_krylov_create(jac, C.byref(ks)))
-        check(L.jh_krylov_set_min_iterations(ks, 1))
-        iters, status = C.c_int64(), C.c_int32()
-        hist = np.zeros(302)
-        check(L.jh_bicgstab(ks, ilu, 2, r, dx, 1e-12, 1e-14, 300, C.byref(iters), C.byref(status), pf(hist), hist.size))
-        check(L.jh_vec_negate_into(dx, dx))
-        dx_buffer = np.zeros(nc)
-        check(L.jh_vec_download(dx, pf(dx_buffer)))
-    assert status.value == 0
-    # -- update_primary_variables! (models.jl:928-953)
-    with L.julia("update_primary_variables!"):
-        check(L.jh_update_primary(law, dx, 1.0, None))
-        X = np.zeros(nc)
-        check(L.jh_law_get_state(law, pf(X)))
-    # -- update_after_step! (models.jl:983-1011)
-    with L.julia("update_after_step!"):
-        check(L.jh_law_update_state0(law))
+    s = m.setup_equation_storage(ctx, N, nc, ne=1, law_kind=1, params=par, face_trans=T, face_gdz=gdz, cell_volumes=vol)
+    krylov = dict(preconditioner={}, storage=None, solver="bicgstab")
 
-    # ---- 1. the mirror issued what the Julia functions list, in order ------------------------------------------------------------
-    by_fn = {}
-    for fn, name in L.log:
-        by_fn.setdefault(fn, []).append(name)
-    for fn, called in by_fn.items():
+    osys = oracle.TPFASystem(N, nc)
+    olaw = oracle.Law("compressible", dt, rho0=(1.0, 1.0), comp=(1e-2, 1e-2), mu=(1.0, 1.0), p_ref=1.0)
+    fc = np.array(sorted(forces))
+    fv = [forces[int(c)] for c in fc]
+
+    def oracle_newton(x, x0):
+        nz_o, r_o = osys.assemble(olaw, x, x0, vol, T, gdz=gdz, src_cells=fc, src_values=fv)
+        J = sp.csr_matrix((nz_o, osys.colidx - 1, osys.rowptr - 1), shape=(nc, nc))
+        return nz_o, r_o, x - spl.spsolve(J.tocsc(), r_o)
+
+    def perform_step(check_parity=None):
+        m.update_equation(s, state, state0, dt)                   # update_state_dependents! -> update_equation!
+        d = m.get_diagonal_entries(s)                             # apply_forces! (models.jl:889-901)
+        for c, v in forces.items():
+            d.add(c, v)
+        nz = np.zeros(osys.nnzb) if check_parity else None
+        r = np.zeros(nc) if check_parity else None
+        m.update_linearized_system_equation(s, nz, r)             # update_linearized_system!
+        err = m.convergence_criterion(s)                          # check_convergence
+        ok, its, hist = m.linear_solve(s, krylov, rtol=1e-12, atol=1e-14, max_iterations=300)   # solve_and_update!
+        assert ok
+        norms = m.update_primary_variables(s, check_increment=True)
+        return err, norms, nz, r
+
+    # ---- time step 1, Newton iteration 1 and 2 -----------------------------------------------------------------------------------
+    x_ref, x0_ref = state.copy(), state0.copy()
+    nz_o, r_o, x1 = oracle_newton(x_ref, x0_ref)
+    err, norms, nz, r = perform_step(check_parity=True)
+    assert np.allclose(r, r_o, rtol=1e-12, atol=1e-13) and np.allclose(nz, nz_o, rtol=1e-12, atol=1e-14)
+    assert abs(err[0] - np.abs(r_o).max()) <= 1e-12 * np.abs(r_o).max() and err[0] > tol
+    dx_ref = x1 - x_ref
+    assert abs(norms[0]["sum"] - np.abs(dx_ref).sum()) <= 1e-6 * np.abs(dx_ref).sum()      # increment_norm (models.jl:955-965)
+    assert abs(norms[0]["max"] - np.abs(dx_ref).max()) <= 1e-6 * np.abs(dx_ref).max()
+    _, _, x2 = oracle_newton(x1, x0_ref)
+    perform_step()
+    # the host arrays were never refreshed: the device copy is the state
+    assert s.host_state_stale and np.array_equal(state, x_ref)
+    rep = m.update_after_step(s)                                                              # end of the ministep
+    assert abs(rep[0]["dx"]["max"] - np.abs(x2 - x0_ref).max()) <= 1e-6 * np.abs(x2 - x0_ref).max()    # variable_change_report
+    assert abs(rep[0]["x"]["sum"] - np.abs(x2).sum()) <= 1e-9 * np.abs(x2).sum()
+    out = m.get_output_state(s, [state0])                                                     # report step: the one download,
+    assert np.allclose(out[0], x2, rtol=1e-7, atol=1e-9) and np.array_equal(out[0], state0)   # straight into storage.state0[k]
+    assert s.host_state_stale and np.array_equal(state, x_ref)    # the Dual-valued storage.state is refreshed on demand only
+    m.sync_host_state(s, state)
+    assert np.array_equal(state, state0)
+
+    # ---- time step 2: one iteration, then a time-step cut (reset_state_to_previous_state!) -----------------------------------
+    _, _, x3 = oracle_newton(x2, x2)
+    perform_step()
+    m.reset_state_to_previous_state(s, state, state0)
+    m.sync_host_state(s, state)
+    assert np.allclose(state, x2, rtol=1e-7, atol=1e-9)          # back at the start of the step, on the device and on the host
+    perform_step()
+    m.sync_host_state(s, state)
+    assert np.allclose(state, x3, rtol=1e-6, atol=1e-8)
+    # ---- a host-side writer (reset_variables!) invalidates the device copy: next update_equation! uploads again --------------
+    state[:] = x_ref
+    state0[:] = x0_ref
+    m.invalidate_device_state(s)
+    perform_step()
+    m.sync_host_state(s, state)
+    assert np.allclose(state, x1, rtol=1e-6, atol=1e-8)
+
+    # ---- 1. every invocation issued what its Julia function lists, in order ---------------------------------------------------
+    seen = set()
+    for fn in {f for f, _, _ in rec.log}:
         listed = jl[fn]
-        assert is_subsequence(called, listed), (fn, called, listed)
-        missing = set(listed) - set(called)
-        assert missing <= NOT_ON_DEFAULT_PATH.get(fn, set()), f"{fn}: JutulHIP.jl also calls {sorted(missing)}; the mirror does not"
-    assert set(by_fn) == {"setup_equation_storage", "update_equation!", "update_linearized_system_equation!", "convergence_criterion",
-                          "update_preconditioner!", "linear_solve!", "update_primary_variables!", "update_after_step!"}
-    # every entry point the .jl file names exists in the library with the header's name
+        for called in rec.calls(fn):
+            assert is_subsequence(called, listed), (fn, called, listed)
+            seen |= set(called)
+    for fn in STEP_FUNCTIONS:
+        reached = {n for c in rec.calls(fn) for n in c}
+        assert reached, f"the sequence never entered {fn}"
+        missing = set(jl[fn]) - reached
+        assert missing <= NOT_REACHED.get(fn, set()), f"{fn}: JutulHIP.jl also calls {sorted(missing)}; the mirror does not"
     lib = _lib.load()
     for fn, names in jl.items():
         for nm in names:
             assert hasattr(lib, nm), (fn, nm)
-
-    # ---- 2. the step equals the oracle's Newton step --------------------------------------------------------------------------------
-    osys = oracle.TPFASystem(N, nc)
-    olaw = oracle.Law("compressible", dt, rho0=(1.0, 1.0), comp=(1e-2, 1e-2), mu=(1.0, 1.0), p_ref=1.0)
-    fc = np.array(sorted(forces))
-    nz_o, r_o = osys.assemble(olaw, state, state0, vol, T, gdz=gdz, src_cells=fc, src_values=[forces[int(c)] for c in fc])
-    # read the device Jacobian / residual back for the comparison
-    nzv = np.zeros(osys.nnzb)
-    check(lib.jh_csr_get_values(jac, pf(nzv)))
-    rv = np.zeros(nc)
-    check(lib.jh_vec_download(r, pf(rv)))
-    assert np.allclose(rv, r_o, rtol=1e-12, atol=1e-13)
-    assert np.allclose(nzv, nz_o, rtol=1e-12, atol=1e-14)
-    assert abs(err[0] - np.abs(r_o).max()) <= 1e-12 * np.abs(r_o).max() and not converged
-    import scipy.sparse as sp
-    import scipy.sparse.linalg as spl
-    J = sp.csr_matrix((nz_o, osys.colidx - 1, osys.rowptr - 1), shape=(nc, nc))
-    x_ref = spl.spsolve(J.tocsc(), r_o)
-    assert np.allclose(dx_buffer, -x_ref, rtol=1e-6, atol=1e-8)       # linear_solve! writes dx = -x
-    assert np.allclose(X, state - x_ref, rtol=1e-6, atol=1e-8)         # update_primary_variables!: state += dx
-    # update_after_step!: state0 <- state on the device: the next assembly sees a vanishing accumulation term
-    check(lib.jh_law_set_sources(law, 0, None, None))
-    check(lib.jh_assemble(law, dt, jac, r))
-    check(lib.jh_vec_download(r, pf(rv)))
-    _, r_flux = osys.assemble(olaw, X, X, vol, T, gdz=gdz)
-    assert np.allclose(rv, r_flux, rtol=1e-11, atol=1e-12)
-    for h, d in ((ks, "jh_krylov_destroy"), (ilu, "jh_ilu0_destroy"), (dx, "jh_vec_destroy"), (r, "jh_vec_destroy"),
-                 (jac, "jh_csr_destroy"), (law, "jh_law_destroy"), (disc, "jh_tpfa_destroy")):
-        getattr(lib, d)(h)
+    # ---- 2. residency: 6 perform_step!s, 2 state uploads (first use + after the host edit), sources uploaded once ------------
+    ue = rec.calls("update_equation!")
+    assert [len(c) for c in ue] == [2, 0, 0, 0, 2] or [len(c) for c in ue if c] == [2, 2], ue
+    assert sum("jh_law_set_sources" in c for c in rec.calls("update_linearized_system_equation!")) == 1
+    per_iteration = {n for f, _, n in rec.log if f in ("update_primary_variables!", "linear_solve!", "update_after_step!")}
+    assert not per_iteration & {"jh_vec_download", "jh_law_get_state", "jh_law_set_state", "jh_law_set_state0"}
+    m.unregister([state0])
+    m.destroy(s, krylov)
 
 
 def test_julia_binding_names_match_header():
