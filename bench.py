@@ -418,11 +418,21 @@ def main():
     kern["ilu0_factor"] = dict(ms=fac_ms, launches=len(reps), bytes=B_fac)
     # BiCGStab: 2 SpMV + 2 preconditioner applies per iteration; the event pairs sample every --profile-stride-th iteration
     n_apply = 2 * int(np.sum(lin_its))
-    if prof["spmv_count"]:
-        kern["spmv"] = dict(ms=prof["spmv_ms"] / prof["spmv_count"], launches=n_apply, timed=prof["spmv_count"], bytes=B_spmv)
-    if prof["precond_count"]:
-        kern["ilu0_apply"] = dict(ms=prof["precond_ms"] / prof["precond_count"], launches=n_apply, timed=prof["precond_count"],
-                                  bytes=B_ilu)
+    fused_product = bool(info.get("fused_product")) and world == 1 and not force_dist and fused
+    if fused_product and prof["spmv_count"] and prof["precond_count"]:
+        # The product is formed inside the preconditioner apply (jh_ilu0_apply_mul): two launches -- ilu_apply_jds_kernel<.., MUL>
+        # (sweeps + in-block product + dot partials) and ilu_eprod_kernel (out-of-block entries) -- do the work of one ILU(0)
+        # apply AND one SpMV; the pair is one line here, priced at the algorithmic bytes of both operators
+        ms_a, ms_e = prof["precond_ms"] / prof["precond_count"], prof["spmv_ms"] / prof["spmv_count"]
+        kern["ilu0_apply+spmv"] = dict(ms=ms_a + ms_e, launches=n_apply, timed=prof["precond_count"], bytes=B_ilu + B_spmv,
+                                       parts={"ilu_apply_jds_kernel<MUL>_ms": round(ms_a, 4), "ilu_eprod_kernel_ms": round(ms_e, 4),
+                                              "ilu0_apply_bytes": int(B_ilu), "spmv_bytes": int(B_spmv)})
+    else:
+        if prof["spmv_count"]:
+            kern["spmv"] = dict(ms=prof["spmv_ms"] / prof["spmv_count"], launches=n_apply, timed=prof["spmv_count"], bytes=B_spmv)
+        if prof["precond_count"]:
+            kern["ilu0_apply"] = dict(ms=prof["precond_ms"] / prof["precond_count"], launches=n_apply, timed=prof["precond_count"],
+                                      bytes=B_ilu)
     for k in kern.values():
         k["gbs"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
         k["total_ms"] = k["ms"] * k["launches"]
@@ -434,7 +444,8 @@ def main():
                     kernels={n: dict(avg_ms=round(k["ms"], 4), launches=k["launches"], timed_launches=k.get("timed", k["launches"]),
                                      algorithmic_bytes=int(k["bytes"]),
                                      gbs=round(k["gbs"], 1), frac=round(k["frac_of_peak"], 4),
-                                     share_of_step=round(k["total_ms"] / (elapsed * 1e3), 4)) for n, k in kern.items()})
+                                     share_of_step=round(k["total_ms"] / (elapsed * 1e3), 4), **({"parts": k["parts"]} if "parts" in k else {}))
+                             for n, k in kern.items()})
 
     # ---- CPU baseline: the oracle (restatement of Jutul's threaded CPU path), bounded sample, rank 0 at N = 1 ------
     cpu = None
@@ -464,7 +475,8 @@ def main():
                        "ilu_kept_fraction": round(kept / max(1, nnz_loc - n_loc), 4),  # couplings inside the block-Jacobi blocks
                        "kernels_selected": {"spmv": ("jagged-slice, 16-bit column codes" if sinfo["col16"] else "jagged-slice, 32-bit columns") if sinfo["jagged"] else "CSR tile kernel",
                                             "ilu0_apply": "chunk-jagged" if info["jagged"] else "row-major (LDS)" if info["lds_mode"] else "level-per-launch",
-                                            "ilu0_factor": info["factor_kernel"], "longest_row": sinfo["longest_row"]},
+                                            "ilu0_factor": info["factor_kernel"], "longest_row": sinfo["longest_row"],
+                                            "product": "inside the preconditioner apply (jh_ilu0_apply_mul)" if fused_product else "separate SpMV"},
                        "linear_iterations_per_step": round(float(np.mean(lin_its)), 2),
                        "linear_iterations_first_steps": its_all[:8], "state_norm": state_norm,
                        "setup_s": round(t_setup, 1), "setup_phases_s": {k: round(v, 2) for k, v in setup.items()},
@@ -563,6 +575,7 @@ def measured_traffic(kernel, args, cells, world):
     null with the reason."""
     import glob
     names = {"ilu0_apply": ["ilu_apply_jds_kernel<1, 1, 4>", "ilu_apply_jds_kernel<1, 2, 4>"],
+             "ilu0_apply+spmv": ["ilu_apply_jds_kernel<1, 1, 4, true, 3>+ilu_eprod_kernel<1, 2>", "ilu_apply_jds_kernel<1, 2, 4, true, 2>+ilu_eprod_kernel<1, 1>"],
              "spmv": ["spmv_jds16_kernel<5, 1>", "spmv_jds16_kernel<5, 2>"], "assembly": ["assemble_pipe_kernel<0>"],
              "ilu0_factor": ["ilu_factor_diag_kernel<1, 4>"]}
     if world != 1 or args.law != "poisson" or cells != 10_025_988:

@@ -221,13 +221,22 @@ int32_t jh_ilu0_destroy(jh_ilu M);
 int32_t jh_ilu0_factor(jh_ilu M);
 /* ldiv!(x, LU, b) (ilu0.jl:233-236; apply!, precond/ilu.jl:62-94) */
 int32_t jh_ilu0_apply(jh_ilu M, jh_vec b, jh_vec x);
+/* x = M^-1 b and q = A x in one call: the pair every iteration of the right-preconditioned Krylov loop evaluates twice
+ * (ldiv! then mul!, StaticCSR/ilu0.jl:156-187 + mat.jl:24-61).  With pivot-only factors on one rank (jh_ilu0_stats bit 4) the
+ * in-block part of the product is formed inside the apply kernel: the factors then hold A's own in-block entries (U = D~ + U_A,
+ * L D~ = L_A), so (A x)_i = A_ii x_i + (g_i - D~_i x_i) + sum_{k<i} L_ik D~_k x_k + sum_{k outside the block} A_ik x_k with g the
+ * forward-sweep result -- one pass over the factors instead of factors + matrix; a second, small launch adds the out-of-block
+ * entries.  Otherwise (patterns with triangles inside a block, rank-local subdomains, diagonal preconditioners) the two
+ * operators run one after the other: same result to rounding. */
+int32_t jh_ilu0_apply_mul(jh_ilu M, jh_vec b, jh_vec x, jh_vec q);
 /* factor values scattered to A's HOST pattern: L multipliers below the diagonal, inv(U_ii) on it, U above */
 int32_t jh_ilu0_get_factor(jh_ilu M, double *lu);
 int32_t jh_ilu0_info(jh_ilu M, int64_t *nblocks, int64_t *max_block_rows, int64_t *max_levels);
 /* stats4: [0] strict-lower block entries kept in L, [1] strict-upper kept in U (fixed_block, ilu0.jl:13-54),
  * [2] execution blocks, [3] kernel selection: bit 0 = LDS (block-Jacobi) kernels (0: level-per-launch kernels), bit 1 = chunk-jagged
  * layout, bit 2 = program-driven refactorisation available, bit 3 = pivot-only refactorisation in use (no elimination step
- * updates an off-diagonal entry: triangle-free block patterns) */
+ * updates an off-diagonal entry: triangle-free block patterns), bit 4 = the product A*x is fused into the apply of the Krylov loop
+ * (jh_ilu0_apply_mul) */
 int32_t jh_ilu0_stats(jh_ilu M, int64_t *stats4);
 
 /* DiagonalPreconditioner family (precond/diagonal.jl): kind 1 = JacobiPreconditioner(w) D_i = w*inv(A_ii)

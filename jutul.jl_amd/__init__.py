@@ -532,6 +532,11 @@ class ILUZeroPreconditioner(_Handle):
         check(_L().jh_ilu0_apply(self.h, y.h, x.h))
         return x
 
+    def apply_mul(self, x, q, y):
+        """x = M^-1 y and q = A x in one call (jh_ilu0_apply_mul): fused into one pass over the factors when info()['fused_product']."""
+        check(_L().jh_ilu0_apply_mul(self.h, y.h, x.h, q.h))
+        return x, q
+
     def factor_values(self):
         out = np.zeros(self.A.nnzb * self.A.bs ** 2)
         check(_L().jh_ilu0_get_factor(self.h, pf(out)))
@@ -544,7 +549,8 @@ class ILUZeroPreconditioner(_Handle):
         check(_L().jh_ilu0_stats(self.h, pi(st)))
         return dict(nblocks=a.value, max_block_rows=b.value, max_levels=c.value, l_entries=int(st[0]),
                     u_entries=int(st[1]), exec_blocks=int(st[2]), lds_mode=bool(st[3] & 1), jagged=bool(st[3] & 2),
-                    factor_kernel="pivot-only" if st[3] & 8 else ("program" if st[3] & 4 else "generic"))
+                    factor_kernel="pivot-only" if st[3] & 8 else ("program" if st[3] & 4 else "generic"),
+                    fused_product=bool(st[3] & 16))
 
 
 class _DiagonalPreconditioner(_Handle):

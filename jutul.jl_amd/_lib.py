@@ -95,6 +95,7 @@ SIGNATURES = {
     "jh_ilu0_destroy": [H],
     "jh_ilu0_factor": [H],
     "jh_ilu0_apply": [H, H, H],
+    "jh_ilu0_apply_mul": [H, H, H, H],
     "jh_ilu0_get_factor": [H, F64P],
     "jh_ilu0_info": [H, I64P, I64P, I64P],
     "jh_ilu0_stats": [H, I64P],

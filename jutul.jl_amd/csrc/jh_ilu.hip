@@ -81,6 +81,22 @@ struct jh_ilu_s {
   int max_chunks = 0;                              // chunks of the largest block
   DevBuf<int32_t> d_jt_map, d_jf_diag;             // per jagged L entry (i,k): A slot of (k,i) or -1; per forward lane: A slot of its pivot
   DevBuf<uint16_t> d_jf_bslot;                     // per forward lane: the row's backward chunk lane inside the block
+  // "D-ILU" storage of a pivot-only factorisation: there L = I + L_A inv(D~) and U = D~ + U_A hold A's own in-block entries, so
+  // M = L U = (D~ + L_A) inv(D~) (D~ + U_A) and the sweeps can run on A's entries and the inverted pivots alone:
+  //   forward   g^_i = inv(D~_i) (b_i - sum_{k<i} A_ik g^_k)        (g^ = inv(D~) g in LDS)
+  //   backward  y_i  = g^_i - inv(D~_i) s_i,  s_i = sum_{k>i} A_ik y_k   (y in LDS, as in the LU form)
+  // With A's entries in both triangles the in-block part of the product A*y that follows every apply of the right-preconditioned
+  // Krylov loop costs one more, dependency-free pass over the L chunks (ilu_apply_jds_kernel<..., MUL>):
+  //   (A y)_i = A_ii y_i + s_i + sum_{k<i} A_ik y_k + sum_{k outside the block} A_ik y_k
+  //             backward lane  third pass             ilu_eprod_kernel ("E" entries)
+  bool uscaled = false;                            // D-ILU storage in use (l_val / u_val = A's entries in jagged order)
+  DevBuf<double> jkap;                             // per backward slot: A_ii
+  DevBuf<double> jdinv_f;                          // inverted pivots once more, in forward-lane order
+  DevBuf<uint16_t> d_jb_dev, d_jf_dev;             // per backward / forward slot: device row of the lane's row relative to the block
+                                                   // (| 0x8000: the row has entries outside its block)
+  int64_t e_rows = 0, e_nent = 0;                  // rows with out-of-block entries, and those entries
+  DevBuf<int32_t> d_e_row, d_e_ptr, d_e_col, d_e_slot;  // device row; CSR-like pointers; device column and slot of A of every entry
+  DevBuf<double> e_val;                            // their values, copied from A at the start of every solve (ilu_eprod_refresh)
   // program-driven factorisation (ilu_factor_prog_kernel): per block the entry ranges and a 16-bit instruction stream
   bool prog = false;
   std::vector<int32_t> blk_lbase, blk_ubase, blk_prog;  // [nb + 1] first jagged L / U entry and first program word of every block
@@ -190,6 +206,9 @@ struct IluDev {
   const int4 *jf_desc, *jb_desc;
   const uint32_t *jf_row, *jb_row;
   const uint16_t *jl_col, *ju_col;
+  // D-ILU storage / fused product (jh_ilu_s::uscaled)
+  double *kap, *dinv_f;
+  const uint16_t *jb_dev, *jf_dev;
 };
 
 // ---- numeric factorisation of one row (ilu0_factor!, ilu0.jl:108-144) -----------------------------------------------
@@ -381,7 +400,7 @@ __device__ __forceinline__ int jd_count(const int4 &d) {
 // forward sweep (chunk, lane): its L entries, their partners A_ki and its own diagonal are loaded up front (coalesced through the
 // chunk-jagged maps), the inverted pivots live in LDS by block-local row, the levels are walked with one barrier each.  Same
 // operations in the same order as ilu_factor_prog_kernel, hence the same bits.
-template <int BS, int KU>
+template <int BS, int KU, bool SC>
 __global__ __launch_bounds__(1024) void ilu_factor_diag_kernel(IluDev F, const double *__restrict__ aval, const int32_t *__restrict__ ubase,
                                                                const int32_t *__restrict__ jl_map, const int32_t *__restrict__ jt_map,
                                                                const int32_t *__restrict__ ju_map, const int32_t *__restrict__ jf_diag,
@@ -399,9 +418,10 @@ __global__ __launch_bounds__(1024) void ilu_factor_diag_kernel(IluDev F, const d
   const int lt = (int)(word & 0xffffu), lev = (int)(word >> 16);
   const bool has_row = lev != 0xffff;
   const size_t fslot = (size_t)(c0 + ch) * 64 + lane;
-  Blk<BS> acc;
+  Blk<BS> acc, aii;
   int bslot = 0;
   if (has_row) { acc = blk_load_al<BS>(aval + (size_t)jf_diag[fslot] * BB); bslot = (int)jf_bslot[fslot]; }
+  if (SC) aii = acc;
   int kcol[KU], pos[KU];
   bool act[KU];
   Blk<BS> av[KU], bv[KU];
@@ -424,7 +444,7 @@ __global__ __launch_bounds__(1024) void ilu_factor_diag_kernel(IluDev F, const d
     JH_FD(0) JH_FD(1) JH_FD(2) JH_FD(3) JH_FD(4) JH_FD(5) JH_FD(6) JH_FD(7)
 #undef JH_FD
   }
-  // U is a copy of A's entries (jagged order), four at a time per thread
+  // U holds A's entries (jagged order), four at a time per thread; SC (D-ILU storage): so does L
   {
     const int u0 = ubase[b], nu = ubase[b + 1] - u0;
     for (int j0 = tid; j0 < nu; j0 += 4 * T) {
@@ -444,6 +464,11 @@ __global__ __launch_bounds__(1024) void ilu_factor_diag_kernel(IluDev F, const d
       }
     }
   }
+  if (SC) {
+#pragma unroll
+    for (int j = 0; j < KU; ++j)
+      if (act[j]) blk_store_al<BS>(F.l_val + (size_t)pos[j] * BB, av[j]);
+  }
   const int lev0 = F.flev_off[b], nlev = F.flev_off[b + 1] - 1 - lev0;
   for (int lv = 0; lv < nlev; ++lv) {
     if (has_row && lev == lv) {
@@ -451,13 +476,17 @@ __global__ __launch_bounds__(1024) void ilu_factor_diag_kernel(IluDev F, const d
       for (int j = 0; j < KU; ++j) {
         if (act[j]) {
           const Blk<BS> lik = blk_mul<BS>(av[j], blk_load<BS>(dv + (size_t)kcol[j] * BB));  // nz_l * inv(A_kk)
-          blk_store_al<BS>(F.l_val + (size_t)pos[j] * BB, lik);
+          if (!SC) blk_store_al<BS>(F.l_val + (size_t)pos[j] * BB, lik);
           if (blk_nonzero<BS>(lik)) blk_sub<BS>(acc, blk_mul<BS>(lik, bv[j]));
         }
       }
       const Blk<BS> di = blk_inv<BS>(acc);
       blk_store<BS>(dv + (size_t)lt * BB, di);
       blk_store_al<BS>(F.dinv + ((size_t)c0 * 64 + bslot) * BB, di);
+      if (SC) {
+        blk_store_al<BS>(F.dinv_f + fslot * BB, di);
+        blk_store_al<BS>(F.kap + ((size_t)c0 * 64 + bslot) * BB, aii);
+      }
     }
     __syncthreads();
   }
@@ -901,8 +930,10 @@ struct JRow {
   int col[KU];
   double val[KU * BS * BS];
   double dinv[BS * BS];  // backward sweep only
+  double kap[BS * BS];   // backward sweep with the fused product only: A_ii inv(D~_i)
+  int dev;               // column-scaled U: device row of the lane's row relative to the block (| 0x8000: has out-of-block entries)
 };
-template <int BS, int KU, bool BWD>
+template <int BS, int KU, bool BWD, bool SC, bool MUL>
 __device__ __forceinline__ void jds_load(const IluDev &F, const int4 &D, int chunk, int lane, JRow<BS, KU> &R) {
   constexpr int BB = BS * BS;
   const uint16_t *cols = BWD ? F.ju_col : F.jl_col;
@@ -917,27 +948,37 @@ __device__ __forceinline__ void jds_load(const IluDev &F, const int4 &D, int chu
   }
   JH_JL(0) JH_JL(1) JH_JL(2) JH_JL(3) JH_JL(4) JH_JL(5) JH_JL(6) JH_JL(7)
 #undef JH_JL
-  if (BWD) {
+  if (BWD || SC) {
+    const double *dsrc = BWD ? F.dinv : F.dinv_f;
 #pragma unroll
-    for (int i = 0; i < BB; ++i) R.dinv[i] = F.dinv[((size_t)chunk * 64 + lane) * BB + i];
+    for (int i = 0; i < BB; ++i) R.dinv[i] = dsrc[((size_t)chunk * 64 + lane) * BB + i];
+  }
+  if (BWD && MUL) {
+#pragma unroll
+    for (int i = 0; i < BB; ++i) R.kap[i] = F.kap[((size_t)chunk * 64 + lane) * BB + i];
+    R.dev = (int)F.jb_dev[(size_t)chunk * 64 + lane];
   }
 }
-template <int BS, int KU, bool BWD>
-__device__ __forceinline__ void jds_sweep(const IluDev &F, double *xs, int c0, int nch, int lane) {
+// SC (D-ILU storage, jh_ilu_s::uscaled): the values are A's own entries; forward g^_i = inv(D~_i) (b_i - sum A_ik g^_k), backward
+// y_i = g^_i - inv(D~_i) s_i with s_i = sum A_ik y_k.  MUL: the backward lane also stores A_ii y_i + s_i, the part of (A y)_i it
+// knows, to qq (= q + first row of the block) at the row's device position.
+template <int BS, int KU, bool BWD, bool SC, bool MUL>
+__device__ __forceinline__ void jds_sweep(const IluDev &F, double *xs, int c0, int nch, int lane, double *qq = nullptr) {
   constexpr int BB = BS * BS;
   const int4 *desc = BWD ? F.jb_desc : F.jf_desc;
   int4 dc = desc[c0], dn = desc[c0 + 1], dnn;  // (the descriptor arrays are padded by two entries)
   JRow<BS, KU> cur, nxt;
-  jds_load<BS, KU, BWD>(F, dc, c0, lane, cur);
+  jds_load<BS, KU, BWD, SC, MUL>(F, dc, c0, lane, cur);
   for (int c = 0; c < nch; ++c) {
     dnn = desc[c0 + c + 2];
-    if (c + 1 < nch) jds_load<BS, KU, BWD>(F, dn, c0 + c + 1, lane, nxt);
+    if (c + 1 < nch) jds_load<BS, KU, BWD, SC, MUL>(F, dn, c0 + c + 1, lane, nxt);
     const int lt = (int)(cur.word & 0xffffu), lev = (int)(cur.word >> 16);
     const int lvlo = dc.w & 0xffff, lvhi = (int)((unsigned)dc.w >> 16);
-    double v[BS];
+    double v[BS], x0[BS];
 #pragma unroll
-    for (int e = 0; e < BS; ++e) v[e] = xs[lt * BS + e];  // this row's right-hand side: only the row itself ever writes it
-    for (int lv = BWD ? lvlo : max(lvlo, 1); lv <= lvhi; ++lv) {  // forward: level-0 rows have no L entries, x = b
+    for (int e = 0; e < BS; ++e) { x0[e] = xs[lt * BS + e]; v[e] = (SC && BWD) ? 0.0 : x0[e]; }  // this row's entry: only the row itself ever writes it
+    // forward, LU form: level-0 rows have no L entries, x = b; D-ILU form: they are scaled by their pivot like every row
+    for (int lv = (BWD || SC) ? lvlo : max(lvlo, 1); lv <= lvhi; ++lv) {
       if (lev == lv) {
 #define JH_JC(J)                                                                                              \
         if (J < KU && jd_count<(J < 8 ? J : 0)>(dc) > 0) {                                                   \
@@ -956,20 +997,30 @@ __device__ __forceinline__ void jds_sweep(const IluDev &F, double *xs, int c0, i
         }
         JH_JC(0) JH_JC(1) JH_JC(2) JH_JC(3) JH_JC(4) JH_JC(5) JH_JC(6) JH_JC(7)
 #undef JH_JC
-        if (BWD) {
-          if (BS == 1) {
-            xs[lt] = cur.dinv[0] * v[0];
-          } else {
-            double o[BS];
+        if (BWD || SC) {
+          double o[BS];  // inv(D~_i) v
+#pragma unroll
+          for (int e = 0; e < BS; ++e) {
+            double sum = 0.0;
+#pragma unroll
+            for (int d = 0; d < BS; ++d) sum += cur.dinv[d * BS + e] * v[d];
+            o[e] = sum;
+          }
+          if (SC && BWD) {  // v = -s_i: y_i = g^_i + inv(D~_i) v
+#pragma unroll
+            for (int e = 0; e < BS; ++e) o[e] += x0[e];
+          }
+#pragma unroll
+          for (int e = 0; e < BS; ++e) xs[lt * BS + e] = o[e];
+          if (MUL) {  // A_ii y_i + s_i
+            const int dev = cur.dev & 0x7fff;
 #pragma unroll
             for (int e = 0; e < BS; ++e) {
-              double sum = 0.0;
+              double sum = -v[e];
 #pragma unroll
-              for (int d = 0; d < BS; ++d) sum += cur.dinv[d * BS + e] * v[d];
-              o[e] = sum;
+              for (int d = 0; d < BS; ++d) sum += cur.kap[d * BS + e] * o[d];
+              qq[dev * BS + e] = sum;
             }
-#pragma unroll
-            for (int e = 0; e < BS; ++e) xs[lt * BS + e] = o[e];
           }
         } else {
 #pragma unroll
@@ -982,13 +1033,71 @@ __device__ __forceinline__ void jds_sweep(const IluDev &F, double *xs, int c0, i
     cur = nxt;
   }
 }
+// Third pass of the fused product (MUL): q_i += sum_{k<i} L_ik w_k over the forward chunks -- no dependencies, all lanes of a
+// chunk at once -- and the fused dot of the rows that are complete (no entry outside the block; the others are finished by
+// ilu_eprod_kernel).  d0 += q.dw ; DOT == 2: d1 += q.q
+template <int BS, int KU, int DOT>
+__device__ __forceinline__ void jds_mul_pass(const IluDev &F, const double *xs, int c0, int nch, int lane, double *qq, const double *dwq,
+                                             int dot_dev_end, double &d0, double &d1) {
+  constexpr int BB = BS * BS;
+  const int4 *desc = F.jf_desc;
+  int4 dc = desc[c0], dn = desc[c0 + 1], dnn;
+  JRow<BS, KU> cur, nxt;
+  jds_load<BS, KU, false, false, false>(F, dc, c0, lane, cur);
+  int devw = (int)F.jf_dev[(size_t)c0 * 64 + lane], devn = 0;
+  for (int c = 0; c < nch; ++c) {
+    dnn = desc[c0 + c + 2];
+    if (c + 1 < nch) { jds_load<BS, KU, false, false, false>(F, dn, c0 + c + 1, lane, nxt); devn = (int)F.jf_dev[(size_t)(c0 + c + 1) * 64 + lane]; }
+    const bool has_row = (cur.word >> 16) != 0xffffu;
+    const int dev = devw & 0x7fff;
+    double t[BS], wv[BS];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) {
+      // the partial product was stored by another lane of this wavefront (backward sweep, ordered by the workgroup-scope fence)
+      t[e] = has_row ? __hip_atomic_load(qq + dev * BS + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0.0;
+      wv[e] = (DOT && has_row) ? dwq[dev * BS + e] : 0.0;
+    }
+#define JH_JM(J)                                                                                              \
+    if (J < KU && jd_count<(J < 8 ? J : 0)>(dc) > 0) {                                                       \
+      const int k = cur.col[J < KU ? J : 0];                                                                 \
+      const bool a = lane < jd_count<(J < 8 ? J : 0)>(dc);                                                   \
+      _Pragma("unroll") for (int e = 0; e < BS; ++e) {                                                       \
+        double sum = 0.0;                                                                                     \
+        _Pragma("unroll") for (int d = 0; d < BS; ++d) sum += cur.val[(J < KU ? J : 0) * BB + d * BS + e] * xs[k * BS + d]; \
+        t[e] = a ? t[e] + sum : t[e];                                                                         \
+      }                                                                                                       \
+    }
+    JH_JM(0) JH_JM(1) JH_JM(2) JH_JM(3) JH_JM(4) JH_JM(5) JH_JM(6) JH_JM(7)
+#undef JH_JM
+    if (has_row) {
+#pragma unroll
+      for (int e = 0; e < BS; ++e) qq[dev * BS + e] = t[e];
+      if (DOT && !(devw & 0x8000) && dev < dot_dev_end) {
+#pragma unroll
+        for (int e = 0; e < BS; ++e) { d0 += t[e] * wv[e]; if (DOT == 2) d1 += t[e] * t[e]; }
+      }
+    }
+    dc = dn; dn = dnn;
+    cur = nxt;
+    devw = devn;
+  }
+}
 
-template <int BS, int GM, int KU>
-__global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec, IluGather G) {
+// MUL: 0 = apply only; 1 / 2 / 3 = fused product without a dot / with <q, dw> / with <q, dw>, <q, q> (jh_ilu_s::uscaled)
+struct IluMul {
+  double *q = nullptr;          // A * x (in-block part; rows with out-of-block entries are finished by ilu_eprod_kernel)
+  const double *dw = nullptr;   // dot weights
+  double *part = nullptr;       // one partial per block (+ pstride: second dot)
+  size_t pstride = 0;
+  int dot_rows = 0x7fffffff;    // device rows >= dot_rows (ghost rows of a rank-local subdomain) do not contribute to the dot
+};
+template <int BS, int GM, int KU, bool SC, int MUL>
+__global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec, IluGather G, IluMul Q) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
   if (GM == 2 && G.pub_rec && blockIdx.x == 0 && threadIdx.x == 0)
     publish_record(G.sc_rw, G.pub_pair, G.pub_eps, G.pub_rec, G.pub_seq);  // raises the done flag on convergence
   if (GM != 0 && G.done && *G.done != 0.0) return;  // speculative launch after the Krylov solve has converged
+  if (GM == 0 && MUL && G.done && *G.done != 0.0) return;
   const int b = blockIdx.x, lane = threadIdx.x;
   const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
   const int nr = b1 - b0;
@@ -1024,9 +1133,23 @@ __global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const doubl
     }
   }
   __syncthreads();
-  jds_sweep<BS, KU, false>(F, xs, c0, nch, lane);
-  jds_sweep<BS, KU, true>(F, xs, c0, nch, lane);
+  jds_sweep<BS, KU, false, SC, false>(F, xs, c0, nch, lane);
+  jds_sweep<BS, KU, true, SC, (MUL != 0)>(F, xs, c0, nch, lane, MUL ? Q.q + (size_t)b0 * BS : nullptr);
   __syncthreads();
+  if (MUL) {
+    // the partial products of the backward sweep were stored by lanes of this wavefront: a workgroup-scope fence orders them
+    // before the third pass reads them back (an agent-scope fence writes back the XCD's L2: 1.7 ms per launch, measured)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double d0 = 0.0, d1 = 0.0;
+    constexpr int DOT = MUL - 1;
+    jds_mul_pass<BS, KU, DOT>(F, xs, c0, nch, lane, Q.q + (size_t)b0 * BS, DOT ? Q.dw + (size_t)b0 * BS : nullptr, Q.dot_rows - b0, d0, d1);
+    if (DOT) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); if (DOT == 2) d1 += __shfl_down(d1, off, 64); }
+      if (lane == 0) { Q.part[b] = d0; if (DOT == 2) Q.part[Q.pstride + b] = d1; }
+    }
+  }
   for (int t = lane; t < nr; t += 64) {
     const int dev = b0 + t;
     const int pos = (int)F.rowmap16[dev];
@@ -1036,15 +1159,68 @@ __global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const doubl
   if (F.send_ptr) {  // rows that neighbouring ranks hold as ghosts go straight into the halo send buffer (no pack kernel)
     for (int j = F.send_ptr[b] + lane; j < F.send_ptr[b + 1]; j += 64) {
       const int t = F.send_local[j];
+      double yv[BS];
+#pragma unroll
+      for (int e = 0; e < BS; ++e) yv[e] = xs[t * BS + e];
       if (F.send_dst) {  // xGMI store into the receiving rank's landing buffer
         double *dp = F.send_dst[F.send_slot[j]];
 #pragma unroll
-        for (int e = 0; e < BS; ++e) __hip_atomic_store(dp + e, xs[t * BS + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int e = 0; e < BS; ++e) __hip_atomic_store(dp + e, yv[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       } else {
         const size_t o = (size_t)F.send_slot[j] * BS;
 #pragma unroll
-        for (int e = 0; e < BS; ++e) F.send_buf[o + e] = xs[t * BS + e];
+        for (int e = 0; e < BS; ++e) F.send_buf[o + e] = yv[e];
       }
+    }
+  }
+}
+
+// The part of the product the blocks cannot form: q_i += sum over the entries of row i OUTSIDE its block of A_ik y_k, one thread
+// per such row (13 % of the entries, a third of the rows on the bisection blocks of a tet grid), and those rows' share of the
+// fused dot.  Partials go behind the part_off per-block partials of the apply kernel.
+template <int BS, int DOT>
+__global__ __launch_bounds__(256) void ilu_eprod_kernel(const int32_t *__restrict__ erow, const int32_t *__restrict__ eptr,
+                                                        const int32_t *__restrict__ ecol, const double *__restrict__ eval,
+                                                        const double *__restrict__ y, double *__restrict__ q,
+                                                        int nrows, const double *__restrict__ dw, int dot_rows, double *__restrict__ part,
+                                                        size_t pstride, int part_off, const double *done) {
+  if (done && *done != 0.0) return;
+  constexpr int BB = BS * BS;
+  __shared__ double red[8];
+  double d0 = 0.0, d1 = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += gridDim.x * blockDim.x) {
+    const int row = erow[i];
+    const int k0 = eptr[i], k1 = eptr[i + 1];
+    double acc[BS];
+#pragma unroll
+    for (int e = 0; e < BS; ++e) acc[e] = q[(size_t)row * BS + e];
+    for (int k = k0; k < k1; ++k) {
+      const int c = ecol[k];
+      const double *Ab = eval + (size_t)k * BB;
+#pragma unroll
+      for (int e = 0; e < BS; ++e) {
+        double sum = 0.0;
+#pragma unroll
+        for (int d = 0; d < BS; ++d) sum += Ab[d * BS + e] * y[(size_t)c * BS + d];
+        acc[e] += sum;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < BS; ++e) q[(size_t)row * BS + e] = acc[e];
+    if (DOT && row < dot_rows) {
+#pragma unroll
+      for (int e = 0; e < BS; ++e) { d0 += acc[e] * dw[(size_t)row * BS + e]; if (DOT == 2) d1 += acc[e] * acc[e]; }
+    }
+  }
+  if (DOT) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); if (DOT == 2) d1 += __shfl_down(d1, off, 64); }
+    if (lane == 0) { red[w] = d0; red[4 + w] = d1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      part[part_off + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+      if (DOT == 2) part[pstride + part_off + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
     }
   }
 }
@@ -1137,6 +1313,7 @@ IluDev dev_view(jh_ilu M) {
   F.send_ptr = nullptr; F.send_local = nullptr; F.send_slot = nullptr; F.send_buf = nullptr; F.send_dst = nullptr;
   F.chunk_ptr = M->d_chunk_ptr.p; F.jf_desc = M->d_jf_desc.p; F.jb_desc = M->d_jb_desc.p;
   F.jf_row = M->d_jf_row.p; F.jb_row = M->d_jb_row.p; F.jl_col = M->d_jl_col.p; F.ju_col = M->d_ju_col.p;
+  F.kap = M->jkap.p; F.dinv_f = M->jdinv_f.p; F.jb_dev = M->d_jb_dev.p; F.jf_dev = M->d_jf_dev.p;
   return F;
 }
 
@@ -1538,7 +1715,72 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
               M->d_jt_map.upload(jt_map, sd); M->d_jf_diag.upload(jf_diag, sd); M->d_jf_bslot.upload(jf_bslot, sd);
               M->d_blk_ubase.upload(M->blk_ubase, sd);
             }
-            if (timing) fprintf(stderr, "[jutul_hip setup] ilu0: pivot-only factorisation %s (largest block: %d chunks)\n", M->diag_only ? "on" : "off", mxc);
+            // D-ILU storage + fused product: OPT-IN (JH_FUSED_PRODUCT=1).  Measured on MI355X, 10M cells (profiles/r03_fused_product_*):
+            // apply + third pass 0.334 ms, out-of-block launch 0.108 ms = 0.442 ms against 0.202 + 0.176 = 0.379 ms for apply +
+            // jagged SpMV.  The factor / matrix ENTRIES read twice today (0.41 GB) are saved, but the per-row streams the fusion
+            // adds -- A_ii, the second copy of the pivots, the partial product written and read back, dot weights and q touched
+            // again by the out-of-block rows at sector granularity -- cost as much: 1.8 GB either way.
+            M->uscaled = M->diag_only && M->blk_ptr.size() > 1 && getenv("JH_FUSED_PRODUCT") != nullptr;
+            if (M->uscaled) {
+              // device row (relative to its block) of every forward / backward lane, flagged when the row has entries outside the block;
+              // the list of those entries ("E": what ilu_eprod_kernel adds after the apply)
+              std::vector<uint16_t> jb_dev(M->j_nslots, 0), jf_dev(M->j_nslots, 0);
+              std::vector<char> has_e(n, 0);
+              std::vector<int32_t> ecount(n + 1, 0);
+              parallel_ranges(nb, 16, [&](int64_t bb0, int64_t bb1) {
+                for (int64_t b = bb0; b < bb1; ++b) {
+                  const int32_t b0 = M->blk_ptr[b], b1 = M->blk_ptr[b + 1];
+                  for (int32_t i = b0; i < b1; ++i) {  // device rows of the block (rowmap_local: the block's rows are [b0, b1))
+                    int32_t ce = 0;
+                    for (int32_t k = P.rowptr[i]; k < P.rowptr[i + 1]; ++k) ce += (P.col[k] < b0 || P.col[k] >= b1) && !P.is_shadow(k);
+                    ecount[i + 1] = ce;
+                    has_e[i] = ce > 0;
+                  }
+                  for (int32_t c = M->chunk_ptr[b]; c < M->chunk_ptr[b + 1]; ++c)
+                    for (int l = 0; l < 64; ++l) {
+                      const size_t sl = (size_t)c * 64 + l;
+                      for (int sweep = 0; sweep < 2; ++sweep) {
+                        const uint32_t wd = (sweep ? brow : frow)[sl];
+                        if ((wd >> 16) == 0xffffu) continue;
+                        const int32_t dev = M->rowmap[b0 + (int32_t)(wd & 0xffffu)];  // ilu row -> device row
+                        (sweep ? jb_dev : jf_dev)[sl] = (uint16_t)((dev - b0) | (has_e[dev] ? 0x8000 : 0));
+                      }
+                    }
+                }
+              });
+              bool local = true;  // (checked again below for every block; the lists assume it)
+              for (int64_t b = 0; b < nb && local; ++b)
+                for (int32_t t = M->blk_ptr[b]; t < M->blk_ptr[b + 1]; ++t)
+                  if (M->rowmap[t] < M->blk_ptr[b] || M->rowmap[t] >= M->blk_ptr[b + 1]) { local = false; break; }
+              if (!local || maxrows >= 0x8000) {
+                M->uscaled = false;
+              } else {
+                std::vector<int32_t> e_row, e_ptr(1, 0), e_col, e_slot;
+                std::vector<int32_t> blk_of_dev(n);
+                for (int64_t b = 0; b < nb; ++b)
+                  for (int32_t i = M->blk_ptr[b]; i < M->blk_ptr[b + 1]; ++i) blk_of_dev[i] = (int32_t)b;
+                for (int64_t i = 0; i < n; ++i) {
+                  if (!has_e[i]) continue;
+                  const int32_t b0 = M->blk_ptr[blk_of_dev[i]], b1 = M->blk_ptr[blk_of_dev[i] + 1];
+                  e_row.push_back((int32_t)i);
+                  for (int32_t k = P.rowptr[i]; k < P.rowptr[i + 1]; ++k)
+                    if ((P.col[k] < b0 || P.col[k] >= b1) && !P.is_shadow(k)) { e_col.push_back(P.col[k]); e_slot.push_back(k); }
+                  e_ptr.push_back((int32_t)e_col.size());
+                }
+                M->e_rows = (int64_t)e_row.size();
+                M->e_nent = (int64_t)e_col.size();
+                hipStream_t su = M->ctx->stream;
+                M->d_jb_dev.upload(jb_dev, su); M->d_jf_dev.upload(jf_dev, su);
+                if (e_row.empty()) { e_row.push_back(0); e_col.push_back(0); e_slot.push_back(0); }
+                M->d_e_row.upload(e_row, su); M->d_e_ptr.upload(e_ptr, su); M->d_e_col.upload(e_col, su); M->d_e_slot.upload(e_slot, su);
+                M->jkap.alloc((size_t)M->j_nslots * P.bs * P.bs);
+                M->jdinv_f.alloc((size_t)M->j_nslots * P.bs * P.bs);
+                JH_HIP(hipMemsetAsync(M->jkap.p, 0, M->jkap.n * sizeof(double), su));
+                JH_HIP(hipMemsetAsync(M->jdinv_f.p, 0, M->jdinv_f.n * sizeof(double), su));
+              }
+            }
+            if (timing) fprintf(stderr, "[jutul_hip setup] ilu0: pivot-only factorisation %s (largest block: %d chunks), fused product %s (%lld rows with %lld out-of-block entries)\n",
+                                M->diag_only ? "on" : "off", mxc, M->uscaled ? "on" : "off", (long long)M->e_rows, (long long)M->e_nent);
           }
           size_t bytes = sizeof(double) * P.bs * P.bs * (size_t)max_vals + sizeof(uint16_t) * (size_t)max_words;
           bytes = (bytes + 15) & ~(size_t)15;
@@ -1635,7 +1877,8 @@ extern "C" int32_t jh_ilu0_stats(jh_ilu M, int64_t *stats4) {
     stats4[0] = (int64_t)M->l_col.size();
     stats4[1] = (int64_t)M->u_col.size();
     stats4[2] = (int64_t)M->blk_ptr.size() - 1;
-    stats4[3] = (M->lds_mode ? 1 : 0) | (M->jag ? 2 : 0) | (M->jag && M->prog ? 4 : 0) | (M->jag && M->prog && M->diag_only ? 8 : 0);
+    stats4[3] = (M->lds_mode ? 1 : 0) | (M->jag ? 2 : 0) | (M->jag && M->prog ? 4 : 0) | (M->jag && M->prog && M->diag_only ? 8 : 0) |
+                ((M->jag && M->uscaled && !getenv("JH_NO_FUSED_PRODUCT")) ? 16 : 0);
   });
 }
 
@@ -1667,13 +1910,22 @@ static void ilu_to_jagged(jh_ilu M) {
     hipLaunchKernelGGL(ilu_jag_permute_kernel, g((int64_t)M->u_col.size() * bb), dim3(256), 0, s, M->ju_val.p, M->u_val.p, M->d_ju_of_old.p, (int64_t)M->u_col.size(), bb);
   hipLaunchKernelGGL(ilu_jag_permute_kernel, g(M->n * bb), dim3(256), 0, s, M->jdinv.p, M->dinv.p, M->d_jd_of_old.p, M->n, bb);
 }
-// launches the chunk-jagged apply (GM as in ilu_apply_chunked_kernel)
-static void ilu_apply_jagged(jh_ilu M, IluDev F, const double *b, double *x, const IluGather &G) {
+// launches the chunk-jagged apply (GM as in ilu_apply_chunked_kernel); Q.q != nullptr: with the fused product (mul = 1 + dots)
+static void ilu_apply_jagged(jh_ilu M, IluDev F, const double *b, double *x, const IluGather &G, const IluMul &Q = IluMul(), int mul = 0) {
   F.l_val = M->jl_val.p; F.u_val = M->ju_val.p; F.dinv = M->jdinv.p;
   const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
   hipStream_t s = M->ctx->stream;
-#define JH_J(BSV, GMV, KUV) hipLaunchKernelGGL((ilu_apply_jds_kernel<BSV, GMV, KUV>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x, G)
-#define JH_JK(BSV, GMV) do { if (M->jag_ku == 4) JH_J(BSV, GMV, 4); else JH_J(BSV, GMV, 8); } while (0)
+  if (mul && !M->uscaled) JH_THROW("fused product needs column-scaled factors");
+#define JH_J(BSV, GMV, KUV, SCV, MULV) hipLaunchKernelGGL((ilu_apply_jds_kernel<BSV, GMV, KUV, SCV, MULV>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x, G, Q)
+#define JH_JM(BSV, GMV, KUV)                                                                          \
+  do {                                                                                                 \
+    if (!M->uscaled) JH_J(BSV, GMV, KUV, false, 0);                                                    \
+    else if (mul == 0) JH_J(BSV, GMV, KUV, true, 0);                                                   \
+    else if (mul == 1) JH_J(BSV, GMV, KUV, true, 1);                                                   \
+    else if (mul == 2) JH_J(BSV, GMV, KUV, true, 2);                                                   \
+    else JH_J(BSV, GMV, KUV, true, 3);                                                                 \
+  } while (0)
+#define JH_JK(BSV, GMV) do { if (M->jag_ku == 4) JH_JM(BSV, GMV, 4); else JH_JM(BSV, GMV, 8); } while (0)
   switch (M->bs * 10 + G.mode) {
     case 10: JH_JK(1, 0); break; case 11: JH_JK(1, 1); break; case 12: JH_JK(1, 2); break;
     case 20: JH_JK(2, 0); break; case 21: JH_JK(2, 1); break; case 22: JH_JK(2, 2); break;
@@ -1681,6 +1933,7 @@ static void ilu_apply_jagged(jh_ilu M, IluDev F, const double *b, double *x, con
     default: JH_THROW("bad jagged apply mode");
   }
 #undef JH_JK
+#undef JH_JM
 #undef JH_J
 }
 void ilu_factor(jh_ilu M) {
@@ -1706,9 +1959,10 @@ void ilu_factor(jh_ilu M) {
     if (M->diag_only) {  // every elimination update lands on a pivot: the sweep-shaped kernel
       const int dthreads = 64 * M->max_chunks;
       const size_t dlds = sizeof(double) * (size_t)M->max_block_rows * M->bs * M->bs;
-#define JH_DIAG(BSV, KUV) hipLaunchKernelGGL((ilu_factor_diag_kernel<BSV, KUV>), dim3((unsigned)nb), dim3(dthreads), dlds, s, F, aval, \
-                                              M->d_blk_ubase.p, M->d_jl_map.p, M->d_jt_map.p, M->d_ju_map.p, M->d_jf_diag.p, M->d_jf_bslot.p)
-#define JH_DIAGK(BSV) do { if (M->jag_ku == 4) JH_DIAG(BSV, 4); else JH_DIAG(BSV, 8); } while (0)
+#define JH_DIAG(BSV, KUV, SCV) hipLaunchKernelGGL((ilu_factor_diag_kernel<BSV, KUV, SCV>), dim3((unsigned)nb), dim3(dthreads), dlds, s, F, aval, \
+                                                   M->d_blk_ubase.p, M->d_jl_map.p, M->d_jt_map.p, M->d_ju_map.p, M->d_jf_diag.p, M->d_jf_bslot.p)
+#define JH_DIAGK(BSV) do { if (M->uscaled) { if (M->jag_ku == 4) JH_DIAG(BSV, 4, true); else JH_DIAG(BSV, 8, true); } \
+                           else { if (M->jag_ku == 4) JH_DIAG(BSV, 4, false); else JH_DIAG(BSV, 8, false); } } while (0)
       switch (M->bs) { case 1: JH_DIAGK(1); break; case 2: JH_DIAGK(2); break; case 3: JH_DIAGK(3); break; }
 #undef JH_DIAGK
 #undef JH_DIAG
@@ -1862,6 +2116,60 @@ void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x, bool pack) {
   }
 #undef JH_FUSED
 }
+// The product that follows every preconditioner apply of the right-preconditioned Krylov loop, formed inside the apply
+// (jh_ilu_s::uscaled): x = M^-1 (b, or the fused vector update G), q = A x, optional fused dot (SpmvDot contract: mode 1
+// sum(q .* w), mode 2 sum(q .* w), sum(q .* q)).  Two launches: the apply with its third pass (in-block entries, one dot partial
+// per block) and ilu_eprod_kernel (out-of-block entries, partials behind them).  Returns the number of partials; the caller
+// runs the second reduction stage.  done: the launches are no-ops once *done != 0.
+bool ilu_can_fuse_product(jh_ilu M) {
+  const bool off = getenv("JH_NO_FUSED_PRODUCT") != nullptr;  // (read per solve: the parity tests compare both paths in one process)
+  return !off && M && M->kind == 0 && M->jag && M->uscaled && M->factored;
+}
+// the out-of-block entries' values in the order ilu_eprod_kernel reads them: once per solve (the matrix is constant inside one)
+void ilu_eprod_refresh(jh_ilu M) {
+  if (!M->uscaled || M->e_nent == 0) return;
+  const int bb = M->bs * M->bs;
+  if (M->e_val.n < (size_t)M->e_nent * bb) M->e_val.alloc((size_t)M->e_nent * bb);
+  k_gather_blocks(M->ctx->stream, M->e_val.p, M->A->val.p, M->d_e_slot.p, M->e_nent, bb, false);
+}
+static int eprod_grid(jh_ilu M) { return (int)std::max<int64_t>(1, std::min<int64_t>((M->e_rows + 255) / 256, 2048)); }
+void ilu_apply_mul(jh_ilu M, const IluGather &G, const double *b, double *x, double *q, const SpmvDot *dot, const double *done, bool pack) {
+  if (!ilu_can_fuse_product(M)) JH_THROW("fused preconditioner apply + product is not available for this factorisation");
+  jh_context ctx = M->ctx;
+  const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
+  const int mode = dot ? dot->mode : 0;
+  if (mode) ensure_partials(ctx, (size_t)nb + eprod_grid(M));
+  IluDev F = dev_view(M);
+  if (pack) {  // as in ilu_apply_fused: the rows neighbouring ranks hold as ghosts leave with the apply
+    if (!ilu_can_pack_halo(M)) JH_THROW("fused halo pack requested without a matching halo plan");
+    F.send_ptr = M->d_send_ptr.p; F.send_local = M->d_send_local.p; F.send_slot = M->d_send_slot.p;
+    F.send_buf = M->A->disc->halo.d_send_buf.p;
+    F.send_dst = halo_push_targets(M->A->disc);
+  }
+  IluMul Q;
+  Q.q = q; Q.dw = dot ? dot->w : nullptr; Q.part = ctx->partials.p; Q.pstride = ctx->partial_stride;
+  if (dot && dot->n_rows > 0) Q.dot_rows = (int)dot->n_rows;
+  IluGather G2 = G;
+  if (G2.mode == 0) G2.done = done;
+  ilu_apply_jagged(M, F, b, x, G2, Q, 1 + mode);
+}
+// second launch of the fused product: the out-of-block entries; returns the number of dot partials of both launches
+int ilu_eprod(jh_ilu M, const double *x, double *q, const SpmvDot *dot, const double *done) {
+  jh_context ctx = M->ctx;
+  hipStream_t s = ctx->stream;
+  const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
+  const int mode = dot ? dot->mode : 0;
+  const int ge = eprod_grid(M);
+  const double *dw = dot ? dot->w : nullptr;
+  const int drows = dot ? (int)dot->n_rows : 0;
+#define JH_E(BSV, DV) hipLaunchKernelGGL((ilu_eprod_kernel<BSV, DV>), dim3(ge), dim3(256), 0, s, M->d_e_row.p, M->d_e_ptr.p, M->d_e_col.p, \
+                                         M->e_val.p, x, q, (int)M->e_rows, dw, drows, ctx->partials.p, ctx->partial_stride, (int)nb, done)
+#define JH_ED(BSV) do { if (mode == 0) JH_E(BSV, 0); else if (mode == 1) JH_E(BSV, 1); else JH_E(BSV, 2); } while (0)
+  switch (M->bs) { case 1: JH_ED(1); break; case 2: JH_ED(2); break; case 3: JH_ED(3); break; }
+#undef JH_ED
+#undef JH_E
+  return (int)nb + ge;
+}
 }  // namespace jh
 
 extern "C" int32_t jh_ilu0_factor(jh_ilu M) {
@@ -1884,6 +2192,25 @@ extern "C" int32_t jh_ilu0_apply(jh_ilu M, jh_vec b, jh_vec x) {
   });
 }
 
+extern "C" int32_t jh_ilu0_apply_mul(jh_ilu M, jh_vec b, jh_vec x, jh_vec q) {
+  return guard([&] {
+    if (!M || !b || !x || !q) JH_THROW("null handle");
+    if (b->len != M->n * M->bs || x->len != b->len || q->len != b->len) JH_THROW("dimension mismatch in ilu apply + product");
+    if (b == x || x == q || b == q) JH_THROW("b, x and q must not alias");
+    if (!M->factored) JH_THROW("ILU(0) applied before jh_ilu0_factor");
+    JH_HIP(hipSetDevice(M->ctx->device));
+    if (jh::ilu_can_fuse_product(M)) {
+      jh::ilu_eprod_refresh(M);
+      jh::ilu_apply_mul(M, jh::IluGather(), b->d.p, x->d.p, q->d.p, nullptr, nullptr, false);
+      jh::ilu_eprod(M, x->d.p, q->d.p, nullptr, nullptr);
+    } else {  // patterns with triangles inside a block, several ranks, diagonal preconditioners: two operators
+      jh::ilu_apply(M, b->d.p, x->d.p);
+      jh::k_spmv(M->ctx, *M->pat, M->A->val.p, x->d.p, q->d.p, 1.0, 0.0);
+    }
+    JH_HIP(hipGetLastError());
+  });
+}
+
 extern "C" int32_t jh_ilu0_get_factor(jh_ilu M, double *lu) {
   return guard([&] {
     if (!M || !lu) JH_THROW("null argument");
@@ -1898,6 +2225,25 @@ extern "C" int32_t jh_ilu0_get_factor(jh_ilu M, double *lu) {
       JH_HIP(hipMemcpy(l.data(), M->jl_val.p, l.size() * sizeof(double), hipMemcpyDeviceToHost));
       JH_HIP(hipMemcpy(u.data(), M->ju_val.p, u.size() * sizeof(double), hipMemcpyDeviceToHost));
       JH_HIP(hipMemcpy(d.data(), M->jdinv.p, d.size() * sizeof(double), hipMemcpyDeviceToHost));
+      if (M->uscaled) {  // D-ILU storage: l holds A's entries; the factor's L_ik = A_ik inv(D~_k) (ilu0.jl:108-144)
+        const int64_t nbk = (int64_t)M->blk_ptr.size() - 1;
+        for (int64_t bk = 0; bk < nbk; ++bk) {
+          const int32_t r0 = M->blk_ptr[bk];
+          for (int32_t t = r0; t < M->blk_ptr[bk + 1]; ++t)
+            for (int32_t pp = M->l_ptr[t]; pp < M->l_ptr[t + 1]; ++pp) {
+              const int32_t j = M->jl_of_old[pp];
+              const double *dk = d.data() + (size_t)M->jd_of_old[M->upos_of[r0 + M->l_col[pp]]] * bb;
+              double tmp[9];
+              for (int cc = 0; cc < M->bs; ++cc)
+                for (int rr = 0; rr < M->bs; ++rr) {
+                  double sum = 0.0;
+                  for (int kk = 0; kk < M->bs; ++kk) sum += l[(size_t)j * bb + kk * M->bs + rr] * dk[cc * M->bs + kk];
+                  tmp[cc * M->bs + rr] = sum;
+                }
+              for (int e = 0; e < bb; ++e) l[(size_t)j * bb + e] = tmp[e];
+            }
+        }
+      }
       for (size_t j = 0; j < M->jl_map.size(); ++j)
         for (int e = 0; e < bb; ++e) lu[hslot(M->jl_map[j]) * bb + e] = l[j * bb + e];
       for (size_t j = 0; j < M->ju_map.size(); ++j)

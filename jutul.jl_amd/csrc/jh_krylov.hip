@@ -17,6 +17,10 @@ namespace jh {
 void ilu_apply(jh_ilu M, const double *b, double *x);
 bool ilu_can_fuse_gather(jh_ilu M);
 void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x, bool pack = false);
+bool ilu_can_fuse_product(jh_ilu M);
+void ilu_apply_mul(jh_ilu M, const IluGather &G, const double *b, double *x, double *q, const SpmvDot *dot, const double *done, bool pack);
+int ilu_eprod(jh_ilu M, const double *x, double *q, const SpmvDot *dot, const double *done);
+void ilu_eprod_refresh(jh_ilu M);
 bool ilu_can_pack_halo(jh_ilu M);
 void halo_exchange_begin(jh_tpfa d, double *v, int bs, bool packed = false);
 void halo_exchange_end(jh_tpfa d);
@@ -256,8 +260,27 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     comm_allreduce_dev(ctx, sc + slot, c2 ? 2 : 1, 0);
   };
   const int64_t rows_dot = nd / P.bs;
+  // Right preconditioning with column-scaled pivot-only factors: every product of the loop is A * (M^-1 v), and its in-block part
+  // is formed inside the apply (ilu_apply_mul); the out-of-block entries -- ghost columns among them, hence after the ghost
+  // exchange -- follow in ilu_eprod.  No SpMV launch, no jagged copy of the matrix.
+  static const bool want_overlap_ = getenv("JH_HALO_OVERLAP") != nullptr;
+  const bool fmul = right && ilu_can_fuse_gather(M) && ilu_can_fuse_product(M) && !(dist && want_overlap_);
+  const bool fmul_pack = fmul && dist && ilu_can_pack_halo(M);
   // the matrix does not change during the solve: multiply out of its jagged-slice copy when it has one (jh_sell.hip)
-  const bool jagged = sell_refresh(K->A);
+  const bool jagged = !fmul && sell_refresh(K->A);
+  if (fmul) ilu_eprod_refresh(M);
+  // x = M^-1 (input), out = A x with the fused dot; event pairs: [1] the apply launch, [0] the out-of-block launch
+  auto apply_mul = [&](const IluGather &G, double *bin, double *xv, double *out, const SpmvDot &dot) {
+    if (bin && dist && n > nd) k_fill(st, bin + nd, n - nd, 0.0);  // ghost part of the preconditioner's input (linalg.jl:78-88)
+    K->mark(1, st);
+    ilu_apply_mul(M, G, bin, xv, out, &dot, done, fmul_pack);
+    K->mark(1, st);
+    if (dist) halo_exchange(disc, xv, P.bs, fmul_pack, true);  // consistent!(x) before the ghost columns are multiplied
+    K->mark(0, st);
+    const int nparts = ilu_eprod(M, xv, out, &dot, done);
+    K->mark(0, st);
+    spmv_dot_reduce(ctx, &dot, nparts, done);
+  };
   auto spmv = [&](double *in, double *out, const SpmvDot *dot, bool packed = false) {
     if (dist) halo_exchange(disc, in, P.bs, packed, true);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
     K->mark(0, st);
@@ -353,7 +376,11 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       G.rho_slot = pair_of(k - 1); G.rho_next_slot = rs; G.cv_slot = S_CV; G.ts_slot = S_TS; G.n_owned_rows = ghost_from;
       if (pend_rec) { G.pub_rec = pend_rec; G.pub_seq = pend_seq; G.pub_pair = pend_pair; G.pub_eps = pend_eps; G.sc_rw = sc; pend_rec = nullptr; }
       yy = K->y.p;
-      if (overlap) {
+      if (fmul) {
+        SpmvDot d1{1, K->c.p, S_CV, rows_dot, true};
+        apply_mul(G, nullptr, yy, K->q.p, d1);
+        v_done = true;
+      } else if (overlap) {
         // NB: q is an input of this gather (p-update) and the output of the SpMV, which follows it on the compute stream
         SpmvDot d1{1, K->c.p, S_CV, rows_dot, true};
         fused_half(G, yy, K->q.p, d1);
@@ -364,6 +391,11 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
         K->mark(1, st);
         y_packed = pack;
       }
+    } else if (fmul) {  // first iteration: y = N^-1 p, q = A y
+      SpmvDot d1{1, K->c.p, S_CV, rows_dot, true};
+      apply_mul(IluGather(), K->p.p, K->y.p, K->q.p, d1);
+      yy = K->y.p;
+      v_done = true;
     } else if (right) { prec(K->p.p, K->y.p); yy = K->y.p; }
     double *vv = K->q.p;
     if (v_done) {
@@ -383,7 +415,11 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       G.mode = 1; G.r = K->r.p; G.q = vv; G.out = K->s.p; G.sc = sc; G.done = done;
       G.rho_slot = rs; G.cv_slot = S_CV; G.n_owned_rows = ghost_from;
       zz = K->z.p;
-      if (overlap) {
+      if (fmul) {
+        SpmvDot d2{2, K->s.p, S_TS, rows_dot, true};
+        apply_mul(G, nullptr, zz, K->d.p, d2);
+        t_done = true;
+      } else if (overlap) {
         SpmvDot d2{2, K->s.p, S_TS, rows_dot, true};
         fused_half(G, zz, K->d.p, d2);
         t_done = true;

@@ -361,6 +361,74 @@ def test_ilu0_device_blocks_on_tpfa_jacobian(ja, ctx, oracle):
     assert F.info()["nblocks"] == len(bp) - 1
 
 
+@pytest.mark.parametrize("kind", ["poisson", "twophase"])
+def test_preconditioned_operator_fused_product(ja, ctx, oracle, kind):
+    """jh_ilu0_apply_mul: x = M^-1 b and q = A x formed in one pass over the column-scaled pivot-only factors (the product
+    inside the preconditioner apply of the right-preconditioned Krylov loop) == oracle spmv(ilu_apply(b)) at 1e-10, for scalar
+    and 2x2-block matrices; the standalone apply on the same factors, the factor export and BiCGStab through the fused
+    operator agree with the unfused path (JH_NO_FUSED_PRODUCT) to rounding."""
+    import os
+    import scipy.sparse as sp
+    g, rng = tet_case(ja, (9, 8, 6), seed=12)
+    lsys, law, disc, osys, nz_o, r_o = assemble_both(ja, ctx, oracle, g, rng, kind, "blocks")
+    nc, bs = g["nc"], law.N
+    os.environ["JH_FUSED_PRODUCT"] = "1"   # opt-in (measured slower than apply + jagged SpMV, see jh_ilu.hip): read when the factors are laid out
+    try:
+        F = ja.ILUZeroPreconditioner(partition="blocks").update_preconditioner(lsys.jac)
+    finally:
+        os.environ.pop("JH_FUSED_PRODUCT", None)
+    info = F.info()
+    assert info["factor_kernel"] == "pivot-only" and info["fused_product"], info
+    perm, bp = disc.ordering()
+    p0 = perm - 1
+    part = np.zeros(nc, dtype=np.int64)
+    part[p0] = np.repeat(np.arange(1, len(bp)), np.diff(bp))
+    b = rng.standard_normal(nc * bs)
+    x, q = F.apply_mul(lsys.jac.new_vector(), lsys.jac.new_vector(), lsys.jac.new_vector(b))
+    x, q = x.download(), q.download()
+    # oracle in the device's elimination order (block rows permuted, blocks intact)
+    if bs == 1:
+        A = sp.csr_matrix((nz_o, osys.colidx - 1, osys.rowptr - 1), shape=(nc, nc))
+        Ap = A[p0][:, p0].tocsr()
+        Ap.sort_indices()
+        Fo = oracle.ILU0(nc, 1, Ap.indptr + 1, Ap.indices + 1, Ap.data, partition=part[p0])
+        x_o = np.zeros(nc)
+        x_o[p0] = Fo.apply(b[p0])
+    else:
+        blocks = nz_o.reshape(-1, bs, bs).transpose(0, 2, 1)          # column-major blocks -> [row, col]
+        A = sp.bsr_matrix((blocks, osys.colidx - 1, osys.rowptr - 1), shape=(nc * bs, nc * bs)).tocsr()
+        pat = sp.csr_matrix((np.arange(1, osys.colidx.size + 1), osys.colidx - 1, osys.rowptr - 1), shape=(nc, nc))
+        Pp = pat[p0][:, p0].tocsr()
+        Pp.sort_indices()
+        nz_p = nz_o.reshape(-1, bs * bs)[Pp.data - 1].reshape(-1)
+        Fo = oracle.ILU0(nc, bs, Pp.indptr + 1, Pp.indices + 1, nz_p, partition=part[p0])
+        x_o = np.zeros(nc * bs)
+        x_o.reshape(nc, bs)[p0] = Fo.apply(b.reshape(nc, bs)[p0].reshape(-1)).reshape(nc, bs)
+    q_o = oracle.spmv(nc, bs, osys.rowptr, osys.colidx, nz_o, x_o)
+    assert relerr(x, x_o) < 1e-10 and relerr(q, q_o) < 1e-10
+    # the product of the SAME x through the CSR kernel: pins the fused arithmetic itself at SpMV precision
+    q_csr = ja.mul_(lsys.jac.new_vector(), lsys.jac, lsys.jac.new_vector(x)).download()
+    assert relerr(q, q_csr) < 1e-12
+    # standalone apply on the column-scaled factors, factor export
+    assert relerr(F.apply(lsys.jac.new_vector(), lsys.jac.new_vector(b)).download(), x_o) < 1e-10
+    assert np.count_nonzero(F.factor_values()) > 0
+    # BiCGStab through the fused operator: same iterates as the two-operator path (environment switch read per solve)
+    sol = {}
+    for off in (False, True):
+        if off:
+            os.environ["JH_NO_FUSED_PRODUCT"] = "1"
+        try:
+            ks = ja.GenericKrylov("bicgstab", preconditioner=F, relative_tolerance=1e-9, max_iterations=300)
+            out = ja.linear_solve(lsys, ks, update_preconditioner=False)
+            sol[off] = (out["iterations"], out["residuals"], lsys.dx.download())
+        finally:
+            os.environ.pop("JH_NO_FUSED_PRODUCT", None)
+    assert abs(sol[False][0] - sol[True][0]) <= 1 and sol[False][0] > 3
+    assert relerr(sol[False][2], sol[True][2]) < 1e-7
+    k = min(len(sol[False][1]), len(sol[True][1]), 6)
+    assert np.allclose(sol[False][1][:k], sol[True][1][:k], rtol=1e-6)
+
+
 def test_device_blocks_come_from_graph_bisection(ja, ctx):
     """JH_REORDER_BLOCKS: the device blocks (= block-Jacobi ILU(0) partition, the job Metis does for the reference,
     precond/ilu.jl:37-60) are a valid partition into round(nc / block_rows) connected-looking compact blocks, none above the
