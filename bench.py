@@ -462,7 +462,7 @@ def main():
                                    f"{mesh_desc}, nf={nf_g}, 1 Newton iteration/step: "
                                    f"assembly + block-Jacobi ILU(0) factor + BiCGStab(rtol={args.rtol})",
                        "cells": nc_g, "faces": nf_g, "mesh": args.mesh, "law": args.law, "block_n": N, "dt": args.dt,
-                       "block_rows": args.block_rows or (256 if disc.nc < 2_000_000 else 512),
+                       "block_rows": args.block_rows or "library default", "ilu_max_block_rows": info["max_block_rows"],
                        "parallelism": f"dd{world}" if world > 1 else "single", "precond_side": ks.config.precond_side,
                        "path": args.path, "seams": seams_extra,
                        "launcher": os.environ.get("JH_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
@@ -498,16 +498,16 @@ def main():
         dist.destroy_process_group()
 
 
-def make_mesh(ja, args, cells=None):
+def make_mesh(ja, args, cells=None, scramble=True):
     cells = cells or args.cells
     if args.mesh == "delaunay":
-        m = ja.delaunay_tet_mesh(max(64, int(cells / 6.7)), grading=args.grading)
+        m = ja.delaunay_tet_mesh(max(64, int(cells / 6.7)), grading=args.grading, scramble=scramble)
         return m, f"Delaunay tet mesh of {m['points']} graded random points (grading {args.grading}, scrambled numbering)"
     if args.mesh == "polyhedral":
-        m = ja.polyhedral_dual_mesh(max(64, cells), grading=args.grading)
+        m = ja.polyhedral_dual_mesh(max(64, cells), grading=args.grading, scramble=scramble)
         return m, f"polyhedral median-dual grid of a Delaunay tet mesh ({m['points']} graded random points, grading {args.grading}, scrambled numbering)"
     nx, ny, nz = dims_for_cells(cells)
-    return ja.tet_lattice_mesh(nx, ny, nz), f"Kuhn-split tet lattice ({nx}x{ny}x{nz}x6, scrambled numbering)"
+    return ja.tet_lattice_mesh(nx, ny, nz, scramble=scramble), f"Kuhn-split tet lattice ({nx}x{ny}x{nz}x6, scrambled numbering)"
 
 
 def initial_state(np, law, nc):
@@ -598,56 +598,102 @@ def measured_traffic(kernel, args, cells, world):
 
 def cpu_baseline(args, nc_gpu):
     """The same step sequence (assemble -> ILU(0) refactor -> BiCGStab -> U <- U - x -> U0 <- U) as the GPU leg, same warm-up,
-    on the host cores with the oracle (OpenMP), on a bounded sample: a --cpu-cells grid of the same family, scaled by cells."""
+    on the host cores with the oracle (OpenMP restatement of Jutul's ParallelCSRContext path: 8-byte indices, one ILU(0) block per
+    thread, unfused threaded BLAS-1, workspace allocated once, pages first touched by the threads that use them), on a bounded
+    sample: a --cpu-cells grid of the same family, scaled by cells.  Two legs: the identical (scrambled) input numbering of the
+    GPU run, and the generator's natural numbering (what a mesh generator would hand Jutul: better locality on a CPU).  Plus
+    per-kernel times / GB/s with the reference's own byte counts, and the probe for a runnable Jutul (baseline B)."""
+    import shutil
     import numpy as np
     import jutul_amd as ja
     from jutul_amd import dd
     from oracle import oracle as o
     o.build()
-    m, _ = make_mesh(ja, args, args.cpu_cells)
-    nc = m["nc"]
-    N = 2 if args.law == "twophase" else 1
-    T = m["T"] / m["T"].mean()
-    U = initial_state(np, args.law, nc)
-    U0 = U.copy()
     threads = o.num_threads()
-    osys = o.TPFASystem(m["N"], nc, nblk=N)
+    N = 2 if args.law == "twophase" else 1
     p = LAW_PAR[args.law]
-    law = o.Law(args.law, args.dt, rho0=p["rho0"], comp=p["compressibility"], mu=p["viscosity"], p_ref=p["p_ref"])
-    # Jutul's CSR path uses block-Jacobi ILU(0) with one block per thread (precond/ilu.jl:37-60)
-    part = dd.partition_rcb(m["cell_centroids"], threads) if threads > 1 else None
-    src = source_values(np, args.law, [1.0, -1.0])
-    nz, r = osys.assemble(law, U, U0, m["volumes"], T, src_cells=[1, nc], src_values=src)
-    F = o.ILU0(nc, N, osys.rowptr, osys.colidx, nz, partition=part)
     itmax = 200 if N == 2 else 100
     lim = update_limits(np, args.law)
+    src = source_values(np, args.law, [1.0, -1.0])
 
-    def step():
-        nonlocal U, U0
-        nz, r = osys.assemble(law, U, U0, m["volumes"], T, src_cells=[1, nc], src_values=src)
-        F.refactor(nz)
-        x, st = o.bicgstab(nc, N, osys.rowptr, osys.colidx, nz, r, prec=F, side=args.precond_side, rtol=args.rtol, atol=1e-12,
-                           itmax=itmax)
-        U = apply_update(np, U, -x, lim)  # dx = -x (update_dx_from_vector!), U <- U + choose_increment(dx)
-        U0 = U.copy()    # state0 <- state
-        return st["iterations"]
+    def leg(scramble, seconds, kernels):
+        m, _ = make_mesh(ja, args, args.cpu_cells, scramble=scramble)
+        nc = m["nc"]
+        T = o.touch_copy(m["T"] / m["T"].mean())
+        vol = o.touch_copy(m["volumes"])
+        U = o.touch_copy(initial_state(np, args.law, nc))
+        U0 = o.touch_copy(U)
+        osys = o.TPFASystem(m["N"], nc, nblk=N)
+        osys.rowptr, osys.colidx = o.touch_copy(osys.rowptr), o.touch_copy(osys.colidx)
+        law = o.Law(args.law, args.dt, rho0=p["rho0"], comp=p["compressibility"], mu=p["viscosity"], p_ref=p["p_ref"])
+        # Jutul's CSR path uses block-Jacobi ILU(0) with one block per thread (precond/ilu.jl:37-60)
+        part = dd.partition_rcb(m["cell_centroids"], threads) if threads > 1 else None
+        nz, r = osys.assemble(law, U, U0, vol, T, src_cells=[1, nc], src_values=src)
+        F = o.ILU0(nc, N, osys.rowptr, osys.colidx, nz, partition=part)
+        state = dict(U=U, U0=U0)
 
-    wits = [step() for _ in range(args.warmup)]
-    t0 = time.perf_counter()
-    its = []
-    while True:
-        its.append(step())
-        el = time.perf_counter() - t0
-        if el > args.cpu_seconds or len(its) >= args.steps:
-            break
-    rate = len(its) / el
-    return {"value": round(rate * nc / nc_gpu, 5), "unit": "Newton iterations/s", "cores": threads, "kind": "port",
-            "linear_iterations_per_step": round(float(np.mean(its)), 2), "linear_iterations_first_steps": (wits + its)[:8],
-            "sample": f"steps {args.warmup + 1}..{args.warmup + len(its)} of the same sequence the GPU leg runs ({args.warmup} warm-up steps, "
-                      f"then {len(its)} timed: assembly + block-Jacobi ILU(0) refactor with {threads} blocks + BiCGStab rtol={args.rtol}, "
-                      f"{float(np.mean(its)):.1f} its/step + state update) on a {nc}-cell grid of the same family in {el:.1f}s = "
-                      f"{rate:.3f} it/s, scaled by cells {nc}/{nc_gpu} to the GPU grid; OpenMP restatement of "
-                      f"Jutul's ParallelCSRContext path (not Jutul itself)"}
+        def step():
+            nz, r = osys.assemble(law, state["U"], state["U0"], vol, T, src_cells=[1, nc], src_values=src)
+            F.refactor(nz)
+            x, st = o.bicgstab(nc, N, osys.rowptr, osys.colidx, nz, r, prec=F, side=args.precond_side, rtol=args.rtol, atol=1e-12,
+                               itmax=itmax)
+            state["U"] = apply_update(np, state["U"], -x, lim)  # dx = -x (update_dx_from_vector!), U <- U + choose_increment(dx)
+            state["U0"] = state["U"].copy()    # state0 <- state
+            return st["iterations"]
+
+        wits = [step() for _ in range(args.warmup)]
+        t0 = time.perf_counter()
+        its = []
+        while True:
+            its.append(step())
+            el = time.perf_counter() - t0
+            if el > seconds or len(its) >= args.steps:
+                break
+        out = dict(rate=len(its) / el, nc=nc, its=its, wits=wits, el=el)
+        if kernels:  # per-kernel CPU times on this leg's arrays, reference byte counts (Int64 indices: 16 nnz + 24 n for the SpMV)
+            nnz, nf = osys.nnzb, m["nf"]
+
+            def best(fn, reps=5):
+                ts = []
+                for _ in range(reps):
+                    t1 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t1)
+                return min(ts)
+            nz, r = osys.assemble(law, state["U"], state["U0"], vol, T, src_cells=[1, nc], src_values=src)
+            xk = o.touch_copy(np.random.default_rng(0).standard_normal(nc * N))
+            yk = np.zeros(nc * N)
+            t_asm = best(lambda: osys.assemble(law, state["U"], state["U0"], vol, T, src_cells=[1, nc], src_values=src), 3)
+            t_spmv = best(lambda: o.spmv(nc, N, osys.rowptr, osys.colidx, nz, xk, yk))
+            t_fac = best(lambda: F.refactor(nz), 3)
+            t_app = best(lambda: F.apply(xk))
+            NN = N * N
+            b_spmv = (8.0 * NN + 8) * nnz + (8 + 16.0 * N) * nc
+            # conn_data 32 B/half-face + position tables 8 NN B + flux/acc Duals + state: the reference's own layouts (SURVEY 8a)
+            b_asm = (32.0 + 8 * NN + 8.0 * N * (1 + 2 * N)) * 2 * nf + (8.0 * N * (1 + N) + 8 * NN + 24.0 * N + 8 * NN) * nc + 8.0 * NN * nnz
+            out["kernels"] = {
+                "assembly": {"ms": round(t_asm * 1e3, 3), "gbs": round(b_asm / t_asm / 1e9, 1)},
+                "spmv": {"ms": round(t_spmv * 1e3, 3), "gbs": round(b_spmv / t_spmv / 1e9, 1), "bytes_formula": "(8 N^2 + 8) nnz + (8 + 16 N) n (mat.jl:24-68, Int64 indices)"},
+                "ilu_factor": {"ms": round(t_fac * 1e3, 3)},
+                "ilu_apply": {"ms": round(t_app * 1e3, 3)},
+                "cells": nc, "note": "best of 3-5 repetitions on the sample grid, all host cores"}
+        return out
+
+    a = leg(True, args.cpu_seconds * 0.6, True)
+    b = leg(False, args.cpu_seconds * 0.4, False)
+    julia = shutil.which("julia")
+    return {"value": round(a["rate"] * a["nc"] / nc_gpu, 5), "unit": "Newton iterations/s", "cores": threads, "kind": "port",
+            "linear_iterations_per_step": round(float(np.mean(a["its"])), 2), "linear_iterations_first_steps": (a["wits"] + a["its"])[:8],
+            "value_natural_numbering": round(b["rate"] * b["nc"] / nc_gpu, 5),
+            "kernels": a["kernels"],
+            "jutul_itself": f"julia found at {julia}, but no build-owned Jutul run is wired: not executed" if julia else
+                            "absent: `command -v julia` finds nothing on this box (BASELINE.md baseline B not possible)",
+            "sample": f"steps {args.warmup + 1}..{args.warmup + len(a['its'])} of the same sequence the GPU leg runs ({args.warmup} warm-up steps, "
+                      f"then {len(a['its'])} timed: assembly + block-Jacobi ILU(0) refactor with {threads} blocks + BiCGStab rtol={args.rtol}, "
+                      f"{float(np.mean(a['its'])):.1f} its/step + state update) on a {a['nc']}-cell grid of the same family (same scrambled "
+                      f"numbering as the GPU input) in {a['el']:.1f}s = {a['rate']:.3f} it/s, scaled by cells {a['nc']}/{nc_gpu} to the GPU grid; "
+                      f"value_natural_numbering: the same on the generator's own cell numbering ({b['rate']:.3f} it/s on the sample); "
+                      f"OpenMP restatement of Jutul's ParallelCSRContext path (not Jutul itself)"}
 
 
 if __name__ == "__main__":

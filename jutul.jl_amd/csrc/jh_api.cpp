@@ -40,6 +40,8 @@ extern "C" int32_t jh_context_create(int32_t device_id, jh_context *out) {
     JH_HIP(hipHostMalloc((void **)&c->h_scalars, jh::JH_NSCALARS * sizeof(double), hipHostMallocDefault));
     JH_HIP(hipHostMalloc((void **)&c->h_pub, 2 * jh::JH_PUB_LEN * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->h_pub, 0, 2 * jh::JH_PUB_LEN * sizeof(double));
+    c->ticket.alloc(128);
+    JH_HIP(hipMemsetAsync(c->ticket.p, 0, 128 * sizeof(unsigned), c->stream));
     JH_HIP(hipHostMalloc((void **)&c->h_rd, jh::JH_NSCALARS * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->h_rd, 0, jh::JH_NSCALARS * sizeof(double));
     JH_HIP(hipStreamSynchronize(c->stream));
@@ -66,6 +68,7 @@ extern "C" int32_t jh_context_destroy(jh_context ctx) {
     }
     ctx->partials.release();
     ctx->scalars.release();
+    ctx->ticket.release();
     ctx->stage.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -1524,7 +1524,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       size_t bytes = sizeof(double) * bbv * (size_t)(mxl + mxu + maxrows) +
                      sizeof(uint16_t) * (size_t)(mxl + mxu + 3 * maxrows + 2 + maxlev + 2);
       bytes = (bytes + 15) & ~(size_t)15;
-      if (mxl < 65536 && mxu < 65536 && maxrows < 65536 && bytes <= LDS_CAP_BYTES && !getenv("JH_ILU_FACTOR_GLOBAL")) {
+      // (up to the 160 KB of a gfx950 CU with the opt-in attribute: blocks of long rows -- polyhedral cells -- stay off the
+      // global-memory factor kernels, which took 33 ms instead of ~1 ms on a 2M-cell polyhedral grid)
+      if (mxl < 65536 && mxu < 65536 && maxrows < 65536 && bytes <= 160 * 1024 - 1024 && !getenv("JH_ILU_FACTOR_GLOBAL")) {
         M->max_blk_l = (int)mxl;
         M->max_blk_u = (int)mxu;
         M->factor_lds_bytes = bytes;
@@ -1990,11 +1992,20 @@ void ilu_factor(jh_ilu M) {
     const int mr = (int)M->max_block_rows;
     // the bulk load/store phases want many lanes (memory-level parallelism); the level loop only needs a few
     static const int fthreads = getenv("JH_ILU_FACTOR_THREADS") ? atoi(getenv("JH_ILU_FACTOR_THREADS")) : 512;
+    if (M->factor_lds_bytes > 64 * 1024) {
+      const int fb = (int)M->factor_lds_bytes;
+      switch (M->bs) {
+        case 1: JH_HIP(hipFuncSetAttribute((const void *)ilu_factor_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, fb)); break;
+        case 2: JH_HIP(hipFuncSetAttribute((const void *)ilu_factor_lds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, fb)); break;
+        case 3: JH_HIP(hipFuncSetAttribute((const void *)ilu_factor_lds_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, fb)); break;
+      }
+    }
     switch (M->bs) {
       case 1: hipLaunchKernelGGL(ilu_factor_lds_kernel<1>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr, (int)M->max_levels); break;
       case 2: hipLaunchKernelGGL(ilu_factor_lds_kernel<2>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr, (int)M->max_levels); break;
       case 3: hipLaunchKernelGGL(ilu_factor_lds_kernel<3>, dim3((unsigned)nb), dim3(fthreads), M->factor_lds_bytes, s, F, aval, M->max_blk_l, M->max_blk_u, mr, (int)M->max_levels); break;
     }
+    JH_HIP(hipGetLastError());
     if (M->jag) ilu_to_jagged(M);
     M->factored = true;
     return;

@@ -11,6 +11,7 @@
 #include "jh_internal.hpp"
 
 namespace jh {
+int comm_size(jh_context ctx);
 
 __device__ __forceinline__ int xcd_tile(int b, int ntiles) {
   // workgroup b runs on XCD b % 8 (observed placement, performance only): give each XCD a contiguous chunk
@@ -533,6 +534,17 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_pipe_kernel(const int32_t *
 }
 
 // second stage of a fused SpMV dot; with dot->allreduce also over the ranks (same launch if the mailboxes are on)
+// TailArgs for a reduction of `count` doubles into `out` (summed over the ranks if allreduce): usable on one rank, or when the
+// mailboxes carry the scalar all-reduces (an RCCL all-reduce cannot run inside a kernel).  The caller decides whether it pays.
+bool tail_args(jh_context ctx, int count, double *out, bool allreduce, TailArgs *t) {
+  if (!ctx->ticket.p) return false;
+  TailArgs a;
+  a.tick = ctx->ticket.p;
+  a.out = out;
+  if (allreduce && comm_size(ctx) > 1 && !comm_mail_args(ctx, count, &a.mail)) return false;
+  *t = a;
+  return true;
+}
 void spmv_dot_reduce(jh_context ctx, const SpmvDot *dot, int nparts, const double *done) {
   const int cnt = dot->mode == 2 ? 2 : 1;
   MailArgs ma;

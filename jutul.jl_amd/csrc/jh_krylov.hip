@@ -107,10 +107,12 @@ __global__ void bicg_publish_kernel(double *sc, int pair_slot, double eps, doubl
 }
 // fused: x_out = x_in + alpha*y + omega*z ; r = s - omega*t ; partial sums of <c,r> and <r,r> over the first nd entries.
 // x ping-pongs between two buffers so that the iterate of iteration k survives the speculatively enqueued iteration k+1.
+// tail.tick != nullptr: the last workgroup to arrive also runs the second reduction stage -- (rho_next, ||r||^2) -> sc[out_slot..+1],
+// all-reduce over the ranks through the mailboxes, stopping test and the iteration's record (what bicg_reduce_publish_kernel does)
 __global__ __launch_bounds__(256) void bicg_xr_dots_kernel(const double *x_in, double *x_out, double *r, const double *y, const double *z,
-                                                           const double *s, const double *t, const double *c, const double *sc,
+                                                           const double *s, const double *t, const double *c, double *sc,
                                                            int rho_slot, int64_t n, int64_t nd, double *part, size_t stride,
-                                                           const double *done) {
+                                                           const double *done, TailArgs tail, int out_slot, double eps, double *rec, double seq) {
   if (done && *done != 0.0) return;
   __shared__ double sm[4];
   const double alpha = sc[rho_slot] / sc[S_CV];
@@ -131,11 +133,20 @@ __global__ __launch_bounds__(256) void bicg_xr_dots_kernel(const double *x_in, d
   for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); d1 += __shfl_down(d1, off, 64); }
   if (lane == 0) sm[w] = d0;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  const double p0 = (sm[0] + sm[1]) + (sm[2] + sm[3]);
   __syncthreads();
   if (lane == 0) sm[w] = d1;
   __syncthreads();
-  if (threadIdx.x == 0) part[stride + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  const double p1 = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  if (threadIdx.x == 0) {
+    if (tail.tick) { tail_store(part + blockIdx.x, p0); tail_store(part + stride + blockIdx.x, p1); }
+    else { part[blockIdx.x] = p0; part[stride + blockIdx.x] = p1; }
+  }
+  if (tail.tick && tail_arrive(tail.tick, gridDim.x)) {
+    tail_reduce<false, 256>(part, stride, (int)gridDim.x, 2, sc + out_slot);
+    if (tail.mail.self) mailbox_allreduce_body(tail.mail, sc + out_slot, 2, 0);
+    if (rec && threadIdx.x == 0) publish_record(sc, out_slot, eps, rec, seq);
+  }
 }
 // second stage of the reduction above: (rho_next, ||r||^2) -> sc[out_slot..+1]; without a communicator the same launch
 // publishes the iteration's record (otherwise bicg_publish_kernel does, after the all-reduce)
@@ -287,14 +298,22 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     if (jagged) {
       // the event pair brackets the product kernel alone (what rocprofv3 reports for it); the second stage of its fused dot,
       // with the all-reduce over the ranks, follows
-      const int nparts = k_spmv_sell(K->A, in, out, 1.0, 0.0, dot, done, false);
+      TailArgs ta;
+      const bool tail = tail_pays && dot && dot->mode && tail_args(ctx, dot->mode == 2 ? 2 : 1, sc + dot->slot, dot->allreduce, &ta);
+      const int nparts = k_spmv_sell(K->A, in, out, 1.0, 0.0, dot, done, false, tail ? &ta : nullptr);
       K->mark(0, st);
-      if (dot && dot->mode) spmv_dot_reduce(ctx, dot, nparts, done);
+      if (dot && dot->mode && !tail) spmv_dot_reduce(ctx, dot, nparts, done);
       return;
     }
     k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done);  // dot->allreduce: summed over the ranks in there
     K->mark(0, st);
   };
+  // Second reduction stage inside the producing kernel (TailArgs) instead of a one-workgroup launch: measured on MI355X
+  // (profiles/r03_tail_reduce_*): 10M cells +1.5 % Newton it/s (the 2048 arrivals spread over a 180 us kernel); 1.25M cells
+  // -21 % -- the workgroups of a 28 us kernel all arrive within a few microseconds and the memory-side arrival counters cost
+  // ~0.25 us per contended increment (SpMV 27.9 -> 43.6 us).  Hence only for long kernels; JH_TAIL_REDUCE=0 / 1 forces it.
+  static const int tail_force = getenv("JH_TAIL_REDUCE") ? atoi(getenv("JH_TAIL_REDUCE")) : -1;
+  const bool tail_pays = tail_force >= 0 ? tail_force != 0 : n >= 3000000;
   K->cur_it = 0;
   ensure_partials(ctx, 4096);
   if (!dist && !left && comm_size(ctx) == 1) {  // (several ranks without a halo plan still all-reduce every dot)
@@ -449,13 +468,16 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     double *rec = ctx->h_pub + (k & 1) * JH_PUB_LEN;
     dim3 g = vgrid(n);
     // (rho_next, ||r||^2) -> the other pair; without a communicator the kernel also publishes the record
+    TailArgs ta;
+    const bool tail = tail_pays && tail_args(ctx, 2, sc + rn, true, &ta);  // one rank, or mailboxes on: second stage, all-reduce and publish in the kernel itself
     hipLaunchKernelGGL(bicg_xr_dots_kernel, g, dim3(256), 0, st, xin, xout, K->r.p, yy, zz, K->s.p, tt, K->c.p, sc, rs, n, nd,
-                       ctx->partials.p, ctx->partial_stride, done);
+                       ctx->partials.p, ctx->partial_stride, done, tail ? ta : TailArgs(), rn, eps_at(k), tail ? rec : (double *)nullptr, seq);
     MailArgs ma;
-    const bool fused_ar = comm_mail_args(ctx, 2, &ma);  // mailboxes on: all-reduce + publish in the reduction launch itself
-    hipLaunchKernelGGL(bicg_reduce_publish_kernel, dim3(1), dim3(FIN_THREADS), 0, st, ctx->partials.p, ctx->partial_stride, (int)g.x,
-                       sc, rn, done, eps_at(k), (ctx->comm && !fused_ar) ? nullptr : rec, seq, fused_ar ? ma : MailArgs());
-    if (ctx->comm && !fused_ar) {
+    const bool fused_ar = !tail && comm_mail_args(ctx, 2, &ma);  // mailboxes on: all-reduce + publish in the reduction launch itself
+    if (!tail)
+      hipLaunchKernelGGL(bicg_reduce_publish_kernel, dim3(1), dim3(FIN_THREADS), 0, st, ctx->partials.p, ctx->partial_stride, (int)g.x,
+                         sc, rn, done, eps_at(k), (ctx->comm && !fused_ar) ? nullptr : rec, seq, fused_ar ? ma : MailArgs());
+    if (!tail && ctx->comm && !fused_ar) {
       comm_allreduce_dev(ctx, sc + rn, 2, 0);
       // the record needs the all-reduced pair: it is published by the first kernel of the next iteration (fused ILU gather)
       // when there is one, otherwise by a one-thread kernel

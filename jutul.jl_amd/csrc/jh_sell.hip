@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void spmv_jds_kernel(const int32_t *__restrict
                                                        const double *__restrict__ jval, int nslices, int nrows,
                                                        const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
                                                        const double *__restrict__ dw, int dot_rows, double *__restrict__ part,
-                                                       size_t pstride, const double *done) {
+                                                       size_t pstride, const double *done, TailArgs tail) {
   if (done && *done != 0.0) return;
   __shared__ double tr[4][64];
   __shared__ double red[8];
@@ -208,8 +208,13 @@ __global__ __launch_bounds__(256) void spmv_jds_kernel(const int32_t *__restrict
     if (lane == 0) { red[w] = d0; red[4 + w] = d1; }
     __syncthreads();
     if (tid == 0) {
-      part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-      if (DOT == 2) part[pstride + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
+      const double p0 = (red[0] + red[1]) + (red[2] + red[3]), p1 = (red[4] + red[5]) + (red[6] + red[7]);
+      if (tail.tick) { tail_store(part + blockIdx.x, p0); if (DOT == 2) tail_store(part + pstride + blockIdx.x, p1); }
+      else { part[blockIdx.x] = p0; if (DOT == 2) part[pstride + blockIdx.x] = p1; }
+    }
+    if (tail.tick && tail_arrive(tail.tick, gridDim.x)) {  // second stage here: no one-workgroup kernel behind every product
+      tail_reduce<false, 256>(part, pstride, (int)gridDim.x, DOT == 2 ? 2 : 1, tail.out);
+      if (tail.mail.self) mailbox_allreduce_body(tail.mail, tail.out, DOT == 2 ? 2 : 1, 0);
     }
   }
 }
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256) void spmv_jds16_kernel(const int32_t *__restri
                                                          const double *__restrict__ jval, int nslices, int nrows,
                                                          const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
                                                          const double *__restrict__ dw, int dot_rows, double *__restrict__ part,
-                                                         size_t pstride, const double *done) {
+                                                         size_t pstride, const double *done, TailArgs tail) {
   if (done && *done != 0.0) return;
   __shared__ double tr[4][64];
   __shared__ double red[8];
@@ -321,8 +326,13 @@ __global__ __launch_bounds__(256) void spmv_jds16_kernel(const int32_t *__restri
     if (lane == 0) { red[w] = d0; red[4 + w] = d1; }
     __syncthreads();
     if (tid == 0) {
-      part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-      if (DOT == 2) part[pstride + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
+      const double p0 = (red[0] + red[1]) + (red[2] + red[3]), p1 = (red[4] + red[5]) + (red[6] + red[7]);
+      if (tail.tick) { tail_store(part + blockIdx.x, p0); if (DOT == 2) tail_store(part + pstride + blockIdx.x, p1); }
+      else { part[blockIdx.x] = p0; if (DOT == 2) part[pstride + blockIdx.x] = p1; }
+    }
+    if (tail.tick && tail_arrive(tail.tick, gridDim.x)) {  // second stage here: no one-workgroup kernel behind every product
+      tail_reduce<false, 256>(part, pstride, (int)gridDim.x, DOT == 2 ? 2 : 1, tail.out);
+      if (tail.mail.self) mailbox_allreduce_body(tail.mail, tail.out, DOT == 2 ? 2 : 1, 0);
     }
   }
 }
@@ -345,7 +355,8 @@ bool sell_refresh(jh_csr A) {
 }
 
 // reduce_now = false: the caller launches the second stage of the fused dot itself (spmv_dot_reduce with the returned count)
-int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done, bool reduce_now) {
+int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done, bool reduce_now,
+                const TailArgs *tail) {
   jh_context ctx = A->ctx;
   const Pattern &P = *A->pat;
   const auto &J = P.jag;
@@ -359,13 +370,14 @@ int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta,
   if (mode) ensure_partials(ctx, (size_t)grid.x);
   const double *dw = dot ? dot->w : nullptr;
   const int drows = dot ? (int)dot->n_rows : 0;
+  const TailArgs ta = (mode && tail) ? *tail : TailArgs();
 #define JH_JDS(KU, DV)                                                                                                          \
   hipLaunchKernelGGL((spmv_jds_kernel<KU, DV>), grid, block, 0, ctx->stream, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), \
-                     J.d_perm.p, J.d_col.p, A->jval.p, J.nslices, (int)P.n, x, y, alpha, beta, dw, drows, ctx->partials.p, ctx->partial_stride, done)
+                     J.d_perm.p, J.d_col.p, A->jval.p, J.nslices, (int)P.n, x, y, alpha, beta, dw, drows, ctx->partials.p, ctx->partial_stride, done, ta)
 #define JH_JDS16(KU, DV)                                                                                                        \
   hipLaunchKernelGGL((spmv_jds16_kernel<KU, DV>), grid, block, 0, ctx->stream, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), \
                      J.d_perm.p, J.d_col16.p, reinterpret_cast<const int2 *>(J.d_win.p), J.d_far.p, A->jval.p, J.nslices, (int)P.n, x, y, \
-                     alpha, beta, dw, drows, ctx->partials.p, ctx->partial_stride, done)
+                     alpha, beta, dw, drows, ctx->partials.p, ctx->partial_stride, done, ta)
   if (J.d_col.n == 0) {  // 16-bit column codes (default)
     if (J.kmax <= 5) {
       if (mode == 0) JH_JDS16(5, 0); else if (mode == 1) JH_JDS16(5, 1); else JH_JDS16(5, 2);
@@ -379,7 +391,7 @@ int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta,
   }
 #undef JH_JDS
 #undef JH_JDS16
-  if (mode && reduce_now) spmv_dot_reduce(ctx, dot, (int)grid.x, done);
+  if (mode && reduce_now && !ta.tick) spmv_dot_reduce(ctx, dot, (int)grid.x, done);
   return (int)grid.x;
 }
 

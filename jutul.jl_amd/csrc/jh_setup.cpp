@@ -490,7 +490,14 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
     } else if (reorder == JH_REORDER_BLOCKS) {
       // default: 512-row blocks; below ~2M rows the ILU(0) apply is bound by per-block latency, not bandwidth, and twice
       // as many half-size blocks fill the chip better (1.25M cells: apply 48 -> 40 us at equal iteration counts)
-      if (block_rows <= 0) block_rows = nc < 2000000 ? 256 : 512;
+      if (block_rows <= 0) {
+        block_rows = nc < 2000000 ? 256 : 512;
+        // The defaults are sized for tet / hex grids (<= 6 faces per cell: ~2500 entries per block).  Cells with many faces
+        // (polyhedral / PEBI grids) get proportionally fewer rows per block, so that a block's factors and dependency levels
+        // stay within what one workgroup holds in LDS.
+        const double deg = nc > 0 ? (double)A.ptr[nc] / (double)nc : 0.0;
+        if (deg > 7.0) block_rows = std::max<int64_t>(64, (int64_t)(block_rows * 6.0 / deg) / 32 * 32);
+      }
       order_blocks(A, nc, n_owned, block_rows, pat->perm, pat->block_ptr, pat->interior_rows, pat->interior_blocks);
     } else if (reorder != JH_REORDER_NONE) {
       JH_THROW("unknown reorder mode");

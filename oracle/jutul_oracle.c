@@ -690,8 +690,10 @@ int jo_spmv(I64 n, int bs, const I64 *rowptr, const I64 *colidx, const double *n
             double *y, double alpha, double beta) {
   int do_inc = 1;
   if (beta == 0.0) do_inc = 0;
-  else if (beta != 1.0)
+  else if (beta != 1.0) {
+#pragma omp parallel for schedule(static)
     for (I64 i = 0; i < n * bs; ++i) y[i] *= beta; /* rmul!(y, beta) mat.jl:35 */
+  }
   if (bs == 1) {
 #pragma omp parallel for schedule(static)
     for (I64 row = 1; row <= n; ++row) {
@@ -1039,20 +1041,48 @@ static double dotp(I64 n, const double *a, const double *b) {
 /* side: 0 none, 1 left (M = prec), 2 right (N = prec; Jutul single-process default, linsolve/utils.jl:25).
  * History: ||r_k|| for k = 0..iters (length iters+1).  Returns: 0 solved, 1 itmax, 2 breakdown.
  * x0 = 0, c = r0 (shadow), stop on ||r|| <= atol + rtol*||r0||. */
+/* Workspace of the Krylov solvers: ten vectors kept between solves (Krylov.jl's BicgstabSolver workspace is allocated once,
+ * linsolve/krylov.jl:27-58), pages first touched by the threads that work on them. */
+static double *ws_buf = NULL;
+static I64 ws_len = 0;
+static double *ws_get(I64 m) {
+  if (ws_len != m) {
+    free(ws_buf);
+    ws_buf = (double *)malloc((size_t)(10 * m) * sizeof(double));
+    ws_len = ws_buf ? m : 0;
+    if (ws_buf)
+      for (int k = 0; k < 10; ++k) {
+        double *w = ws_buf + (size_t)k * m;
+#pragma omp parallel for schedule(static)
+        for (I64 i = 0; i < m; ++i) w[i] = 0.0;
+      }
+  }
+  return ws_buf;
+}
+static void vcopy(I64 m, double *dst, const double *src) {
+#pragma omp parallel for schedule(static)
+  for (I64 i = 0; i < m; ++i) dst[i] = src[i];
+}
+/* y = a*x + b*y (the solver's kaxpy! / kaxpby! calls: BLAS level 1 on all cores, as OpenBLAS runs them for Jutul) */
+static void vaxpby(I64 m, double a, const double *x, double b, double *y) {
+#pragma omp parallel for schedule(static)
+  for (I64 i = 0; i < m; ++i) y[i] = a * x[i] + b * y[i];
+}
+
 int jo_bicgstab(I64 n, int bs, const I64 *rowptr, const I64 *colidx, const double *nz, const jo_ilu_par *P,
                 int side, const double *b, double *x, double rtol, double atol, I64 itmax, I64 *iters_out,
                 double *hist, I64 hist_cap) {
   I64 m = n * bs;
-  double *r = (double *)calloc((size_t)m, sizeof(double)), *p = (double *)calloc((size_t)m, sizeof(double));
-  double *v = (double *)calloc((size_t)m, sizeof(double)), *s = (double *)calloc((size_t)m, sizeof(double));
-  double *q = (double *)calloc((size_t)m, sizeof(double)), *y = (double *)calloc((size_t)m, sizeof(double));
-  double *z = (double *)calloc((size_t)m, sizeof(double)), *t = (double *)calloc((size_t)m, sizeof(double));
-  double *d = (double *)calloc((size_t)m, sizeof(double)), *c = (double *)calloc((size_t)m, sizeof(double));
+  double *ws = ws_get(m);
+  if (!ws) return -1;
+  double *r = ws, *p = ws + m, *v = ws + 2 * m, *s = ws + 3 * m, *q = ws + 4 * m, *y = ws + 5 * m, *z = ws + 6 * m, *t = ws + 7 * m,
+         *d = ws + 8 * m, *c = ws + 9 * m;
   int left = (side == 1 && P), right = (side == 2 && P);
+#pragma omp parallel for schedule(static)
   for (I64 i = 0; i < m; ++i) x[i] = 0.0;
-  if (left) jo_ilu0_apply(P, r, b); else memcpy(r, b, sizeof(double) * m); /* r0 = M^-1 b */
-  memcpy(p, r, sizeof(double) * m);
-  memcpy(c, r, sizeof(double) * m); /* c = r0 */
+  if (left) jo_ilu0_apply(P, r, b); else vcopy(m, r, b); /* r0 = M^-1 b */
+  vcopy(m, p, r);
+  vcopy(m, c, r); /* c = r0 */
   double rho = dotp(m, c, r);
   double rnorm = sqrt(dotp(m, r, r));
   double eps = atol + rtol * rnorm;
@@ -1067,10 +1097,11 @@ int jo_bicgstab(I64 n, int bs, const I64 *rowptr, const I64 *colidx, const doubl
     if (right) { jo_ilu0_apply(P, y, p); yy = y; }
     jo_spmv(n, bs, rowptr, colidx, nz, yy, q, 1.0, 0.0);
     const double *vv = q;
-    if (left) { jo_ilu0_apply(P, v, q); vv = v; } else { memcpy(v, q, sizeof(double) * m); vv = v; }
+    if (left) { jo_ilu0_apply(P, v, q); vv = v; } else { vcopy(m, v, q); vv = v; }
     double alpha = rho / dotp(m, c, vv);
-    for (I64 i = 0; i < m; ++i) s[i] = r[i] - alpha * vv[i];
-    for (I64 i = 0; i < m; ++i) x[i] += alpha * yy[i];
+    vcopy(m, s, r);
+    vaxpby(m, -alpha, vv, 1.0, s);  /* s = r - alpha*v */
+    vaxpby(m, alpha, yy, 1.0, x);   /* x = x + alpha*y */
     const double *zz = s;
     if (right) { jo_ilu0_apply(P, z, s); zz = z; }
     jo_spmv(n, bs, rowptr, colidx, nz, zz, d, 1.0, 0.0);
@@ -1079,11 +1110,13 @@ int jo_bicgstab(I64 n, int bs, const I64 *rowptr, const I64 *colidx, const doubl
     double ttn = dotp(m, tt, tt);
     /* 0/0 guard for an exact first half-step (s == 0): Krylov.jl's formula would give NaN */
     double omega = (ttn == 0.0) ? 0.0 : dotp(m, tt, s) / ttn;
-    for (I64 i = 0; i < m; ++i) x[i] += omega * zz[i];
-    for (I64 i = 0; i < m; ++i) r[i] = s[i] - omega * tt[i];
+    vaxpby(m, omega, zz, 1.0, x);   /* x = x + omega*z */
+    vcopy(m, r, s);
+    vaxpby(m, -omega, tt, 1.0, r);  /* r = s - omega*t */
     double rho_next = dotp(m, c, r);
     double beta = (rho_next / rho) * (alpha / omega);
-    for (I64 i = 0; i < m; ++i) p[i] = r[i] + beta * (p[i] - omega * vv[i]);
+    vaxpby(m, -omega, vv, 1.0, p);  /* p = p - omega*v */
+    vaxpby(m, 1.0, r, beta, p);     /* p = r + beta*p */
     rho = rho_next;
     rnorm = sqrt(dotp(m, r, r));
     if (hist && it < hist_cap) hist[it] = rnorm;
@@ -1093,8 +1126,15 @@ int jo_bicgstab(I64 n, int bs, const I64 *rowptr, const I64 *colidx, const doubl
   if (!solved && status == 0 && it >= itmax) status = 1;
   if (solved) status = 0;
   *iters_out = it;
-  free(r); free(p); free(v); free(s); free(q); free(y); free(z); free(t); free(d); free(c);
   return status;
+}
+
+/* dst = src on all cores: used to hand the solver arrays whose pages are spread over the NUMA nodes like the loops that read
+ * them (first touch), the way Julia's threaded initialisation would */
+int jo_touch_copy(I64 nbytes8, double *dst, const double *src) {
+#pragma omp parallel for schedule(static)
+  for (I64 i = 0; i < nbytes8; ++i) dst[i] = src[i];
+  return 0;
 }
 
 /* GMRES (Krylov.jl 0.9 `gmres!`, third-party, restated from its published algorithm: MGS Arnoldi + Givens rotations,

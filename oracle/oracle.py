@@ -453,6 +453,15 @@ def unit_diagonalize(n, n_self, bs, rowptr, colidx, nz, r):
     return nz, r
 
 
+def touch_copy(a):
+    """Copy of a float64 / int64 array whose pages are first touched by the OpenMP threads (static schedule), not by numpy."""
+    a = np.ascontiguousarray(a)
+    assert a.dtype.itemsize == 8
+    out = np.empty_like(a)
+    lib().jo_touch_copy(C.c_int64(a.size), out.ctypes.data_as(C.POINTER(C.c_double)), a.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
 def set_num_threads(n):
     lib().jo_set_num_threads(C.c_int(n))
 
