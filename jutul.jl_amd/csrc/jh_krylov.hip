@@ -271,6 +271,12 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     comm_allreduce_dev(ctx, sc + slot, c2 ? 2 : 1, 0);
   };
   const int64_t rows_dot = nd / P.bs;
+  // Second reduction stage inside the producing kernel (TailArgs) instead of a one-workgroup launch: measured on MI355X
+  // (profiles/r03_tail_reduce_*): 10M cells +1.5 % Newton it/s (the 2048 arrivals spread over a 180 us kernel); 1.25M cells
+  // -21 % -- the workgroups of a 28 us kernel all arrive within a few microseconds and the memory-side arrival counters cost
+  // ~0.25 us per contended increment (SpMV 27.9 -> 43.6 us).  Hence only for long kernels; JH_TAIL_REDUCE=0 / 1 forces it.
+  static const int tail_force = getenv("JH_TAIL_REDUCE") ? atoi(getenv("JH_TAIL_REDUCE")) : -1;
+  const bool tail_pays = tail_force >= 0 ? tail_force != 0 : n >= 3000000;
   // Right preconditioning with column-scaled pivot-only factors: every product of the loop is A * (M^-1 v), and its in-block part
   // is formed inside the apply (ilu_apply_mul); the out-of-block entries -- ghost columns among them, hence after the ghost
   // exchange -- follow in ilu_eprod.  No SpMV launch, no jagged copy of the matrix.
@@ -308,12 +314,6 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done);  // dot->allreduce: summed over the ranks in there
     K->mark(0, st);
   };
-  // Second reduction stage inside the producing kernel (TailArgs) instead of a one-workgroup launch: measured on MI355X
-  // (profiles/r03_tail_reduce_*): 10M cells +1.5 % Newton it/s (the 2048 arrivals spread over a 180 us kernel); 1.25M cells
-  // -21 % -- the workgroups of a 28 us kernel all arrive within a few microseconds and the memory-side arrival counters cost
-  // ~0.25 us per contended increment (SpMV 27.9 -> 43.6 us).  Hence only for long kernels; JH_TAIL_REDUCE=0 / 1 forces it.
-  static const int tail_force = getenv("JH_TAIL_REDUCE") ? atoi(getenv("JH_TAIL_REDUCE")) : -1;
-  const bool tail_pays = tail_force >= 0 ? tail_force != 0 : n >= 3000000;
   K->cur_it = 0;
   ensure_partials(ctx, 4096);
   if (!dist && !left && comm_size(ctx) == 1) {  // (several ranks without a halo plan still all-reduce every dot)
