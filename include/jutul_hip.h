@@ -316,7 +316,7 @@ int32_t jh_comm_init_ipc_only(jh_context ctx, int32_t nranks, int32_t rank);
  * out8: [0] ranks of the communicator (1 without one), [1] this rank, [2] ranks RCCL counts in its communicator
  * (ncclCommCount; 0 = no RCCL communicator), [3] 1 = scalar all-reduces through the mailboxes, [4] 1 = ghost exchanges through
  * the host callback, [5] 1 = in-process backend, [6] waits that timed out so far, [7] time limit of a wait in seconds.
- * Waits inside the mailbox all-reduce / push halo are time-limited (JH_COMM_TIMEOUT_S, default 30; 0 = unbounded): when a
+ * Waits inside the mailbox all-reduce / push halo are time-limited (JH_COMM_TIMEOUT_S, default 600; 0 = unbounded): when a
  * peer never arrives, the running solve fails with a jh_last_error message naming this rank, the missing peer and the
  * epoch, instead of hanging every rank of the node. */
 int32_t jh_comm_info(jh_context ctx, int64_t *out8);

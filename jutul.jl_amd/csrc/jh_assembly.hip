@@ -85,6 +85,26 @@ template <int NP> __device__ __forceinline__ Dual<NP> density(const LawPar &P, i
   return P.rho0[ph] * dexp(P.comp[ph] * (p - dconst<NP>(P.p_ref)));  // rho0*exp(c*(p-p0))
 }
 
+// the same density from E = exp(c*(p - p0)) evaluated once per cell (twophase_exp_kernel): identical operations on identical
+// inputs, hence the same bits as density()
+template <int NP> __device__ __forceinline__ Dual<NP> density_from_exp(const LawPar &P, int ph, double E, int var) {
+  Dual<NP> a = dconst<NP>(0.0);  // c * (p - p0): only its partials are needed
+  a.d[var] = P.comp[ph] * 1.0;
+  Dual<NP> r; r.v = E;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) r.d[i] = E * a.d[i];
+  return P.rho0[ph] * r;
+}
+// E[2c + ph] = exp(comp[ph] * (p_c - p_ref)): the four software fp64 exponentials per entry of the two-phase flux become
+// four loads (per-cell property pre-pass; 32 B per cell of extra traffic against ~16 exp evaluations per cell)
+__global__ void twophase_exp_kernel(const double *__restrict__ X, double *__restrict__ E, int64_t nc, LawPar par) {
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
+    const double p = X[2 * c];
+    E[2 * c] = exp(par.comp[0] * (p - par.p_ref));
+    E[2 * c + 1] = exp(par.comp[1] * (p - par.p_ref));
+  }
+}
+
 // flux of the scalar laws across one half-face with its derivatives w.r.t. the self / other primary variable (shared by the
 // tile kernel and its pipelined variant)
 template <int KIND>
@@ -106,12 +126,12 @@ __device__ __forceinline__ void flux_scalar(double Us, double Uo, double T, doub
   }
 }
 // ---- the kernel -------------------------------------------------------------------------------------------------
-template <int KIND>
+template <int KIND, bool PRE = false>
 __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
     const int32_t *__restrict__ tile_row, int ntiles, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const int32_t *__restrict__ diag, const double *__restrict__ Tnz, const double *__restrict__ gnz, const double *__restrict__ X,
     const double *__restrict__ X0, double *__restrict__ nz, double *__restrict__ r, double dt, LawPar par, int reg_row,
-    int nrows_total) {
+    int nrows_total, const double *__restrict__ Eexp) {
   constexpr int N = (KIND == JH_LAW_TWOPHASE) ? 2 : 1;
   constexpr int NN = N * N;
   constexpr int TNNZ = (N == 1) ? TILE_NNZ : TILE_NNZ / 2;  // tile entry budget (Pattern::build_tiles)
@@ -184,9 +204,17 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
       Dual<4> ps = dvar<4>(xs[(own + lr) * 2], 0), ss_w = dvar<4>(xs[(own + lr) * 2 + 1], 1);
       Dual<4> po = dvar<4>(inl ? xs[cw * 2] : X[(size_t)c * 2], 2);
       Dual<4> so_w = dvar<4>(inl ? xs[cw * 2 + 1] : X[(size_t)c * 2 + 1], 3);
+      // exp(c (p - p0)) of both cells and both phases: from the per-cell pre-pass (own rows: consecutive, served by the vector
+      // L1; neighbours: one 16-byte gather next to the 16-byte gather of their primary variables)
+      double Es[2], Eo[2];
+      if (PRE) {
+        const double2 es = reinterpret_cast<const double2 *>(Eexp)[r0 + lr], eo = reinterpret_cast<const double2 *>(Eexp)[c];
+        Es[0] = es.x; Es[1] = es.y; Eo[0] = eo.x; Eo[1] = eo.y;
+      }
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph) {
-        Dual<4> rs = density(par, ph, ps), ro = density(par, ph, po);
+        Dual<4> rs = PRE ? density_from_exp<4>(par, ph, Es[ph], 0) : density(par, ph, ps);
+        Dual<4> ro = PRE ? density_from_exp<4>(par, ph, Eo[ph], 2) : density(par, ph, po);
         Dual<4> ravg = 0.5 * (rs + ro);
         Dual<4> dphi = (ps - po) + gz * ravg;
         Dual<4> ss = ph == 0 ? ss_w : dconst<4>(1.0) - ss_w;
@@ -234,8 +262,8 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
         Dual<4> p = dvar<4>(xs[(own + tid) * 2], 0), sw = dvar<4>(xs[(own + tid) * 2 + 1], 1);
         Dual<4> so = dconst<4>(1.0) - sw;
         const double p0 = X0[(size_t)row * 2], sw0 = X0[(size_t)row * 2 + 1];
-        Dual<4> Mw = vol * (density(par, 0, p) * sw);
-        Dual<4> Mo = vol * (density(par, 1, p) * so);
+        Dual<4> Mw = vol * ((PRE ? density_from_exp<4>(par, 0, Eexp[(size_t)row * 2], 0) : density(par, 0, p)) * sw);
+        Dual<4> Mo = vol * ((PRE ? density_from_exp<4>(par, 1, Eexp[(size_t)row * 2 + 1], 0) : density(par, 1, p)) * so);
         double Mw0 = vol * (density(par, 0, dconst<4>(p0)).v * sw0);
         double Mo0 = vol * (density(par, 1, dconst<4>(p0)).v * (1.0 - sw0));
         Dual<4> aw = ddiv(Mw - dconst<4>(Mw0), dt), ao = ddiv(Mo - dconst<4>(Mo0), dt);
@@ -454,7 +482,18 @@ void k_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
   int chunk = (P.ntiles + NUM_XCD - 1) / NUM_XCD;
   dim3 grid(chunk * NUM_XCD), block(TILE_THREADS);
   const double *g = L->has_gdz ? L->gnz.p : nullptr;
-#define JH_ASM_ARGS P.d_tile_desc.p, P.ntiles, P.d_rowptr.p, P.d_col.p, P.d_diag.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row, (int)P.n
+  const double *Eexp = nullptr;
+  // Per-cell exp pre-pass for the two-phase law: measured on MI355X, 5M cells (profiles/r03_twophase_prepass_*): assembly 0.515 ->
+  // 0.579 ms (pre-pass launch included) -- the 16-byte gathers that replace the exponentials cost more than the exponentials.
+  // Opt-in (JH_ASM_PREPASS=1).
+  static const bool prepass = getenv("JH_ASM_PREPASS") != nullptr;
+  if (L->kind == JH_LAW_TWOPHASE && prepass) {
+    if (L->Eexp.n < (size_t)P.n * 2) L->Eexp.alloc((size_t)P.n * 2);
+    hipLaunchKernelGGL(twophase_exp_kernel, dim3((unsigned)std::min<int64_t>((P.n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, L->X.p,
+                       L->Eexp.p, P.n, par);
+    Eexp = L->Eexp.p;
+  }
+#define JH_ASM_ARGS P.d_tile_desc.p, P.ntiles, P.d_rowptr.p, P.d_col.p, P.d_diag.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row, (int)P.n, Eexp
   static const bool pipe = getenv("JH_ASM_NO_PIPE") == nullptr;
   // persistent grid of the pipelined scalar kernels: 8 workgroups per CU like the SpMV
   dim3 pgrid((unsigned)(std::min(chunk, 256) * NUM_XCD));
@@ -462,13 +501,16 @@ void k_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
   switch (L->kind) {
     case JH_LAW_POISSON:
       if (pipe) hipLaunchKernelGGL(assemble_pipe_kernel<JH_LAW_POISSON>, pgrid, block, 0, ctx->stream, JH_ASM_PIPE_ARGS);
-      else hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_POISSON>, grid, block, 0, ctx->stream, JH_ASM_ARGS);
+      else hipLaunchKernelGGL((assemble_tile_kernel<JH_LAW_POISSON, false>), grid, block, 0, ctx->stream, JH_ASM_ARGS);
       break;
     case JH_LAW_COMPRESSIBLE:
       if (pipe) hipLaunchKernelGGL(assemble_pipe_kernel<JH_LAW_COMPRESSIBLE>, pgrid, block, 0, ctx->stream, JH_ASM_PIPE_ARGS);
-      else hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_COMPRESSIBLE>, grid, block, 0, ctx->stream, JH_ASM_ARGS);
+      else hipLaunchKernelGGL((assemble_tile_kernel<JH_LAW_COMPRESSIBLE, false>), grid, block, 0, ctx->stream, JH_ASM_ARGS);
       break;
-    case JH_LAW_TWOPHASE: hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_TWOPHASE>, grid, block, 0, ctx->stream, JH_ASM_ARGS); break;
+    case JH_LAW_TWOPHASE:
+      if (Eexp) hipLaunchKernelGGL((assemble_tile_kernel<JH_LAW_TWOPHASE, true>), grid, block, 0, ctx->stream, JH_ASM_ARGS);
+      else hipLaunchKernelGGL((assemble_tile_kernel<JH_LAW_TWOPHASE, false>), grid, block, 0, ctx->stream, JH_ASM_ARGS);
+      break;
     default: JH_THROW("unknown law kind");
   }
 #undef JH_ASM_ARGS

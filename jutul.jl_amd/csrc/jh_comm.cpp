@@ -94,7 +94,9 @@ struct Comm {
   std::vector<Mailbox *> mail_peer;  // [nranks], mail_peer[rank] == mail_self
   DevBuf<Mailbox *> d_mail_peer;
   DevBuf<unsigned long long> mail_ctr;  // [0] all-reduces this rank has executed (the epoch lives on the device, see MailArgs)
-  uint64_t wait_ticks = 3000000000ull;  // time limit of the in-solve waits in 100 MHz ticks (JH_COMM_TIMEOUT_S, default 30 s)
+  // time limit of the in-solve waits in 100 MHz ticks (JH_COMM_TIMEOUT_S; default 600 s: ranks may legitimately enter a reduction
+  // far apart -- lazy first-solve set-up, JIT compilation on one rank, several ranks time-sharing a GPU -- and a timeout is sticky)
+  uint64_t wait_ticks = 60000000000ull;
   bool mail_attached = false, mail_enabled = false;
   // host-language halo backend (jh_comm_set_halo_callback): the packed send buffer is staged to the host and exchanged there
   jh_halo_callback halo_cb = nullptr;

@@ -99,8 +99,10 @@ struct jh_ilu_s {
   DevBuf<double> e_val;                            // their values, copied from A at the start of every solve (ilu_eprod_refresh)
   // program-driven factorisation (ilu_factor_prog_kernel): per block the entry ranges and a 16-bit instruction stream
   bool prog = false;
+  bool prog_rowmajor = false;  // the programs address the row-major factor arrays (rows too long for the jagged layout)
   std::vector<int32_t> blk_lbase, blk_ubase, blk_prog;  // [nb + 1] first jagged L / U entry and first program word of every block
-  DevBuf<int32_t> d_blk_lbase, d_blk_ubase, d_blk_prog;
+  std::vector<int32_t> blk_dbase;                       // [nb + 1] first pivot slot of every block
+  DevBuf<int32_t> d_blk_lbase, d_blk_ubase, d_blk_prog, d_blk_dbase;
   DevBuf<uint16_t> d_prog;
   size_t prog_lds_bytes = 0;
   int prog_max_vals = 0, prog_max_words = 0;
@@ -492,11 +494,146 @@ __global__ __launch_bounds__(1024) void ilu_factor_diag_kernel(IluDev F, const d
   }
 }
 
+// The same refactorisation, persistent and software-pipelined over the blocks a workgroup owns (b, b + gridDim, ...): the
+// index loads of the NEXT block (descriptor, row word, pivot slot, L maps / columns / partner maps) -- and for scalar matrices the
+// values behind them -- are in flight while the current block walks its levels, so that a block no longer pays the two dependent
+// memory round trips of its gather (index -> value) in front of its sweep.  Arithmetic and stores are those of
+// ilu_factor_diag_kernel.  PFV: prefetch the values too (scalar: 9 more registers; blocks keep one hop).
+template <int BS, int KU>
+struct FDIdx {
+  int4 D;
+  unsigned word;
+  int diag, bslot;
+  int kcol[KU], lmap[KU], tmap[KU];
+};
+template <int BS, int KU, bool SC, bool PFV, int LB>
+__global__ __launch_bounds__(LB) void ilu_factor_diag_pipe_kernel(IluDev F, const double *__restrict__ aval, const int32_t *__restrict__ ubase,
+                                                                    const int32_t *__restrict__ jl_map, const int32_t *__restrict__ jt_map,
+                                                                    const int32_t *__restrict__ ju_map, const int32_t *__restrict__ jf_diag,
+                                                                    const uint16_t *__restrict__ jf_bslot, int nb) {
+  extern __shared__ __attribute__((aligned(16))) double dv[];  // inverted pivots by block-local row
+  constexpr int BB = BS * BS;
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, ch = tid >> 6;
+  auto load_idx = [&](int b, FDIdx<BS, KU> &I) {
+    const int c0 = F.chunk_ptr[b], nch = F.chunk_ptr[b + 1] - c0;
+    I.D = make_int4(0, 0, 0, 0);
+    I.word = 0xffff0000u;
+    I.diag = -1; I.bslot = 0;
+    if (ch < nch) {
+      const size_t fslot = (size_t)(c0 + ch) * 64 + lane;
+      I.D = F.jf_desc[c0 + ch];
+      I.word = F.jf_row[fslot];
+      if ((I.word >> 16) != 0xffffu) { I.diag = jf_diag[fslot]; I.bslot = (int)jf_bslot[fslot]; }
+    }
+    int off = I.D.x;
+#define JH_FI(J)                                                                                     \
+    if (J < KU) {                                                                                    \
+      const int cnt = jd_count<(J < 8 ? J : 0)>(I.D);                                                \
+      const bool a = I.diag >= 0 && lane < cnt;                                                      \
+      I.kcol[J < KU ? J : 0] = a ? (int)F.jl_col[off + lane] : -1;                                   \
+      I.lmap[J < KU ? J : 0] = a ? jl_map[off + lane] : -1;                                          \
+      I.tmap[J < KU ? J : 0] = a ? jt_map[off + lane] : -1;                                          \
+      off += cnt;                                                                                    \
+    }
+    JH_FI(0) JH_FI(1) JH_FI(2) JH_FI(3) JH_FI(4) JH_FI(5) JH_FI(6) JH_FI(7)
+#undef JH_FI
+  };
+  auto load_val = [&](const FDIdx<BS, KU> &I, Blk<BS> &acc, Blk<BS> *av, Blk<BS> *bv) {
+    if (I.diag >= 0) acc = blk_load_al<BS>(aval + (size_t)I.diag * BB);
+#pragma unroll
+    for (int j = 0; j < KU; ++j) {
+      if (I.kcol[j] >= 0) {
+        av[j] = blk_load_al<BS>(aval + (size_t)I.lmap[j] * BB);
+        if (I.tmap[j] >= 0) bv[j] = blk_load_al<BS>(aval + (size_t)I.tmap[j] * BB);
+        else { _Pragma("unroll") for (int i = 0; i < BB; ++i) bv[j].a[i] = 0.0; }
+      }
+    }
+  };
+  FDIdx<BS, KU> In;
+  Blk<BS> accn, avn[KU], bvn[KU];
+  int b = blockIdx.x;
+  if (b < nb) { load_idx(b, In); if (PFV) load_val(In, accn, avn, bvn); }
+  for (; b < nb; b += gridDim.x) {
+    const FDIdx<BS, KU> I = In;
+    Blk<BS> acc, av[KU], bv[KU];
+    if (PFV) {
+      acc = accn;
+#pragma unroll
+      for (int j = 0; j < KU; ++j) { av[j] = avn[j]; bv[j] = bvn[j]; }
+    } else {
+      load_val(I, acc, av, bv);
+    }
+    const Blk<BS> aii = acc;
+    const int c0 = F.chunk_ptr[b];
+    const int lt = (int)(I.word & 0xffffu), lev = (int)(I.word >> 16);
+    const bool has_row = I.diag >= 0;
+    // U (and, D-ILU storage, L) hold A's entries: first batch of four loaded now, stored after the sweep
+    const int u0 = ubase[b], nu = ubase[b + 1] - u0;
+    int um[4];
+    Blk<BS> uv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int j = tid + u * T; um[u] = j < nu ? ju_map[u0 + j] : -1; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (um[u] >= 0) uv[u] = blk_load_al<BS>(aval + (size_t)um[u] * BB);
+      else { _Pragma("unroll") for (int e = 0; e < BB; ++e) uv[u].a[e] = 0.0; }
+    }
+    // the next block's indices (and values) go out before this block's level loop
+    if (b + (int)gridDim.x < nb) { load_idx(b + gridDim.x, In); if (PFV) load_val(In, accn, avn, bvn); }
+    int pos[KU];
+    {
+      int off = I.D.x;
+#define JH_FP(J) if (J < KU) { pos[J < KU ? J : 0] = off + lane; off += jd_count<(J < 8 ? J : 0)>(I.D); }
+      JH_FP(0) JH_FP(1) JH_FP(2) JH_FP(3) JH_FP(4) JH_FP(5) JH_FP(6) JH_FP(7)
+#undef JH_FP
+    }
+    if (SC) {
+#pragma unroll
+      for (int j = 0; j < KU; ++j)
+        if (I.kcol[j] >= 0) blk_store_al<BS>(F.l_val + (size_t)pos[j] * BB, av[j]);
+    }
+    const int lev0 = F.flev_off[b], nlev = F.flev_off[b + 1] - 1 - lev0;
+    for (int lv = 0; lv < nlev; ++lv) {
+      if (has_row && lev == lv) {
+#pragma unroll
+        for (int j = 0; j < KU; ++j) {
+          if (I.kcol[j] >= 0) {
+            const Blk<BS> lik = blk_mul<BS>(av[j], blk_load<BS>(dv + (size_t)I.kcol[j] * BB));  // nz_l * inv(A_kk)
+            if (!SC) blk_store_al<BS>(F.l_val + (size_t)pos[j] * BB, lik);
+            if (blk_nonzero<BS>(lik)) blk_sub<BS>(acc, blk_mul<BS>(lik, bv[j]));
+          }
+        }
+        const Blk<BS> di = blk_inv<BS>(acc);
+        blk_store<BS>(dv + (size_t)lt * BB, di);
+        blk_store_al<BS>(F.dinv + ((size_t)c0 * 64 + I.bslot) * BB, di);
+        if (SC) {
+          blk_store_al<BS>(F.dinv_f + ((size_t)(c0 + ch) * 64 + lane) * BB, di);
+          blk_store_al<BS>(F.kap + ((size_t)c0 * 64 + I.bslot) * BB, aii);
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = tid + u * T;
+      if (j < nu) blk_store_al<BS>(F.u_val + (size_t)(u0 + j) * BB, uv[u]);
+    }
+    for (int j0 = tid + 4 * T; j0 < nu; j0 += T) {  // (only blocks with more than 4 U entries per thread)
+      const int m = ju_map[u0 + j0];
+      Blk<BS> v;
+      if (m >= 0) v = blk_load_al<BS>(aval + (size_t)m * BB);
+      else { _Pragma("unroll") for (int e = 0; e < BB; ++e) v.a[e] = 0.0; }
+      blk_store_al<BS>(F.u_val + (size_t)(u0 + j0) * BB, v);
+    }
+  }
+}
+
 template <int BS>
 __global__ void ilu_factor_prog_kernel(IluDev F, const double *__restrict__ aval, const int32_t *__restrict__ lbase,
                                        const int32_t *__restrict__ ubase, const int32_t *__restrict__ pbase,
                                        const int32_t *__restrict__ jl_map, const int32_t *__restrict__ ju_map,
-                                       const int32_t *__restrict__ jd_map, const uint16_t *__restrict__ prog, int max_vals) {
+                                       const int32_t *__restrict__ jd_map, const uint16_t *__restrict__ prog, int max_vals,
+                                       const int32_t *__restrict__ dbase) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BB = BS * BS;
   double *vals = reinterpret_cast<double *>(smem);
@@ -505,7 +642,7 @@ __global__ void ilu_factor_prog_kernel(IluDev F, const double *__restrict__ aval
   const int b0 = F.blk_ptr[b], nr = F.blk_ptr[b + 1] - b0;
   const int l0 = lbase[b], nl = lbase[b + 1] - l0;
   const int u0 = ubase[b], nu = ubase[b + 1] - u0;
-  const int c0 = F.chunk_ptr[b], nd = (F.chunk_ptr[b + 1] - c0) * 64;  // pivot slots (backward chunk lanes)
+  const int d0 = dbase[b], nd = dbase[b + 1] - d0;  // pivot slots: backward chunk lanes (jagged layout) or U-order positions (row-major)
   const int p0 = pbase[b], np = pbase[b + 1] - p0;
   // gather through the maps, four entries per thread at a time: the map loads, then the dependent value loads, are in flight
   // together (one entry per thread and iteration leaves the block waiting on two memory latencies per 128 entries)
@@ -526,7 +663,7 @@ __global__ void ilu_factor_prog_kernel(IluDev F, const double *__restrict__ aval
   };
   gather(jl_map, l0, nl, 0);
   gather(ju_map, u0, nu, nl);
-  gather(jd_map, c0 * 64, nd, nl + nu);
+  gather(jd_map, d0, nd, nl + nu);
   for (int j = tid; j < np; j += T) pw[j] = prog[p0 + j];
   __syncthreads();
   // program layout: [row offsets (nr + 1)] [pivot index of every row (nr)] [instructions]
@@ -559,7 +696,7 @@ __global__ void ilu_factor_prog_kernel(IluDev F, const double *__restrict__ aval
   }
   for (int j = tid; j < nl * BB; j += T) F.l_val[(size_t)l0 * BB + j] = vals[j];
   for (int j = tid; j < nu * BB; j += T) F.u_val[(size_t)u0 * BB + j] = vals[(size_t)nl * BB + j];
-  for (int j = tid; j < nd * BB; j += T) F.dinv[(size_t)c0 * 64 * BB + j] = vals[(size_t)(nl + nu) * BB + j];
+  for (int j = tid; j < nd * BB; j += T) F.dinv[(size_t)d0 * BB + j] = vals[(size_t)(nl + nu) * BB + j];
 }
 
 // LDS mode: one workgroup per block, levels separated by __syncthreads()
@@ -1524,9 +1661,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       size_t bytes = sizeof(double) * bbv * (size_t)(mxl + mxu + maxrows) +
                      sizeof(uint16_t) * (size_t)(mxl + mxu + 3 * maxrows + 2 + maxlev + 2);
       bytes = (bytes + 15) & ~(size_t)15;
-      // (up to the 160 KB of a gfx950 CU with the opt-in attribute: blocks of long rows -- polyhedral cells -- stay off the
-      // global-memory factor kernels, which took 33 ms instead of ~1 ms on a 2M-cell polyhedral grid)
-      if (mxl < 65536 && mxu < 65536 && maxrows < 65536 && bytes <= 160 * 1024 - 1024 && !getenv("JH_ILU_FACTOR_GLOBAL")) {
+      // (not beyond 64 KB: with the 160 KB opt-in the LDS row kernel took 151 ms on 512-row blocks of a 2M-cell polyhedral grid,
+      // the global-memory row kernels 33 ms; long rows take the program-driven kernel instead, below)
+      if (mxl < 65536 && mxu < 65536 && maxrows < 65536 && bytes <= LDS_CAP_BYTES && !getenv("JH_ILU_FACTOR_GLOBAL")) {
         M->max_blk_l = (int)mxl;
         M->max_blk_u = (int)mxu;
         M->factor_lds_bytes = bytes;
@@ -1798,6 +1935,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
                                 bytes, max_vals, max_words, total, (long long)maxrows);
             hipStream_t sp = M->ctx->stream;
             M->d_blk_lbase.upload(M->blk_lbase, sp); M->d_blk_ubase.upload(M->blk_ubase, sp); M->d_blk_prog.upload(M->blk_prog, sp);
+            M->blk_dbase.assign(nb + 1, 0);
+            for (int64_t b = 0; b <= nb; ++b) M->blk_dbase[b] = M->chunk_ptr[b] * 64;
+            M->d_blk_dbase.upload(M->blk_dbase, sp);
             M->d_prog.upload(prog, sp);
           }
         }
@@ -1814,6 +1954,89 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         JH_HIP(hipMemsetAsync(M->jl_val.p, 0, M->jl_val.n * sizeof(double), sj));
         JH_HIP(hipMemsetAsync(M->ju_val.p, 0, M->ju_val.n * sizeof(double), sj));
         JH_HIP(hipMemsetAsync(M->jdinv.p, 0, M->jdinv.n * sizeof(double), sj));
+      } else if (!getenv("JH_ILU_NO_PROG")) {
+        // Rows with more than 8 strict-L / strict-U entries (polyhedral / PEBI cells): no jagged layout, the triangular sweeps keep
+        // the row-major kernels -- but the refactorisation still runs program-driven (ilu_factor_prog_kernel over the row-major
+        // arrays: value index = old entry position, pivot slot = U-order position).  The per-row factor kernels it replaces
+        // search the pattern on the device: 33 ms instead of ~1 ms on a 2M-cell polyhedral grid.
+        M->blk_lbase.assign(nb + 1, 0); M->blk_ubase.assign(nb + 1, 0); M->blk_prog.assign(nb + 1, 0); M->blk_dbase.assign(nb + 1, 0);
+        for (int64_t b = 0; b <= nb; ++b) { M->blk_lbase[b] = M->l_ptr[M->blk_ptr[b]]; M->blk_ubase[b] = M->u_ptr[M->blk_ptr[b]]; M->blk_dbase[b] = M->blk_ptr[b]; }
+        std::vector<std::vector<uint16_t>> progs(nb);
+        std::vector<int> blk_vals(nb, 0);
+        std::vector<char> blk_ok(nb, 1);
+        parallel_ranges(nb, 16, [&](int64_t bb0, int64_t bb1) {
+          std::vector<uint16_t> code;
+          for (int64_t b = bb0; b < bb1; ++b) {
+            const int32_t b0 = M->blk_ptr[b], nrb = M->blk_ptr[b + 1] - b0;
+            const int32_t l0 = M->blk_lbase[b], nl = M->blk_lbase[b + 1] - l0, u0 = M->blk_ubase[b], nu = M->blk_ubase[b + 1] - u0;
+            blk_vals[b] = nl + nu + nrb;
+            if (nl + nu + nrb >= 65536) { blk_ok[b] = 0; continue; }
+            std::vector<uint16_t> &prog = progs[b];
+            prog.assign(2 * (size_t)nrb + 1, 0);  // row offsets (nrb + 1), pivot indices (nrb)
+            code.clear();
+            auto didx = [&](int32_t t) { return (uint16_t)(nl + nu + (M->upos_of[t] - b0)); };  // t: ilu row
+            for (int32_t lt = 0; lt < nrb && blk_ok[b]; ++lt) {
+              const int32_t t = b0 + lt, ipos = M->upos_of[t];
+              prog[lt] = (uint16_t)code.size();
+              prog[nrb + 1 + lt] = didx(t);
+              const int32_t ls = M->l_ptr[t], le = M->l_ptr[t + 1], us = M->u_ptr[ipos], ue = M->u_ptr[ipos + 1];
+              for (int32_t pp = ls; pp < le; ++pp) {
+                const int32_t k = M->l_col[pp], kpos = M->upos_of[b0 + k];
+                code.push_back((uint16_t)(pp - l0));
+                code.push_back(didx(b0 + k));
+                const size_t cnt_at = code.size();
+                code.push_back(0);
+                uint16_t nupd = 0;
+                for (int32_t q = M->u_ptr[kpos]; q < M->u_ptr[kpos + 1]; ++q) {  // U row k, ascending columns
+                  const int32_t j = M->u_col[q];
+                  int32_t tgt = -1;
+                  if (j == lt) {
+                    tgt = didx(t);
+                  } else if (j < lt) {  // a later strict-L entry of this row (process_partial_row! on rem_l_pos, ilu0.jl:100-106)
+                    for (int32_t p2 = pp + 1; p2 < le; ++p2) if (M->l_col[p2] == j) { tgt = p2 - l0; break; }
+                  } else {
+                    for (int32_t qi = us; qi < ue; ++qi) if (M->u_col[qi] == j) { tgt = nl + (qi - u0); break; }
+                  }
+                  if (tgt < 0) continue;  // (k, j) has no counterpart in row i: dropped fill, ILU(0)
+                  code.push_back((uint16_t)tgt);
+                  code.push_back((uint16_t)(nl + (q - u0)));
+                  ++nupd;
+                }
+                code[cnt_at] = nupd;
+              }
+              if (code.size() >= 65536) blk_ok[b] = 0;
+            }
+            prog[nrb] = (uint16_t)code.size();
+            prog.insert(prog.end(), code.begin(), code.end());
+          }
+        });
+        bool ok = true;
+        int max_vals = 0, max_words = 0;
+        size_t total = 0;
+        for (int64_t b = 0; b < nb; ++b) {
+          ok = ok && blk_ok[b];
+          max_vals = std::max(max_vals, blk_vals[b]);
+          max_words = std::max<int>(max_words, (int)progs[b].size());
+          M->blk_prog[b] = (int32_t)total;
+          total += progs[b].size();
+        }
+        M->blk_prog[nb] = (int32_t)total;
+        size_t bytes = sizeof(double) * P.bs * P.bs * (size_t)max_vals + sizeof(uint16_t) * (size_t)max_words;
+        bytes = (bytes + 15) & ~(size_t)15;
+        if (timing) fprintf(stderr, "[jutul_hip setup] ilu0: long rows (%d entries): row-major factor programs %s, LDS %zu B per block\n", maxcnt,
+                            (ok && bytes <= 160 * 1024 - 512) ? "on" : "off", bytes);
+        if (ok && total < (size_t)INT32_MAX && bytes <= 160 * 1024 - 512) {
+          std::vector<uint16_t> prog(std::max<size_t>(total, 1), 0);
+          for (int64_t b = 0; b < nb; ++b)
+            if (!progs[b].empty()) std::copy(progs[b].begin(), progs[b].end(), prog.begin() + M->blk_prog[b]);
+          M->prog = true;
+          M->prog_rowmajor = true;
+          M->prog_lds_bytes = bytes; M->prog_max_vals = max_vals; M->prog_max_words = max_words;
+          hipStream_t sp = M->ctx->stream;
+          M->d_blk_lbase.upload(M->blk_lbase, sp); M->d_blk_ubase.upload(M->blk_ubase, sp); M->d_blk_prog.upload(M->blk_prog, sp);
+          M->d_blk_dbase.upload(M->blk_dbase, sp);
+          M->d_prog.upload(prog, sp);
+        }
       }
     }
     lap("jagged layout + programs");
@@ -1879,7 +2102,7 @@ extern "C" int32_t jh_ilu0_stats(jh_ilu M, int64_t *stats4) {
     stats4[0] = (int64_t)M->l_col.size();
     stats4[1] = (int64_t)M->u_col.size();
     stats4[2] = (int64_t)M->blk_ptr.size() - 1;
-    stats4[3] = (M->lds_mode ? 1 : 0) | (M->jag ? 2 : 0) | (M->jag && M->prog ? 4 : 0) | (M->jag && M->prog && M->diag_only ? 8 : 0) |
+    stats4[3] = (M->lds_mode ? 1 : 0) | (M->jag ? 2 : 0) | (((M->jag && M->prog) || M->prog_rowmajor) ? 4 : 0) | (M->jag && M->prog && M->diag_only ? 8 : 0) |
                 ((M->jag && M->uscaled && !getenv("JH_NO_FUSED_PRODUCT")) ? 16 : 0);
   });
 }
@@ -1965,7 +2188,29 @@ void ilu_factor(jh_ilu M) {
                                                    M->d_blk_ubase.p, M->d_jl_map.p, M->d_jt_map.p, M->d_ju_map.p, M->d_jf_diag.p, M->d_jf_bslot.p)
 #define JH_DIAGK(BSV) do { if (M->uscaled) { if (M->jag_ku == 4) JH_DIAG(BSV, 4, true); else JH_DIAG(BSV, 8, true); } \
                            else { if (M->jag_ku == 4) JH_DIAG(BSV, 4, false); else JH_DIAG(BSV, 8, false); } } while (0)
-      switch (M->bs) { case 1: JH_DIAGK(1); break; case 2: JH_DIAGK(2); break; case 3: JH_DIAGK(3); break; }
+      // Persistent, software-pipelined variant (ilu_factor_diag_pipe_kernel): measured on MI355X (profiles/r03_factor_pipe_*): scalar
+      // 10M cells 0.408 -> 0.514 ms (indices prefetched) / 0.763 ms (values too: 86 VGPRs, two blocks per CU); 2x2 blocks 5M cells
+      // 1.047 -> 0.976 ms.  Opt-in (JH_ILU_FACTOR_PIPE=1), default: one workgroup per block.
+      static const int pipe = getenv("JH_ILU_FACTOR_PIPE") ? atoi(getenv("JH_ILU_FACTOR_PIPE")) : 0;
+      if (pipe) {
+        // persistent workgroups: as many as are resident at once (waves of a workgroup = chunks of the largest block)
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const int per_cu = std::max(1, std::min(8, 32 / std::max(1, M->max_chunks)));
+        const int pg = (int)std::min<int64_t>(nb, (int64_t)ncu * per_cu * (pipe > 1 ? pipe : 1));
+#define JH_DPL(BSV, KUV, SCV, PFVV, LBV) hipLaunchKernelGGL((ilu_factor_diag_pipe_kernel<BSV, KUV, SCV, PFVV, LBV>), dim3((unsigned)pg), dim3(dthreads), dlds, s, F, aval, \
+                                                       M->d_blk_ubase.p, M->d_jl_map.p, M->d_jt_map.p, M->d_ju_map.p, M->d_jf_diag.p, M->d_jf_bslot.p, (int)nb)
+#define JH_DP(BSV, KUV, SCV, PFVV) do { if (dthreads <= 640) JH_DPL(BSV, KUV, SCV, PFVV, 640); else JH_DPL(BSV, KUV, SCV, PFVV, 1024); } while (0)
+#define JH_DPK(BSV, PFVV) do { if (M->uscaled) { if (M->jag_ku == 4) JH_DP(BSV, 4, true, PFVV); else JH_DP(BSV, 8, true, PFVV); } \
+                               else { if (M->jag_ku == 4) JH_DP(BSV, 4, false, PFVV); else JH_DP(BSV, 8, false, PFVV); } } while (0)
+        static const bool pfv = !getenv("JH_ILU_FACTOR_NO_PFV");
+        switch (M->bs) { case 1: if (pfv) JH_DPK(1, true); else JH_DPK(1, false); break; case 2: JH_DPK(2, false); break; case 3: JH_DPK(3, false); break; }
+#undef JH_DPK
+#undef JH_DP
+#undef JH_DPL
+      } else {
+        switch (M->bs) { case 1: JH_DIAGK(1); break; case 2: JH_DIAGK(2); break; case 3: JH_DIAGK(3); break; }
+      }
 #undef JH_DIAGK
 #undef JH_DIAG
       JH_HIP(hipGetLastError());  // a refused launch must not leave stale factors marked as fresh
@@ -1978,10 +2223,27 @@ void ilu_factor(jh_ilu M) {
       if (M->prog_lds_bytes > 64 * 1024)                                                                                          \
         JH_HIP(hipFuncSetAttribute((const void *)ilu_factor_prog_kernel<BSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes)); \
       hipLaunchKernelGGL(ilu_factor_prog_kernel<BSV>, dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
-                         M->d_blk_ubase.p, M->d_blk_prog.p, M->d_jl_map.p, M->d_ju_map.p, M->d_jd_map.p, M->d_prog.p, M->prog_max_vals); \
+                         M->d_blk_ubase.p, M->d_blk_prog.p, M->d_jl_map.p, M->d_ju_map.p, M->d_jd_map.p, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p); \
     } while (0)
     switch (M->bs) { case 1: JH_PROG(1); break; case 2: JH_PROG(2); break; case 3: JH_PROG(3); break; }
 #undef JH_PROG
+    JH_HIP(hipGetLastError());
+    M->factored = true;
+    return;
+  }
+  if (M->prog_rowmajor && M->lds_mode) {  // long rows: the program-driven refactorisation over the row-major arrays
+    IluDev F = dev_view(M);
+    const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
+    static const int pthreads = getenv("JH_ILU_FACTOR_THREADS") ? atoi(getenv("JH_ILU_FACTOR_THREADS")) : 512;
+#define JH_PROGR(BSV)                                                                                                            \
+    do {                                                                                                                          \
+      if (M->prog_lds_bytes > 64 * 1024)                                                                                          \
+        JH_HIP(hipFuncSetAttribute((const void *)ilu_factor_prog_kernel<BSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes)); \
+      hipLaunchKernelGGL(ilu_factor_prog_kernel<BSV>, dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
+                         M->d_blk_ubase.p, M->d_blk_prog.p, M->d_l_map.p, M->d_u_map.p, M->d_d_map.p, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p); \
+    } while (0)
+    switch (M->bs) { case 1: JH_PROGR(1); break; case 2: JH_PROGR(2); break; case 3: JH_PROGR(3); break; }
+#undef JH_PROGR
     JH_HIP(hipGetLastError());
     M->factored = true;
     return;

@@ -310,6 +310,7 @@ struct jh_law_s {
   jh::DevBuf<double> limits; // 5*N update limits for jh_newton_step (jh_law_set_update_limits); empty: none
   jh::DevBuf<double> Tnz;    // per device nnz: T_f off-diagonal, accumulation coefficient on the diagonal
   jh::DevBuf<double> gnz;    // per device nnz: signed gdz (self -> other); empty when no gravity
+  jh::DevBuf<double> Eexp;   // two-phase law: exp(c_ph (p - p_ref)) per cell and phase, refreshed by every assembly (pre-pass)
   bool has_gdz = false;
   int64_t nsrc = 0;
   jh::DevBuf<int32_t> src_cell;

@@ -439,8 +439,12 @@ static void order_by_partition(const Adj &A, int64_t nc, const int64_t *partitio
   if (bfs_inside) {  // JH_REORDER_BLOCKS with a partition: the caller's blocks, ordered inside for short dependency chains
     std::vector<int32_t> lab(nc);
     for (int64_t c = 0; c < nc; ++c) lab[c] = (int32_t)(partition[c] - 1);
+    // (the parts are disjoint: one distance array serves all threads, as in blocks_by_bisection -- a private one per thread would
+    // be 4 bytes x cells x threads)
+    std::vector<int32_t> dist;
+    resize_parallel(dist, (size_t)nc);
     parallel_ranges(np, 8, [&](int64_t b0, int64_t b1) {
-      std::vector<int32_t> bq, dist(nc, -1);
+      std::vector<int32_t> bq;
       for (int64_t b = b0; b < b1; ++b)
         centre_bfs_order(A, lab, (int32_t)b, perm.data() + block_ptr[b], block_ptr[b + 1] - block_ptr[b], dist, bq);
     });

@@ -77,6 +77,12 @@ extern "C" int32_t jh_subdomain_create(int64_t nc, int64_t nf, const int64_t *N,
     });
     std::vector<int64_t> owned, ghosts;
     select_ascending(nc, [&](int64_t c) { return kd[c] == 1; }, owned);
+    if (owned.empty()) {  // an empty part is legal, a rank beyond the partition's parts is a caller error (0- vs 1-based ranks)
+      int64_t pmax = 0;
+      for (int64_t c = 0; c < nc; ++c) pmax = std::max(pmax, partition[c]);
+      if (rank > pmax) JH_THROW("jh_subdomain_create: rank " + std::to_string(rank) + " but the partition vector has parts 1.." +
+                                std::to_string(pmax) + " (rank is 1-based like the partition ids)");
+    }
     select_ascending(nc, [&](int64_t c) { return kd[c] == 2; }, ghosts);
     if (ghost_order == 1)
       std::stable_sort(ghosts.begin(), ghosts.end(), [&](int64_t a, int64_t b) { return partition[a] < partition[b]; });
@@ -184,6 +190,11 @@ extern "C" int32_t jh_partition_rcb(int64_t nc, int32_t dim, const double *X, in
     if (nc < 1 || dim < 1 || dim > 3 || !X || !out) JH_THROW("bad arguments");
     if (nparts < 1 || nparts > nc) JH_THROW("nparts must be in 1..nc");
     if (nc > 2000000000LL) JH_THROW("too many cells");
+    // (a NaN would break the strict weak ordering nth_element relies on)
+    parallel_ranges(nc * dim, 1 << 18, [&](int64_t b, int64_t e) {
+      for (int64_t i = b; i < e; ++i)
+        if (!std::isfinite(X[i])) JH_THROW("jh_partition_rcb: non-finite coordinate of cell " + std::to_string(i / dim + 1));
+    });
     std::vector<int32_t> idx;
     resize_parallel(idx, (size_t)nc);
     parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { std::iota(idx.begin() + b, idx.begin() + e, (int32_t)b); });

@@ -1440,3 +1440,43 @@ def test_halo_plan_must_agree_with_the_discretisation_on_n_owned(ja):
     good = ja.TwoPointPotentialFlowHardCoded(c, sub["N"], sub["n_local"], reorder="blocks", block_rows=32, n_owned=sub["n_owned"])
     good.set_halo(sub["n_owned"], sub["neighbors"], sub["send"], sub["recv"])
     assert good.halo_info()["n_owned"] == sub["n_owned"]
+
+
+def test_device_side_reports_and_per_variable_download(ja, ctx):
+    """increment_norm (models.jl:955-965), variable_change_report (models.jl:1023-1038) and the per-variable state download behind
+    get_output_state (models.jl:1048-1058) for a 2-variable law on a reordered grid: against numpy on the host arrays."""
+    import ctypes as C
+    from jutul_amd import _lib
+    from jutul_amd._lib import check, pf
+    g, rng = tet_case(ja, (7, 6, 5), seed=21)
+    nc = g["nc"]
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, block_n=2, reorder="blocks", block_rows=64)
+    law = ja.ConservationLaw(disc, "twophase", rho0=(1.0, 0.8), compressibility=(1e-2, 2e-2), viscosity=(1.0, 2.0), p_ref=1.0)
+    X = np.stack([rng.uniform(1.0, 2.0, nc), rng.uniform(0.2, 0.8, nc)]).T.copy()      # [nc, 2] = the reference's [N, nc] column-major
+    X0 = np.stack([rng.uniform(1.0, 2.0, nc), rng.uniform(0.2, 0.8, nc)]).T.copy()
+    law.set_state(X)
+    law.set_state0(X0)
+    dxh = rng.standard_normal((nc, 2))
+    dx = ja.DeviceVector(disc, dxh)
+    for e, (s_, m_) in enumerate(law.increment_norm(dx)):
+        assert abs(s_ - np.abs(dxh[:, e]).sum()) <= 1e-12 * np.abs(dxh[:, e]).sum() and m_ == np.abs(dxh[:, e]).max()
+    n_own = nc - 37                                                                       # owned cells of a rank-local model come first
+    for e, (s_, m_) in enumerate(law.increment_norm(dx, n_owned=n_own)):
+        assert abs(s_ - np.abs(dxh[:n_own, e]).sum()) <= 1e-12 * np.abs(dxh[:, e]).sum() and m_ == np.abs(dxh[:n_own, e]).max()
+    for e, rep in enumerate(law.change_report()):
+        d = np.abs(X[:, e] - X0[:, e])
+        assert abs(rep["dx"][0] - d.sum()) <= 1e-12 * d.sum() and rep["dx"][1] == d.max()
+        assert abs(rep["x"][0] - np.abs(X[:, e]).sum()) <= 1e-12 * np.abs(X[:, e]).sum() and rep["x"][1] == np.abs(X[:, e]).max()
+    dxh[5, 1] = np.nan                                                                    # check_increment: a non-finite entry shows in the sum
+    dx.upload(dxh)
+    assert not np.isfinite(law.increment_norm(dx)[1][0]) and np.isfinite(law.increment_norm(dx)[0][0])
+    L = _lib.load()
+    out = np.empty(nc)
+    check(L.jh_host_register(out.ctypes.data_as(C.c_void_p), out.nbytes))                # page-locked target, as JutulHIP.jl does for state0[k]
+    try:
+        for which, ref in ((0, X), (1, X0)):
+            for e in range(2):
+                check(L.jh_law_get_variable(law.h, which, e, pf(out)))
+                assert np.array_equal(out, ref[:, e])
+    finally:
+        check(L.jh_host_unregister(out.ctypes.data_as(C.c_void_p)))

@@ -36,8 +36,14 @@ def test_subdomain_random_partition_and_edge_cases():
     one = np.ones(g["nc"], dtype=np.int64)        # a single part: no ghosts, no neighbours
     s = dd.local_subdomain(g["N"], one, 1)
     assert s["n_owned"] == s["n_local"] == g["nc"] and len(s["neighbors"]) == 0 and s["faces"].size == g["nf"]
-    empty = dd.local_subdomain(g["N"], one, 2)    # a rank that owns nothing
+    two = one.copy()
+    two[0] = 3                                    # parts 1 and 3 are populated, part 2 is empty: legal, an empty subdomain
+    empty = dd.local_subdomain(g["N"], two, 2)
     assert empty["n_owned"] == 0 and empty["n_local"] == 0 and empty["faces"].size == 0
+    with pytest.raises(Exception, match="parts 1..1"):
+        dd.local_subdomain(g["N"], one, 2)        # a rank beyond the partition's parts (0- vs 1-based mix-up) is an error
+    with pytest.raises(Exception, match="non-finite"):
+        dd.partition_rcb(np.full((3, 10), np.nan), 2)
     with pytest.raises(Exception):
         dd.local_subdomain(g["N"], one * 0, 1)    # partition ids are 1-based
     with pytest.raises(ValueError):
