@@ -139,6 +139,9 @@ def main():
         del os.environ["NCCL_DEBUG"]
     os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/jutul_hip_rccl_%h_%p.log")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
+    # the library's default limit for a wait inside a solve is generous (600 s: JIT / lazy set-up skew); the ranks of a benchmark
+    # start together, so a peer that is 60 s late is a failure to report, not to sit out
+    os.environ.setdefault("JH_COMM_TIMEOUT_S", "60")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -574,10 +577,9 @@ def measured_traffic(kernel, args, cells, world):
     measurement -- quoted only if it was taken on exactly this kernel source (hash recorded next to it) and workload; otherwise
     null with the reason."""
     import glob
-    names = {"ilu0_apply": ["ilu_apply_jds_kernel<1, 1, 4>", "ilu_apply_jds_kernel<1, 2, 4>"],
-             "ilu0_apply+spmv": ["ilu_apply_jds_kernel<1, 1, 4, true, 3>+ilu_eprod_kernel<1, 2>", "ilu_apply_jds_kernel<1, 2, 4, true, 2>+ilu_eprod_kernel<1, 1>"],
+    names = {"ilu0_apply": ["ilu_apply_jds_kernel<1, 1, 4, false, 0>", "ilu_apply_jds_kernel<1, 2, 4, false, 0>"],
              "spmv": ["spmv_jds16_kernel<5, 1>", "spmv_jds16_kernel<5, 2>"], "assembly": ["assemble_pipe_kernel<0>"],
-             "ilu0_factor": ["ilu_factor_diag_kernel<1, 4>"]}
+             "ilu0_factor": ["ilu_factor_diag_kernel<1, 4, false>"]}
     if world != 1 or args.law != "poisson" or cells != 10_025_988:
         return None, "PMC passes are committed for the default 1-GPU 10M-cell poisson workload only"
     want = kernel_source_hash()
@@ -667,6 +669,9 @@ def cpu_baseline(args, nc_gpu):
             t_spmv = best(lambda: o.spmv(nc, N, osys.rowptr, osys.colidx, nz, xk, yk))
             t_fac = best(lambda: F.refactor(nz), 3)
             t_app = best(lambda: F.apply(xk))
+            t1 = time.perf_counter()
+            _, stk = o.bicgstab(nc, N, osys.rowptr, osys.colidx, nz, r, prec=F, side=args.precond_side, rtol=args.rtol, atol=1e-12, itmax=itmax)
+            t_it = (time.perf_counter() - t1) / max(1, stk["iterations"])
             NN = N * N
             b_spmv = (8.0 * NN + 8) * nnz + (8 + 16.0 * N) * nc
             # conn_data 32 B/half-face + position tables 8 NN B + flux/acc Duals + state: the reference's own layouts
@@ -676,6 +681,7 @@ def cpu_baseline(args, nc_gpu):
                 "spmv": {"ms": round(t_spmv * 1e3, 3), "gbs": round(b_spmv / t_spmv / 1e9, 1), "bytes_formula": "(8 N^2 + 8) nnz + (8 + 16 N) n (mat.jl:24-68, Int64 indices)"},
                 "ilu_factor": {"ms": round(t_fac * 1e3, 3)},
                 "ilu_apply": {"ms": round(t_app * 1e3, 3)},
+                "bicgstab_iteration": {"ms": round(t_it * 1e3, 3), "note": "one whole solve / its iterations: 2 SpMV + 2 ILU(0) applies + unfused BLAS-1"},
                 "cells": nc, "note": "best of 3-5 repetitions on the sample grid, all host cores"}
         return out
 

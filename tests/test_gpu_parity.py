@@ -1450,7 +1450,8 @@ def test_device_side_reports_and_per_variable_download(ja, ctx):
     from jutul_amd._lib import check, pf
     g, rng = tet_case(ja, (7, 6, 5), seed=21)
     nc = g["nc"]
-    disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, block_n=2, reorder="blocks", block_rows=64)
+    n_own = nc - 37                     # a rank-local model: owned cells first, the last 37 host cells are ghosts (last device rows)
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, block_n=2, reorder="blocks", block_rows=64, n_owned=n_own)
     law = ja.ConservationLaw(disc, "twophase", rho0=(1.0, 0.8), compressibility=(1e-2, 2e-2), viscosity=(1.0, 2.0), p_ref=1.0)
     X = np.stack([rng.uniform(1.0, 2.0, nc), rng.uniform(0.2, 0.8, nc)]).T.copy()      # [nc, 2] = the reference's [N, nc] column-major
     X0 = np.stack([rng.uniform(1.0, 2.0, nc), rng.uniform(0.2, 0.8, nc)]).T.copy()
@@ -1460,8 +1461,7 @@ def test_device_side_reports_and_per_variable_download(ja, ctx):
     dx = ja.DeviceVector(disc, dxh)
     for e, (s_, m_) in enumerate(law.increment_norm(dx)):
         assert abs(s_ - np.abs(dxh[:, e]).sum()) <= 1e-12 * np.abs(dxh[:, e]).sum() and m_ == np.abs(dxh[:, e]).max()
-    n_own = nc - 37                                                                       # owned cells of a rank-local model come first
-    for e, (s_, m_) in enumerate(law.increment_norm(dx, n_owned=n_own)):
+    for e, (s_, m_) in enumerate(law.increment_norm(dx, n_owned=n_own)):                   # owned cells only
         assert abs(s_ - np.abs(dxh[:n_own, e]).sum()) <= 1e-12 * np.abs(dxh[:, e]).sum() and m_ == np.abs(dxh[:n_own, e]).max()
     for e, rep in enumerate(law.change_report()):
         d = np.abs(X[:, e] - X0[:, e])
