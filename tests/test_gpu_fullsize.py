@@ -266,3 +266,45 @@ def test_3M_cells_oracle_parity_where_the_defaults_switch(ja, oracle):
     assert np.abs(xh - x_o).max() <= 1e-10 * np.abs(x_o).max()
     kept = int(lower.sum() - (lu[lower] == 0).sum()), int(upper.sum() - (lu[upper] == 0).sum())
     assert (fi["l_entries"], fi["u_entries"]) == kept, (fi, kept)
+
+
+def test_3M_cells_in_kernel_reduction_stage_is_deterministic_and_matches_the_separate_launch(ja):
+    """Opt-in JH_TAIL_REDUCE=1: the second stage of the fused dot products runs inside the producing kernel (the last workgroup
+    to arrive reads the partials other XCDs wrote, TailArgs).  A stale partial would show as a run-to-run difference: four long
+    BiCGStab solves of the same system must give bit-identical residual histories, and they must follow the history of the
+    separate-launch path (default; a different but fixed summation tree) to rounding."""
+    import os
+    from bench import dims_for_cells
+    ctx = ja.HIPContext(0)
+    g = ja.tet_lattice_mesh(*dims_for_cells(3_200_000))
+    nc = g["nc"]
+    rng = np.random.default_rng(5)
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, reorder="blocks")
+    law = ja.ConservationLaw(disc, "compressible", rho0=(1.0, 1.0), compressibility=(1e-1, 1e-1), viscosity=(1.0, 1.0), p_ref=1.0)
+    law.set_face_trans(g["T"] / g["T"].mean())
+    law.set_volumes(g["volumes"])
+    U = 1.0 + 0.1 * rng.random(nc)
+    law.set_state(U)
+    law.set_state0(U)
+    law.set_sources([1, nc], [1.0, -1.0])
+    lsys = ja.LinearizedSystem(disc)
+    law.update_equation_and_linearized_system(5.0, lsys.jac, lsys.r)
+    prec = ja.ILUZeroPreconditioner(partition="blocks").update_preconditioner(lsys.jac)
+    ks = ja.GenericKrylov("bicgstab", preconditioner=prec, relative_tolerance=1e-9, max_iterations=400)
+
+    def solve():
+        out = ja.linear_solve(lsys, ks, update_preconditioner=False)
+        return out["iterations"], out["residuals"].copy(), lsys.dx.download()
+    assert "JH_TAIL_REDUCE" not in os.environ
+    it0, hist0, dx0 = solve()
+    assert it0 > 8
+    os.environ["JH_TAIL_REDUCE"] = "1"
+    try:
+        runs = [solve() for _ in range(4)]
+    finally:
+        os.environ.pop("JH_TAIL_REDUCE", None)
+    for it, hist, dx in runs[1:]:
+        assert it == runs[0][0] and np.array_equal(hist, runs[0][1]) and np.array_equal(dx, runs[0][2])
+    k = 12
+    assert np.allclose(runs[0][1][:k], hist0[:k], rtol=1e-9), (runs[0][1][:k], hist0[:k])
+    assert abs(it0 - runs[0][0]) <= max(3, 0.15 * it0)
