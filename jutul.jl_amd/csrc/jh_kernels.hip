@@ -157,13 +157,10 @@ void ensure_partials(jh_context ctx, size_t min_stride) {
   if (ctx->partials.n == 0 || ctx->partial_stride < min_stride) {
     JH_HIP(hipStreamSynchronize(ctx->stream));
     ctx->partial_stride = std::max<size_t>(65536, min_stride);  // also used by tile-level partials
-    // UNCACHED device memory: with the second reduction stage inside the producing kernel (TailArgs) a workgroup reads partials
-    // that workgroups on other XCDs wrote during the same launch, and the XCDs' L2s are not coherent with each other for cached
-    // memory -- write-through stores + an acquire on the reader's side were not enough (round 3: the compressible 10M-cell run
-    // stalled on stale partials).  A few thousand 8-byte stores and loads per launch do not need a cache.
-    ctx->partials.release();
-    ctx->partials.n = ctx->partial_stride * 4;
-    JH_HIP(hipExtMallocWithFlags((void **)&ctx->partials.p, ctx->partials.n * sizeof(double), hipDeviceMallocUncached));
+    // (Cached memory.  Uncached partials -- tried in round 3 to make the cross-XCD hand-over of the opt-in in-kernel second stage
+    // coherent by construction -- made processes with several rank threads abort now and then inside the runtime; the opt-in
+    // path relies on write-through stores by the producers and an agent-scope acquire by the one workgroup that reads them.)
+    ctx->partials.alloc(ctx->partial_stride * 4);
   }
 }
 void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max, const double *done, const MailArgs *mail) {

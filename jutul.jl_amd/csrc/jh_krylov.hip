@@ -272,10 +272,10 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   };
   const int64_t rows_dot = nd / P.bs;
   // Second reduction stage inside the producing kernel (TailArgs) instead of a one-workgroup launch: measured on MI355X
-  // (profiles/r03_tail_reduce_*): 10M cells +1.5 % Newton it/s with the partials in cached memory, -0.8 % with the partials in
-  // uncached memory (what makes the cross-XCD hand-over coherent by construction, ensure_partials); 1.25M cells -21 % -- the
-  // workgroups of a 28 us kernel all arrive within a few microseconds and the memory-side arrival counters cost ~0.25 us per
-  // contended increment (SpMV 27.9 -> 43.6 us).  Opt-in: JH_TAIL_REDUCE=1 (read per solve: the tests compare both paths).
+  // (profiles/r03_tail_reduce_*): 10M cells +1.5 % Newton it/s on one box, -0.8 % on another (box-to-box spread is +-3 %); 1.25M
+  // cells -21 % -- the workgroups of a 28 us kernel all arrive within a few microseconds and the memory-side arrival counters
+  // cost ~0.25 us per contended increment (SpMV 27.9 -> 43.6 us).  Opt-in: JH_TAIL_REDUCE=1 (read per solve: the tests compare
+  // both paths).
   const bool tail_pays = getenv("JH_TAIL_REDUCE") && atoi(getenv("JH_TAIL_REDUCE")) != 0;
   // Right preconditioning with column-scaled pivot-only factors: every product of the loop is A * (M^-1 v), and its in-block part
   // is formed inside the apply (ilu_apply_mul); the out-of-block entries -- ghost columns among them, hence after the ghost
