@@ -441,7 +441,9 @@ __device__ __forceinline__ void mailbox_wait_failed(Mailbox *self, MailErr *err,
     __hip_atomic_store(&err->epoch, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&err->code, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __hip_atomic_fetch_add(&err->count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // (plain load + store: a read-modify-write on host-pinned memory needs PCIe atomics; concurrent time-outs may lose a count)
+  __hip_atomic_store(&err->count, __hip_atomic_load(&err->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1ull, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(&self->abort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // spin until *flag >= epoch; false when the time limit ran out (or an earlier wait of this rank already had)

@@ -292,6 +292,7 @@ end
 # ---- host <-> device state hand-over ----------------------------------------------------------------------------------------
 # every host-side writer of the primary variables invalidates the device copy; the next update_equation! uploads it again
 function invalidate_device_state!(storage; state = true, state0 = true)
+    haskey(storage, :LinearizedSystem) || return storage      # (initial reset_variables! during set-up: nothing uploaded yet)
     s = storage.LinearizedSystem.eq_s
     state && (s.device_state_valid = false)
     state0 && (s.device_state0_valid = false)
@@ -325,7 +326,7 @@ function get_output_state(storage, model::HIPModel)
         for (i, k) in enumerate(keys(Jutul.get_primary_variables(model)))
             v0 = storage.state0[k]::Array{Float64}
             if !s.registered
-                @jh :jh_host_register (Ptr{Cvoid}, Int64) pointer(v0) Int64(sizeof(v0))
+                @jh :jh_host_register (Ptr{Cvoid}, Int64) v0 Int64(sizeof(v0))
             end
             @jh :jh_law_get_variable (Handle, Int32, Int32, Ptr{Float64}) s.law Int32(1) Int32(i - 1) v0
         end
