@@ -1131,6 +1131,11 @@ int jo_bicgstab(I64 n, int bs, const I64 *rowptr, const I64 *colidx, const doubl
 
 /* dst = src on all cores: used to hand the solver arrays whose pages are spread over the NUMA nodes like the loops that read
  * them (first touch), the way Julia's threaded initialisation would */
+int jo_zero(I64 n8, double *dst) {
+#pragma omp parallel for schedule(static)
+  for (I64 i = 0; i < n8; ++i) dst[i] = 0.0;
+  return 0;
+}
 int jo_touch_copy(I64 nbytes8, double *dst, const double *src) {
 #pragma omp parallel for schedule(static)
   for (I64 i = 0; i < nbytes8; ++i) dst[i] = src[i];

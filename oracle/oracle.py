@@ -273,12 +273,21 @@ class Law:
             pass
 
 
-def update_equation(law, nc, hfm, X, X0, vol, Tf, gdz=None):
-    """a-5.  Returns (acc [nc, N, 1+N], hf [nhf, N, 1+N]) Dual arrays."""
+def _zero(a):
+    lib().jo_zero(C.c_int64(a.size), a.ctypes.data_as(C.POINTER(C.c_double)))
+    return a
+
+
+def update_equation(law, nc, hfm, X, X0, vol, Tf, gdz=None, out=None):
+    """a-5.  Returns (acc [nc, N, 1+N], hf [nhf, N, 1+N]) Dual arrays.  out = (acc, hf) of an earlier call: the caches are kept
+    between Newton iterations like the reference's ConservationLawTPFAStorage (conservation.jl:101-135), zeroed on all cores."""
     N = law.N
     nhf = hfm["faces"].size
-    acc = np.zeros((nc, N, 1 + N))
-    hf = np.zeros((nhf, N, 1 + N))
+    if out is None:
+        acc = np.zeros((nc, N, 1 + N))
+        hf = np.zeros((nhf, N, 1 + N))
+    else:
+        acc, hf = _zero(out[0]), _zero(out[1])
     X, X0, vol, Tf = _f(X), _f(X0), _f(vol), _f(Tf)
     g = _f(gdz) if gdz is not None else None
     _ck(lib().jo_update_equation(law.h, C.c_int64(nc), C.c_int64(nhf), _pi(hfm["face_pos"]), _pi(hfm["self"]),
@@ -294,12 +303,20 @@ def apply_sources(acc, cells, values):
     _ck(lib().jo_apply_sources(C.c_int(N), C.c_int64(cells.size), _pi(cells), _pf(values), _pf(acc)), "sources")
 
 
-def fill_conservation_eq(nc, N, hfm, acc, hf, pos_acc, pos_flux, nnz_flat, equation_major=False):
-    """a-6.  Returns (nz flat [nnz_flat], r flat [N*nc]) in the requested residual layout."""
-    nz = np.zeros(nnz_flat)
-    r = np.zeros(N * nc)
-    pa = _i(pos_acc.T.reshape(-1))
-    pf = _i(pos_flux.T.reshape(-1))
+def fill_conservation_eq(nc, N, hfm, acc, hf, pos_acc, pos_flux, nnz_flat, equation_major=False, out=None, flat_pos=None):
+    """a-6.  Returns (nz flat [nnz_flat], r flat [N*nc]) in the requested residual layout.  out = (nz, r) buffers to reuse
+    (jac_buffer / r_buffer live as long as the LinearizedSystem, linsolve/default.jl:166-226); flat_pos = the flattened
+    position tables of an earlier call."""
+    if out is None:
+        nz = np.zeros(nnz_flat)
+        r = np.zeros(N * nc)
+    else:
+        nz, r = _zero(out[0]), _zero(out[1])
+    if flat_pos is None:
+        pa = _i(pos_acc.T.reshape(-1))
+        pf = _i(pos_flux.T.reshape(-1))
+    else:
+        pa, pf = flat_pos
     se, sc = (nc, 1) if equation_major else (1, N)
     _ck(lib().jo_fill_conservation_eq(C.c_int(N), C.c_int64(nc), _pi(hfm["face_pos"]), _pf(acc), _pf(hf), _pi(pa),
                                       _pi(pf), _pf(nz), _pf(r), C.c_int64(se), C.c_int64(sc)), "fill")
@@ -483,13 +500,23 @@ class TPFASystem:
         self.rowptr, self.colidx = csr_pattern(nc, self.hfm)
         self.nnzb = int(self.rowptr[-1] - 1)
         self.pos_acc, self.pos_flux = align(nc, nblk, 2, self.rowptr, self.colidx, self.hfm)
+        self._buf = None
 
-    def assemble(self, law, X, X0, vol, Tf, gdz=None, src_cells=None, src_values=None):
-        acc, hf = update_equation(law, self.nc, self.hfm, X, X0, vol, Tf, gdz)
+    def assemble(self, law, X, X0, vol, Tf, gdz=None, src_cells=None, src_values=None, reuse=False):
+        """reuse=True keeps the Dual caches, the position tables' flat copies and the jac / r buffers between calls (what the
+        reference's storage does); the returned arrays are then overwritten by the next call."""
+        if reuse and getattr(self, "_buf", None) is None:
+            self._buf = dict(flat_pos=(_i(self.pos_acc.T.reshape(-1)), _i(self.pos_flux.T.reshape(-1))))
+        b = self._buf if reuse else None
+        acc, hf = update_equation(law, self.nc, self.hfm, X, X0, vol, Tf, gdz, out=b.get("duals") if b else None)
         if src_cells is not None and len(src_cells):
             apply_sources(acc, src_cells, src_values)
-        return fill_conservation_eq(self.nc, self.nblk, self.hfm, acc, hf, self.pos_acc, self.pos_flux,
-                                    self.nnzb * self.nblk * self.nblk)
+        nz, r = fill_conservation_eq(self.nc, self.nblk, self.hfm, acc, hf, self.pos_acc, self.pos_flux,
+                                     self.nnzb * self.nblk * self.nblk, out=b.get("sys") if b else None,
+                                     flat_pos=b["flat_pos"] if b else None)
+        if b is not None:
+            b["duals"], b["sys"] = (acc, hf), (nz, r)
+        return nz, r
 
 
 def submap_cells(N, indices, nc, buffer=0, excluded=()):
