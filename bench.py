@@ -598,6 +598,31 @@ def measured_traffic(kernel, args, cells, world):
     return None, f"no committed PMC pass matches the current kernel sources (hash {want}): re-run tools/collect_profiles.sh"
 
 
+def usable_cores():
+    """Cores this process may actually use: the minimum of the logical CPUs, the affinity mask and the cgroup CPU quota (the GPU
+    test box shows 256 logical CPUs under a 16-CPU quota: 128 OpenMP threads there spend their time being throttled)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:  # noqa: BLE001
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except Exception:  # noqa: BLE001
+            pass
+    try:  # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            n = min(n, max(1, q // p))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
 def cpu_baseline(args, nc_gpu):
     """The same step sequence (assemble -> ILU(0) refactor -> BiCGStab -> U <- U - x -> U0 <- U) as the GPU leg, same warm-up,
     on the host cores with the oracle (OpenMP restatement of Jutul's ParallelCSRContext path: 8-byte indices, one ILU(0) block per
@@ -611,7 +636,8 @@ def cpu_baseline(args, nc_gpu):
     from jutul_amd import dd
     from oracle import oracle as o
     o.build()
-    threads = o.num_threads()
+    threads = min(o.num_threads(), usable_cores()) if "OMP_NUM_THREADS" not in os.environ else o.num_threads()
+    o.set_num_threads(threads)
     N = 2 if args.law == "twophase" else 1
     p = LAW_PAR[args.law]
     itmax = 200 if N == 2 else 100
@@ -689,6 +715,7 @@ def cpu_baseline(args, nc_gpu):
     b = leg(False, args.cpu_seconds * 0.4, False)
     julia = shutil.which("julia")
     return {"value": round(a["rate"] * a["nc"] / nc_gpu, 5), "unit": "Newton iterations/s", "cores": threads, "kind": "port",
+            "cores_note": f"{threads} OpenMP threads = min(logical CPUs {os.cpu_count()}, affinity, cgroup CPU quota)",
             "linear_iterations_per_step": round(float(np.mean(a["its"])), 2), "linear_iterations_first_steps": (a["wits"] + a["its"])[:8],
             "value_natural_numbering": round(b["rate"] * b["nc"] / nc_gpu, 5),
             "kernels": a["kernels"],

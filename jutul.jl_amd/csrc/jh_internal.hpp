@@ -48,9 +48,27 @@ static inline int32_t guard(F &&f) noexcept {
 
 // ---- host-side parallel loop for the set-up phases (integer work over independent rows / blocks) ------------------------------
 // fn(begin, end) on contiguous index ranges, one per hardware thread (at most 64); exceptions are rethrown on the caller.
+// Cores the set-up may use: hardware threads, capped by the cgroup CPU quota (a container that shows 256 logical CPUs under a
+// 16-CPU quota throttles 64 busy threads instead of running them).
+static inline int64_t setup_cores() {
+  static const int64_t cached = [] {
+    int64_t nt = (int64_t)std::thread::hardware_concurrency();
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0};
+      long long period = 0;
+      if (fscanf(f, "%31s %lld", q, &period) == 2 && period > 0 && q[0] >= '0' && q[0] <= '9') {
+        const long long quota = atoll(q);
+        if (quota > 0) nt = std::min<int64_t>(nt, std::max<int64_t>(1, (quota + period - 1) / period));
+      }
+      fclose(f);
+    }
+    return std::max<int64_t>(1, nt);
+  }();
+  return cached;
+}
 template <class F>
 static inline void parallel_ranges(int64_t n, int64_t min_per_thread, F &&fn) {
-  int64_t nt = (int64_t)std::thread::hardware_concurrency();
+  int64_t nt = setup_cores();
   if (const char *e = getenv("JH_SETUP_THREADS")) nt = atoi(e);
   nt = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nt, 64), n / std::max<int64_t>(1, min_per_thread)));
   if (nt <= 1) { fn((int64_t)0, n); return; }

@@ -274,7 +274,7 @@ void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t npa
     j.start = rim_cell;
     queue.push_back(j);
   }
-  int nt = (int)std::thread::hardware_concurrency();
+  int nt = (int)setup_cores();  // hardware threads, capped by the cgroup CPU quota
   if (const char *e = getenv("JH_SETUP_THREADS")) nt = atoi(e);
   nt = std::max(1, std::min(nt, 64));
   auto worker = [&] {
