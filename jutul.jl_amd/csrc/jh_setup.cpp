@@ -500,7 +500,9 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
         // (polyhedral / PEBI grids) get proportionally fewer rows per block, so that a block's factors and dependency levels
         // stay within what one workgroup holds in LDS.
         const double deg = nc > 0 ? (double)A.ptr[nc] / (double)nc : 0.0;
-        if (deg > 7.0) block_rows = std::max<int64_t>(64, (int64_t)(block_rows * 6.0 / deg) / 32 * 32);
+        // (2M-cell polyhedral grid, 15.5 faces per cell: 96 / 128 / 160 / 192 / 256 rows -> 90 / 86 / 92 / 77 / 85 Newton it/s; from
+        // 192 rows the factorisation program of a block exceeds 64 KB of LDS: 3.1 -> 4.5 ms)
+        if (deg > 7.0) block_rows = std::max<int64_t>(64, (int64_t)(block_rows * 5.0 / deg) / 32 * 32);
       }
       order_blocks(A, nc, n_owned, block_rows, pat->perm, pat->block_ptr, pat->interior_rows, pat->interior_blocks);
     } else if (reorder != JH_REORDER_NONE) {

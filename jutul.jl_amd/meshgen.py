@@ -209,12 +209,16 @@ def polyhedral_dual_mesh(n_points, *, seed=7, grading=1.0, seed_perm=20260928, s
     a = tets[:, pairs[:, 0]].reshape(-1)
     b = tets[:, pairs[:, 1]].reshape(-1)
     lo, hi = np.minimum(a, b), np.maximum(a, b)
-    key = lo * nc + hi
-    uk, invk = np.unique(key, return_inverse=True)
-    l, r = uk // nc, uk % nc
-    nf = uk.size
+    # unique edges in (lo, hi) order with the tet volumes round each edge summed: a COO -> CSR conversion (counting sort in C)
+    # instead of np.unique over 6 * ntet keys (50 s at 2M tets)
+    import scipy.sparse as sp
+    E = sp.coo_matrix((np.repeat(tvol, 6), (lo, hi)), shape=(nc, nc)).tocsr()
+    E.sum_duplicates()
+    E.sort_indices()
+    l, r = np.repeat(np.arange(nc, dtype=np.int64), np.diff(E.indptr)), E.indices.astype(np.int64)
+    nf = l.size
     elen = np.linalg.norm(P[r] - P[l], axis=1)
-    area = np.bincount(invk, weights=np.repeat(tvol, 6), minlength=nf) / (2.0 * np.maximum(elen, 1e-300))
+    area = E.data / (2.0 * np.maximum(elen, 1e-300))
     area = np.maximum(area, 1e-12 * np.median(area))
     K = np.exp(np.random.default_rng(seed_perm_k).uniform(np.log(k_range[0]), np.log(k_range[1]), nc))
     T = 2.0 * K[l] * K[r] / (K[l] + K[r]) * area / np.maximum(elen, 1e-300)
