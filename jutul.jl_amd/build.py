@@ -26,13 +26,14 @@ def build(force=False, verbose=False):
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     headers = [os.path.join(CSRC, "jh_internal.hpp"), os.path.join(HERE, "..", "include", "jutul_hip.h")]
+    extra = os.environ.get("JH_EXTRA_FLAGS", "").split()  # compile-time experiments, e.g. -DJH_PFW_SCALAR=12 (use with force)
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(bdir, src + ".o")
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            jobs.append([hipcc, "-x", "hip"] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc, "-x", "hip"] + FLAGS + extra + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -628,7 +628,11 @@ __global__ __launch_bounds__(LB) void ilu_factor_diag_pipe_kernel(IluDev F, cons
   }
 }
 
-template <int BS>
+// WPR (wave per row; long rows, i.e. the row-major programs of polyhedral cells): a block of ~160 rows of ~15 entries has ~90
+// dependency levels of one or two rows each, so a thread per row leaves the elimination serial (3.1 ms at 2M cells: 0.3 ms per
+// block of LDS round trips); the update pairs of ONE multiplier are independent, so a wavefront takes a row and its lanes the
+// pairs.  Same operations per entry, same order of the multipliers, hence the same bits.
+template <int BS, bool WPR = false>
 __global__ void ilu_factor_prog_kernel(IluDev F, const double *__restrict__ aval, const int32_t *__restrict__ lbase,
                                        const int32_t *__restrict__ ubase, const int32_t *__restrict__ pbase,
                                        const int32_t *__restrict__ jl_map, const int32_t *__restrict__ ju_map,
@@ -671,6 +675,40 @@ __global__ void ilu_factor_prog_kernel(IluDev F, const double *__restrict__ aval
   const int lev0 = F.flev_off[b], nlev = F.flev_off[b + 1] - 1 - lev0;
   for (int lev = 0; lev < nlev; ++lev) {
     const int s = F.flev_ptr[lev0 + lev] - b0, e = F.flev_ptr[lev0 + lev + 1] - b0;
+    if (WPR) {
+      const int lane = tid & 63, wv = tid >> 6, nwv = T >> 6;
+      for (int t = s + wv; t < e; t += nwv) {  // wave-uniform
+        int pc = rptr[t];
+        const int pe = rptr[t + 1];
+        while (pc < pe) {
+          const int lidx = code[pc], kd = code[pc + 1], nupd = code[pc + 2];
+          pc += 3;
+          // (every lane forms the multiplier from the same LDS words; lane 0 stores it)
+          const Blk<BS> lik = blk_mul<BS>(blk_load<BS>(vals + (size_t)lidx * BB), blk_load<BS>(vals + (size_t)kd * BB));  // nz_l * inv(A_kk)
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) blk_store<BS>(vals + (size_t)lidx * BB, lik);
+          if (blk_nonzero<BS>(lik)) {
+            for (int u = lane; u < nupd; u += 64) {  // distinct targets: the pairs of one multiplier are independent
+              const int tgt = code[pc + 2 * u], src = code[pc + 2 * u + 1];
+              Blk<BS> v = blk_load<BS>(vals + (size_t)tgt * BB);
+              blk_sub<BS>(v, blk_mul<BS>(lik, blk_load<BS>(vals + (size_t)src * BB)));
+              blk_store<BS>(vals + (size_t)tgt * BB, v);
+            }
+          }
+          pc += 2 * nupd;
+          // the next multiplier of this row may be one of the targets just updated (by another lane)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (lane == 0) {
+          const int di = rdiag[t];
+          blk_store<BS>(vals + (size_t)di * BB, blk_inv<BS>(blk_load<BS>(vals + (size_t)di * BB)));
+        }
+      }
+      __syncthreads();
+      continue;
+    }
     for (int t = s + tid; t < e; t += T) {
       int pc = rptr[t];
       const int pe = rptr[t + 1];
@@ -784,7 +822,15 @@ __device__ __forceinline__ void bwd_row(const IluDev &F, int pos, int lt, double
 // entries) before it can touch LDS (0.66 ms at 10M cells).  Nothing but the LDS vector depends on earlier levels, so the factor data of
 // level l+1 (entries) and l+2 (row pointers) is fetched into registers while level l computes: the per-level
 // critical path shrinks to LDS latency + one barrier.  Rows longer than PFW entries take a slow tail loop.
-constexpr int PFW = 4;
+// (scalar matrices: 12 since round 3 -- only rows beyond the jagged layouts still take these kernels, i.e. polyhedral cells with ~6
+// strict-L / strict-U entries per row on average, whose tails were global loads inside the level loop.  2M-cell polyhedral grid,
+// width 4 / 8 / 12: solve 8.03 / 6.29 / 6.11 ms, 99.7 / 120.7 / 123.5 Newton it/s; 116 VGPRs, no scratch.  -DJH_PFW_SCALAR=n
+// through JH_EXTRA_FLAGS for experiments.)
+#ifndef JH_PFW_SCALAR
+#define JH_PFW_SCALAR 12
+#endif
+template <int BS> struct PfWidth { static constexpr int value = BS == 1 ? JH_PFW_SCALAR : 4; };
+#define PFW (PfWidth<BS>::value)
 
 template <int BS>
 struct RowPF {
@@ -2221,8 +2267,8 @@ void ilu_factor(jh_ilu M) {
 #define JH_PROG(BSV)                                                                                                             \
     do {                                                                                                                          \
       if (M->prog_lds_bytes > 64 * 1024)                                                                                          \
-        JH_HIP(hipFuncSetAttribute((const void *)ilu_factor_prog_kernel<BSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes)); \
-      hipLaunchKernelGGL(ilu_factor_prog_kernel<BSV>, dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
+        JH_HIP(hipFuncSetAttribute((const void *)ilu_factor_prog_kernel<BSV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes)); \
+      hipLaunchKernelGGL((ilu_factor_prog_kernel<BSV, false>), dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
                          M->d_blk_ubase.p, M->d_blk_prog.p, M->d_jl_map.p, M->d_ju_map.p, M->d_jd_map.p, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p); \
     } while (0)
     switch (M->bs) { case 1: JH_PROG(1); break; case 2: JH_PROG(2); break; case 3: JH_PROG(3); break; }
@@ -2235,11 +2281,15 @@ void ilu_factor(jh_ilu M) {
     IluDev F = dev_view(M);
     const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
     static const int pthreads = getenv("JH_ILU_FACTOR_THREADS") ? atoi(getenv("JH_ILU_FACTOR_THREADS")) : 512;
+    static const bool wpr = getenv("JH_ILU_FACTOR_NO_WPR") == nullptr;  // wave per row (long rows); 0: thread per row
 #define JH_PROGR(BSV)                                                                                                            \
     do {                                                                                                                          \
       if (M->prog_lds_bytes > 64 * 1024)                                                                                          \
-        JH_HIP(hipFuncSetAttribute((const void *)ilu_factor_prog_kernel<BSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes)); \
-      hipLaunchKernelGGL(ilu_factor_prog_kernel<BSV>, dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
+        JH_HIP(hipFuncSetAttribute(wpr ? (const void *)ilu_factor_prog_kernel<BSV, true> : (const void *)ilu_factor_prog_kernel<BSV, false>,        \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes));                                         \
+      if (wpr) hipLaunchKernelGGL((ilu_factor_prog_kernel<BSV, true>), dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
+                         M->d_blk_ubase.p, M->d_blk_prog.p, M->d_l_map.p, M->d_u_map.p, M->d_d_map.p, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p); \
+      else hipLaunchKernelGGL((ilu_factor_prog_kernel<BSV, false>), dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
                          M->d_blk_ubase.p, M->d_blk_prog.p, M->d_l_map.p, M->d_u_map.p, M->d_d_map.p, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p); \
     } while (0)
     switch (M->bs) { case 1: JH_PROGR(1); break; case 2: JH_PROGR(2); break; case 3: JH_PROGR(3); break; }
