@@ -24,85 +24,95 @@ __device__ __forceinline__ int xcd_tile_a(int b, int ntiles) {
 }
 
 // ---- forward-mode duals over the 2N primary variables of (self, other) ------------------------------------------
-template <int NP>
+// Sparse: M is the compile-time set of partials that can be non-zero; the others are never computed.  A dense Dual<4> product
+// costs 1 + 8 multiplies and 4 adds whatever its operands depend on (0 * x cannot be folded under IEEE rules); in the
+// two-phase flux a density depends on one of the four variables, a mobility on two, and 45 % of the kernel's VALU instructions
+// were products with structural zeros.  For finite values the results are bit-identical to the dense duals (x + 0*y == x).
+template <unsigned M>
 struct Dual {
   double v;
-  double d[NP];
+  double d[4];
 };
-template <int NP> __device__ __forceinline__ Dual<NP> dconst(double v) {
-  Dual<NP> r; r.v = v;
+#define JH_HAS(M, i) ((((M) >> (i)) & 1u) != 0u)
+__device__ __forceinline__ Dual<0u> dconst(double v) {
+  Dual<0u> r; r.v = v;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) r.d[i] = 0.0;
+  for (int i = 0; i < 4; ++i) r.d[i] = 0.0;
   return r;
 }
-template <int NP> __device__ __forceinline__ Dual<NP> dvar(double v, int idx) {
-  Dual<NP> r = dconst<NP>(v);
-  r.d[idx] = 1.0;
-  return r;
-}
-template <int NP> __device__ __forceinline__ Dual<NP> operator+(Dual<NP> a, Dual<NP> b) {
-  Dual<NP> r; r.v = a.v + b.v;
+template <int IDX> __device__ __forceinline__ Dual<(1u << IDX)> dvar(double v) {
+  Dual<(1u << IDX)> r; r.v = v;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] + b.d[i];
+  for (int i = 0; i < 4; ++i) r.d[i] = (i == IDX) ? 1.0 : 0.0;
   return r;
 }
-template <int NP> __device__ __forceinline__ Dual<NP> operator-(Dual<NP> a, Dual<NP> b) {
-  Dual<NP> r; r.v = a.v - b.v;
+template <unsigned A, unsigned B> __device__ __forceinline__ Dual<(A | B)> operator+(Dual<A> a, Dual<B> b) {
+  Dual<(A | B)> r; r.v = a.v + b.v;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] - b.d[i];
+  for (int i = 0; i < 4; ++i)
+    r.d[i] = (JH_HAS(A, i) && JH_HAS(B, i)) ? a.d[i] + b.d[i] : JH_HAS(A, i) ? a.d[i] : JH_HAS(B, i) ? b.d[i] : 0.0;
   return r;
 }
-template <int NP> __device__ __forceinline__ Dual<NP> operator*(Dual<NP> a, Dual<NP> b) {
-  Dual<NP> r; r.v = a.v * b.v;
+template <unsigned A, unsigned B> __device__ __forceinline__ Dual<(A | B)> operator-(Dual<A> a, Dual<B> b) {
+  Dual<(A | B)> r; r.v = a.v - b.v;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+  for (int i = 0; i < 4; ++i)
+    r.d[i] = (JH_HAS(A, i) && JH_HAS(B, i)) ? a.d[i] - b.d[i] : JH_HAS(A, i) ? a.d[i] : JH_HAS(B, i) ? -b.d[i] : 0.0;
   return r;
 }
-template <int NP> __device__ __forceinline__ Dual<NP> operator*(double s, Dual<NP> a) {
-  Dual<NP> r; r.v = s * a.v;
+template <unsigned A, unsigned B> __device__ __forceinline__ Dual<(A | B)> operator*(Dual<A> a, Dual<B> b) {
+  Dual<(A | B)> r; r.v = a.v * b.v;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) r.d[i] = s * a.d[i];
+  for (int i = 0; i < 4; ++i)
+    r.d[i] = (JH_HAS(A, i) && JH_HAS(B, i)) ? a.d[i] * b.v + a.v * b.d[i]
+             : JH_HAS(A, i)                 ? a.d[i] * b.v
+             : JH_HAS(B, i)                 ? a.v * b.d[i]
+                                            : 0.0;
   return r;
 }
-template <int NP> __device__ __forceinline__ Dual<NP> ddiv(Dual<NP> a, double s) {
-  Dual<NP> r; r.v = a.v / s;
+template <unsigned A> __device__ __forceinline__ Dual<A> operator*(double s, Dual<A> a) {
+  Dual<A> r; r.v = s * a.v;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) r.d[i] = a.d[i] / s;
+  for (int i = 0; i < 4; ++i) r.d[i] = JH_HAS(A, i) ? s * a.d[i] : 0.0;
   return r;
 }
-template <int NP> __device__ __forceinline__ Dual<NP> dexp(Dual<NP> a) {
+template <unsigned A> __device__ __forceinline__ Dual<A> ddiv(Dual<A> a, double s) {
+  Dual<A> r; r.v = a.v / s;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.d[i] = JH_HAS(A, i) ? a.d[i] / s : 0.0;
+  return r;
+}
+template <unsigned A> __device__ __forceinline__ Dual<A> dexp(Dual<A> a) {
   double e = exp(a.v);
-  Dual<NP> r; r.v = e;
+  Dual<A> r; r.v = e;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) r.d[i] = e * a.d[i];
+  for (int i = 0; i < 4; ++i) r.d[i] = JH_HAS(A, i) ? e * a.d[i] : 0.0;
+  return r;
+}
+// c ? a : b (the upwind choice between two mobilities that depend on different cells)
+template <unsigned A, unsigned B> __device__ __forceinline__ Dual<(A | B)> dselect(bool c, Dual<A> a, Dual<B> b) {
+  Dual<(A | B)> r; r.v = c ? a.v : b.v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.d[i] = c ? (JH_HAS(A, i) ? a.d[i] : 0.0) : (JH_HAS(B, i) ? b.d[i] : 0.0);
   return r;
 }
 
 struct LawPar {
   double rho0[2], comp[2], mu[2], p_ref;
+  double inv_mu[2];  // 1.0 / mu[ph], formed once on the host (the same IEEE quotient the per-lane division produced)
 };
-template <int NP> __device__ __forceinline__ Dual<NP> density(const LawPar &P, int ph, Dual<NP> p) {
-  return P.rho0[ph] * dexp(P.comp[ph] * (p - dconst<NP>(P.p_ref)));  // rho0*exp(c*(p-p0))
+// argument of the density's exponential; ONE expression for every place that evaluates it, so that an exponential computed
+// once and handed over through LDS has the bits of one computed in place
+__device__ __forceinline__ double density_arg(const LawPar &P, int ph, double p) { return P.comp[ph] * (p - P.p_ref); }
+template <unsigned A> __device__ __forceinline__ Dual<A> density(const LawPar &P, int ph, Dual<A> p) {
+  return P.rho0[ph] * dexp(P.comp[ph] * (p - dconst(P.p_ref)));  // rho0*exp(c*(p-p0))
 }
-
-// the same density from E = exp(c*(p - p0)) evaluated once per cell (twophase_exp_kernel): identical operations on identical
-// inputs, hence the same bits as density()
-template <int NP> __device__ __forceinline__ Dual<NP> density_from_exp(const LawPar &P, int ph, double E, int var) {
-  Dual<NP> a = dconst<NP>(0.0);  // c * (p - p0): only its partials are needed
-  a.d[var] = P.comp[ph] * 1.0;
-  Dual<NP> r; r.v = E;
-#pragma unroll
-  for (int i = 0; i < NP; ++i) r.d[i] = E * a.d[i];
+// the same density from E = exp(density_arg(p)) evaluated elsewhere (once per cell of the tile instead of once per entry):
+// identical operations on identical inputs, hence the same bits as density()
+template <int VAR> __device__ __forceinline__ Dual<(1u << VAR)> density_from_exp(const LawPar &P, int ph, double E) {
+  Dual<(1u << VAR)> r = dvar<VAR>(E);
+  r.d[VAR] = E * (P.comp[ph] * 1.0);
   return P.rho0[ph] * r;
-}
-// E[2c + ph] = exp(comp[ph] * (p_c - p_ref)): the four software fp64 exponentials per entry of the two-phase flux become
-// four loads (per-cell property pre-pass; 32 B per cell of extra traffic against ~16 exp evaluations per cell)
-__global__ void twophase_exp_kernel(const double *__restrict__ X, double *__restrict__ E, int64_t nc, LawPar par) {
-  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nc; c += (int64_t)gridDim.x * blockDim.x) {
-    const double p = X[2 * c];
-    E[2 * c] = exp(par.comp[0] * (p - par.p_ref));
-    E[2 * c + 1] = exp(par.comp[1] * (p - par.p_ref));
-  }
 }
 
 // flux of the scalar laws across one half-face with its derivatives w.r.t. the self / other primary variable (shared by the
@@ -115,28 +125,91 @@ __device__ __forceinline__ void flux_scalar(double Us, double Uo, double T, doub
     dself = T;
     dother = -T;
   } else {
-    Dual<2> ps = dvar<2>(Us, 0), po = dvar<2>(Uo, 1);
-    Dual<2> rs = density(par, 0, ps), ro = density(par, 0, po);
-    Dual<2> ravg = 0.5 * (rs + ro);             // face_average (flux.jl:372-375)
-    Dual<2> dphi = (ps - po) + gz * ravg;       // two_point_potential_drop (flux.jl:335-338)
-    Dual<2> f = (T / par.mu[0]) * (ravg * dphi);
+    auto ps = dvar<0>(Us);
+    auto po = dvar<1>(Uo);
+    auto rs = density(par, 0, ps);
+    auto ro = density(par, 0, po);
+    auto ravg = 0.5 * (rs + ro);             // face_average (flux.jl:372-375)
+    auto dphi = (ps - po) + gz * ravg;       // two_point_potential_drop (flux.jl:335-338)
+    auto f = (T / par.mu[0]) * (ravg * dphi);
     q = f.v;
     dself = f.d[0];
     dother = f.d[1];
   }
 }
+// flux of the two-phase law across one half-face: values of both equations, derivatives w.r.t. the self cell's (p, S) in ds
+// (column-major (e, d)) and w.r.t. the other cell's in dother (shared by the tile kernel and the pipelined kernel)
+__device__ __forceinline__ void flux_twophase(double ps_, double ss_, double po_, double so_, const double Eself[2],
+                                              const double Eoth[2], double T, double gz, const LawPar &par, double q2[2],
+                                              double ds[4], double dother[4]) {
+  auto ps = dvar<0>(ps_);
+  auto ss_w = dvar<1>(ss_);
+  auto po = dvar<2>(po_);
+  auto so_w = dvar<3>(so_);
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph) {
+    auto rs = density_from_exp<0>(par, ph, Eself[ph]);
+    auto ro = density_from_exp<2>(par, ph, Eoth[ph]);
+    auto ravg = 0.5 * (rs + ro);
+    auto dphi = (ps - po) + gz * ravg;
+    auto ss = ph == 0 ? ss_w : dconst(1.0) - ss_w;
+    auto so = ph == 0 ? so_w : dconst(1.0) - so_w;
+    auto ms = par.inv_mu[ph] * ((ss * ss) * rs);
+    auto mo = par.inv_mu[ph] * ((so * so) * ro);
+    auto up = dselect(dphi.v < 0.0, mo, ms);  // SPU upwind (flux.jl:382-405)
+    auto q = T * (up * dphi);
+    q2[ph] = q.v;
+    ds[0 * 2 + ph] = q.d[0];  // (e = ph, d = 0), column-major
+    ds[1 * 2 + ph] = q.d[1];
+    dother[0 * 2 + ph] = q.d[2];
+    dother[1 * 2 + ph] = q.d[3];
+  }
+}
+// accumulation term of the two-phase law for one row: (M - M0)/dt with its derivatives w.r.t. the row's (p, S)
+__device__ __forceinline__ void accum_twophase(double p, double sw_, double p0, double sw0, const double E[2], double vol,
+                                               double dt, const LawPar &par, double ar[2], double ap[4]) {
+  auto sw = dvar<1>(sw_);
+  auto so = dconst(1.0) - sw;
+  auto Mw = vol * (density_from_exp<0>(par, 0, E[0]) * sw);
+  auto Mo = vol * (density_from_exp<0>(par, 1, E[1]) * so);
+  double Mw0 = vol * (density(par, 0, dconst(p0)).v * sw0);
+  double Mo0 = vol * (density(par, 1, dconst(p0)).v * (1.0 - sw0));
+  auto aw = ddiv(Mw - dconst(Mw0), dt);
+  auto ao = ddiv(Mo - dconst(Mo0), dt);
+  ar[0] = aw.v; ar[1] = ao.v;
+  ap[0] = aw.d[0]; ap[1] = ao.d[0]; ap[2] = aw.d[1]; ap[3] = ao.d[1];  // column-major (e, d)
+}
+
+// Store of a tile's 2x2 blocks.  A lane that stores its own block issues four 8-byte stores 32 bytes apart from its neighbours':
+// every store instruction touches a quarter of each line.  The off-diagonal blocks go to their (free by now) dsv slots next to
+// the parked diagonal blocks instead, and the tile's nzval range leaves the CU as one linear copy, 16 bytes per lane.
+template <int KPT>
+__device__ __forceinline__ void store_blocks2(double *__restrict__ nz, double *dsv, const double (*off)[4], const bool *isdiag,
+                                              int base, int cnt, int tid) {
+#pragma unroll
+  for (int kk = 0; kk < KPT; ++kk) {
+    const int k = tid + kk * TILE_THREADS;
+    if (k < cnt && !isdiag[kk]) {
+      reinterpret_cast<double2 *>(dsv)[k * 2] = make_double2(off[kk][0], off[kk][1]);
+      reinterpret_cast<double2 *>(dsv)[k * 2 + 1] = make_double2(off[kk][2], off[kk][3]);
+    }
+  }
+  __syncthreads();
+  double2 *dst = reinterpret_cast<double2 *>(nz + (size_t)base * 4);
+  for (int i = tid; i < cnt * 2; i += TILE_THREADS) dst[i] = reinterpret_cast<const double2 *>(dsv)[i];
+}
 // ---- the kernel -------------------------------------------------------------------------------------------------
-template <int KIND, bool PRE = false>
+template <int KIND>
 __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
     const int32_t *__restrict__ tile_row, int ntiles, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const int32_t *__restrict__ diag, const double *__restrict__ Tnz, const double *__restrict__ gnz, const double *__restrict__ X,
     const double *__restrict__ X0, double *__restrict__ nz, double *__restrict__ r, double dt, LawPar par, int reg_row,
-    int nrows_total, const double *__restrict__ Eexp) {
+    int nrows_total) {
   constexpr int N = (KIND == JH_LAW_TWOPHASE) ? 2 : 1;
   constexpr int NN = N * N;
   constexpr int TNNZ = (N == 1) ? TILE_NNZ : TILE_NNZ / 2;  // tile entry budget (Pattern::build_tiles)
   __shared__ double qv[TNNZ * N];    // flux values per entry
-  __shared__ double dsv[TNNZ * NN];  // d q / d x_self per entry (column-major N x N)
+  __shared__ __align__(16) double dsv[TNNZ * NN];  // d q / d x_self per entry (column-major N x N)
   // Rows staged on either side of the tile's own rows.  0: a +-128-row window (82% instead of 66% of the neighbours in
   // LDS) did not shorten the launch (0.331 vs 0.335 ms) and raised the measured HBM traffic from 1.48 to 1.65 GB.
   constexpr int WIN = 0;
@@ -192,43 +265,29 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
       isdiag[kk] = true;
       continue;
     }
-    if (KIND != JH_LAW_TWOPHASE) {
+    if constexpr (N == 1) {
       const double gz = gnz ? gnz[base + k] : 0.0;
       double q, ds, dother_;
-      flux_scalar<KIND>(xs[own + lr], inl ? xs[cw] : X[c], T, gz, par, q, ds, dother_);
+      flux_scalar<KIND>(xs[own + lr], lds_or_global(xs, cw, inl, X, (size_t)c), T, gz, par, q, ds, dother_);
       qv[k] = q;
       dsv[k] = ds;
       off[kk][0] = dother_;
     } else {
       const double gz = gnz ? gnz[base + k] : 0.0;
-      Dual<4> ps = dvar<4>(xs[(own + lr) * 2], 0), ss_w = dvar<4>(xs[(own + lr) * 2 + 1], 1);
-      Dual<4> po = dvar<4>(inl ? xs[cw * 2] : X[(size_t)c * 2], 2);
-      Dual<4> so_w = dvar<4>(inl ? xs[cw * 2 + 1] : X[(size_t)c * 2 + 1], 3);
-      // exp(c (p - p0)) of both cells and both phases: from the per-cell pre-pass (own rows: consecutive, served by the vector
-      // L1; neighbours: one 16-byte gather next to the 16-byte gather of their primary variables)
-      double Es[2], Eo[2];
-      if (PRE) {
-        const double2 es = reinterpret_cast<const double2 *>(Eexp)[r0 + lr], eo = reinterpret_cast<const double2 *>(Eexp)[c];
-        Es[0] = es.x; Es[1] = es.y; Eo[0] = eo.x; Eo[1] = eo.y;
-      }
+      const double ps = xs[(own + lr) * 2], ss = xs[(own + lr) * 2 + 1];
+      const double po = lds_or_global(xs, cw * 2, inl, X, (size_t)c * 2);
+      const double so = lds_or_global(xs, cw * 2 + 1, inl, X, (size_t)c * 2 + 1);
+      double Eself[2], Eoth[2], q2[2], ds[4];
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph) {
-        Dual<4> rs = PRE ? density_from_exp<4>(par, ph, Es[ph], 0) : density(par, ph, ps);
-        Dual<4> ro = PRE ? density_from_exp<4>(par, ph, Eo[ph], 2) : density(par, ph, po);
-        Dual<4> ravg = 0.5 * (rs + ro);
-        Dual<4> dphi = (ps - po) + gz * ravg;
-        Dual<4> ss = ph == 0 ? ss_w : dconst<4>(1.0) - ss_w;
-        Dual<4> so = ph == 0 ? so_w : dconst<4>(1.0) - so_w;
-        Dual<4> ms = (1.0 / par.mu[ph]) * ((ss * ss) * rs);
-        Dual<4> mo = (1.0 / par.mu[ph]) * ((so * so) * ro);
-        Dual<4> up = (dphi.v < 0.0) ? mo : ms;  // SPU upwind (flux.jl:382-405)
-        Dual<4> q = T * (up * dphi);
-        qv[k * 2 + ph] = q.v;
-        dsv[k * 4 + 0 * 2 + ph] = q.d[0];  // (e=ph, d=0) column-major
-        dsv[k * 4 + 1 * 2 + ph] = q.d[1];
-        off[kk][(0 * 2 + ph) % NN] = q.d[2];
-        off[kk][(1 * 2 + ph) % NN] = q.d[3];
+        Eself[ph] = exp(density_arg(par, ph, ps));
+        Eoth[ph] = exp(density_arg(par, ph, po));
       }
+      flux_twophase(ps, ss, po, so, Eself, Eoth, T, gz, par, q2, ds, off[kk]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) qv[k * 2 + e] = q2[e];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dsv[k * 4 + i] = ds[i];
     }
   }
   __syncthreads();
@@ -252,23 +311,15 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
           ap[0] = (row == reg_row) ? 1e-10 : 0.0;
         }
       } else if (KIND == JH_LAW_COMPRESSIBLE) {
-        Dual<2> p = dvar<2>(xs[own + tid], 0);
-        Dual<2> M = vol * density(par, 0, p);
-        double M0 = vol * density(par, 0, dconst<2>(X0[row])).v;
-        Dual<2> a = ddiv(M - dconst<2>(M0), dt);
+        auto p = dvar<0>(xs[own + tid]);
+        auto M = vol * density(par, 0, p);
+        double M0 = vol * density(par, 0, dconst(X0[row])).v;
+        auto a = ddiv(M - dconst(M0), dt);
         ar[0] = a.v;
         ap[0] = a.d[0];
-      } else {
-        Dual<4> p = dvar<4>(xs[(own + tid) * 2], 0), sw = dvar<4>(xs[(own + tid) * 2 + 1], 1);
-        Dual<4> so = dconst<4>(1.0) - sw;
-        const double p0 = X0[(size_t)row * 2], sw0 = X0[(size_t)row * 2 + 1];
-        Dual<4> Mw = vol * ((PRE ? density_from_exp<4>(par, 0, Eexp[(size_t)row * 2], 0) : density(par, 0, p)) * sw);
-        Dual<4> Mo = vol * ((PRE ? density_from_exp<4>(par, 1, Eexp[(size_t)row * 2 + 1], 0) : density(par, 1, p)) * so);
-        double Mw0 = vol * (density(par, 0, dconst<4>(p0)).v * sw0);
-        double Mo0 = vol * (density(par, 1, dconst<4>(p0)).v * (1.0 - sw0));
-        Dual<4> aw = ddiv(Mw - dconst<4>(Mw0), dt), ao = ddiv(Mo - dconst<4>(Mo0), dt);
-        ar[0] = aw.v; ar[1] = ao.v;
-        ap[0] = aw.d[0]; ap[1] = ao.d[0]; ap[2] = aw.d[1]; ap[3] = ao.d[1];  // column-major (e, d)
+      } else if constexpr (N == 2) {
+        const double p = xs[(own + tid) * 2], E[2] = {exp(density_arg(par, 0, p)), exp(density_arg(par, 1, p))};
+        accum_twophase(p, xs[(own + tid) * 2 + 1], X0[(size_t)row * 2], X0[(size_t)row * 2 + 1], E, vol, dt, par, ar, ap);
       }
     }
     for (int j = rp[tid]; j < rp[tid + 1]; ++j) {
@@ -286,13 +337,17 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
   }
   __syncthreads();
   // ---- phase 3: every lane stores its entries; nzval lines leave the CU complete ---------------------------------------
+  if constexpr (N == 2) {
+    store_blocks2<KPT>(nz, dsv, off, isdiag, base, cnt, tid);
+  } else {
 #pragma unroll
-  for (int kk = 0; kk < KPT; ++kk) {
-    const int k = tid + kk * TILE_THREADS;
-    if (k >= cnt) continue;
-    double *blk = nz + (size_t)(base + k) * NN;
+    for (int kk = 0; kk < KPT; ++kk) {
+      const int k = tid + kk * TILE_THREADS;
+      if (k >= cnt) continue;
+      double *blk = nz + (size_t)(base + k) * NN;
 #pragma unroll
-    for (int i = 0; i < NN; ++i) blk[i] = isdiag[kk] ? dsv[k * NN + i] : off[kk][i];
+      for (int i = 0; i < NN; ++i) blk[i] = isdiag[kk] ? dsv[k * NN + i] : off[kk][i];
+    }
   }
 }
 
@@ -303,31 +358,37 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_tile_kernel(
 // the first-level loads of its next tile before it computes the current one.  The diagonal slot's Tnz value IS the row's
 // accumulation coefficient and its position IS diag[row]: the entry lane that owns the slot hands both to the row lane
 // through LDS, so the row phase needs no dependent global load (and the diag array is not read at all).
+template <int N, int KPT>
 struct AsmPre {
   int r0, nrows, base, cnt;
-  int cidx[TILE_NNZ / TILE_THREADS];
-  double Tk[TILE_NNZ / TILE_THREADS], gz[TILE_NNZ / TILE_THREADS];
-  double xrow, x0;
+  int cidx[KPT];
+  double Tk[KPT], gz[KPT];
+  double xrow[N], x0[N];
   int rpv;
 };
 template <int KIND>
 __global__ __launch_bounds__(TILE_THREADS) void assemble_pipe_kernel(
     const int32_t *__restrict__ tile_desc, int ntiles, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const double *__restrict__ Tnz, const double *__restrict__ gnz, const double *__restrict__ X, const double *__restrict__ X0,
-    double *__restrict__ nz, double *__restrict__ r, double dt, LawPar par, int reg_row) {
-  constexpr int KPT = TILE_NNZ / TILE_THREADS;
-  __shared__ double qv[TILE_NNZ];
-  __shared__ double dsv[TILE_NNZ];
-  __shared__ double xs[TILE_ROWS];
+    double *__restrict__ nz, double *__restrict__ r, double dt, LawPar par, int reg_row, int nrows_total) {
+  constexpr int N = (KIND == JH_LAW_TWOPHASE) ? 2 : 1;
+  constexpr int NN = N * N;
+  constexpr int TNNZ = (N == 1) ? TILE_NNZ : TILE_NNZ / 2;  // tile entry budget (Pattern::build_tiles)
+  constexpr int KPT = TNNZ / TILE_THREADS;
+  __shared__ double qv[TNNZ * N];
+  __shared__ __align__(16) double dsv[TNNZ * NN];
+  // primary variables of the TILE_ROWS rows from the tile's first row on: the tile's own rows (<= TILE_ROWS; ~100 for 2x2
+  // blocks) and the rows after them, which hold most of the remaining neighbours (the device blocks are contiguous)
+  __shared__ double xs[TILE_ROWS * N];
   __shared__ double volrow[TILE_ROWS];
-  __shared__ int32_t rp[TILE_ROWS + 1];
+  __shared__ uint16_t rp[TILE_ROWS + 2];  // entry offsets inside the tile (<= TILE_NNZ)
   __shared__ uint16_t diagk[TILE_ROWS];
-  __shared__ uint8_t rowof[TILE_NNZ];
+  __shared__ uint8_t rowof[TNNZ];
   const int tid = threadIdx.x;
   const int chunk = (ntiles + NUM_XCD - 1) / NUM_XCD;
   const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, wgs = gridDim.x / NUM_XCD;
   auto in_range = [&](int tl) { return tl < chunk && xcd * chunk + tl < ntiles; };
-  auto issue = [&](int tl, AsmPre &P) {
+  auto issue = [&](int tl, AsmPre<N, KPT> &P) {
     const int4 td = reinterpret_cast<const int4 *>(tile_desc)[xcd * chunk + tl];
     P.r0 = td.x; P.nrows = td.y; P.base = td.z; P.cnt = td.w;
 #pragma unroll
@@ -338,11 +399,15 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_pipe_kernel(
       P.gz[kk] = (gnz && k < P.cnt) ? gnz[P.base + k] : 0.0;
     }
     const bool rowlane = tid < P.nrows;
-    P.xrow = rowlane ? X[P.r0 + tid] : 0.0;
-    P.x0 = rowlane ? X0[P.r0 + tid] : 0.0;
+    const bool winlane = P.r0 + tid < nrows_total;  // TILE_THREADS == TILE_ROWS: one window row per lane
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      P.xrow[e] = winlane ? X[(size_t)(P.r0 + tid) * N + e] : 0.0;
+      P.x0[e] = rowlane ? X0[(size_t)(P.r0 + tid) * N + e] : 0.0;
+    }
     P.rpv = rowlane ? rowptr[P.r0 + tid] - P.base : P.cnt;
   };
-  AsmPre cur, nxt;
+  AsmPre<N, KPT> cur, nxt;
   int tl = wg;
   bool have = in_range(tl);
   if (have) issue(tl, cur);
@@ -350,75 +415,112 @@ __global__ __launch_bounds__(TILE_THREADS) void assemble_pipe_kernel(
     const int tln = tl + wgs;
     const bool have_next = in_range(tln);
     if (have_next) issue(tln, nxt);
-    const int r0 = cur.r0, nrows = cur.nrows, r1 = r0 + nrows, base = cur.base, cnt = cur.cnt;
-    rp[tid] = cur.rpv;
-    if (tid == 0) rp[nrows] = cnt;
-    xs[tid] = cur.xrow;
+    const int r0 = cur.r0, nrows = cur.nrows, base = cur.base, cnt = cur.cnt;
+    const int wn = min(TILE_ROWS, nrows_total - r0);  // rows in the LDS window
+    rp[tid] = (uint16_t)cur.rpv;
+    if (tid == 0) rp[nrows] = (uint16_t)cnt;
+#pragma unroll
+    for (int e = 0; e < N; ++e) xs[tid * N + e] = cur.xrow[e];
     __syncthreads();
     if (tid < nrows)
       for (int j = rp[tid]; j < rp[tid + 1]; ++j) rowof[j] = (uint8_t)tid;
     __syncthreads();
     // phase 1: one lane per CSR entry; off-diagonals stay in registers until the coalesced store of phase 3
-    double off[KPT];
+    double off[KPT][NN];
     bool isdiag[KPT];
 #pragma unroll
     for (int kk = 0; kk < KPT; ++kk) {
       const int k = tid + kk * TILE_THREADS;
       isdiag[kk] = false;
-      off[kk] = 0.0;
+#pragma unroll
+      for (int i = 0; i < NN; ++i) off[kk][i] = 0.0;
       if (k >= cnt) continue;
       const int lr = rowof[k];
       const int c = cur.cidx[kk];
       if (c == r0 + lr) {  // diagonal slot: no flux; hand the accumulation coefficient and the slot to the row lane
-        qv[k] = 0.0;
-        dsv[k] = 0.0;
+#pragma unroll
+        for (int e = 0; e < N; ++e) qv[k * N + e] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NN; ++i) dsv[k * NN + i] = 0.0;
         volrow[lr] = cur.Tk[kk];
         diagk[lr] = (uint16_t)k;
         isdiag[kk] = true;
         continue;
       }
-      const double Uo = (c >= r0 && c < r1) ? xs[c - r0] : X[c];
-      double q, ds, dother_;
-      flux_scalar<KIND>(xs[lr], Uo, cur.Tk[kk], cur.gz[kk], par, q, ds, dother_);
-      qv[k] = q;
-      dsv[k] = ds;
-      off[kk] = dother_;
+      const unsigned cw = (unsigned)(c - r0);
+      const bool inl = cw < (unsigned)wn;
+      if constexpr (N == 1) {
+        const double Uo = lds_or_global(xs, cw, inl, X, (size_t)c);
+        double q, ds, dother_;
+        flux_scalar<KIND>(xs[lr], Uo, cur.Tk[kk], cur.gz[kk], par, q, ds, dother_);
+        qv[k] = q;
+        dsv[k] = ds;
+        off[kk][0] = dother_;
+      } else {
+        const double ps = xs[lr * 2], ss = xs[lr * 2 + 1];
+        const double po = lds_or_global(xs, cw * 2, inl, X, (size_t)c * 2);
+        const double so = lds_or_global(xs, cw * 2 + 1, inl, X, (size_t)c * 2 + 1);
+        double Eself[2], Eoth[2], q2[2], ds[4];
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          Eself[ph] = exp(density_arg(par, ph, ps));
+          Eoth[ph] = exp(density_arg(par, ph, po));
+        }
+        flux_twophase(ps, ss, po, so, Eself, Eoth, cur.Tk[kk], cur.gz[kk], par, q2, ds, off[kk]);
+#pragma unroll
+        for (int e = 0; e < N; ++e) qv[k * N + e] = q2[e];
+#pragma unroll
+        for (int i = 0; i < NN; ++i) dsv[k * NN + i] = ds[i];
+      }
     }
     __syncthreads();
     // phase 2: one lane per row
     if (tid < nrows) {
       const int row = r0 + tid;
-      const double vol = volrow[tid], U = xs[tid];
-      double ar, ap;
+      const double vol = volrow[tid];
+      double ar[N], ap[NN];
       if (KIND == JH_LAW_POISSON) {
+        const double U = xs[tid];
         if (dt > 0.0) {
-          ar = (vol * U - vol * cur.x0) / dt;
-          ap = vol / dt;
+          ar[0] = (vol * U - vol * cur.x0[0]) / dt;
+          ap[0] = vol / dt;
         } else {  // stationary variant with the 1e-10*U regulariser on host cell 1 (variable_poisson.jl:101-104)
-          ar = (row == reg_row) ? 1e-10 * U : 0.0;
-          ap = (row == reg_row) ? 1e-10 : 0.0;
+          ar[0] = (row == reg_row) ? 1e-10 * U : 0.0;
+          ap[0] = (row == reg_row) ? 1e-10 : 0.0;
         }
-      } else {
-        Dual<2> p = dvar<2>(U, 0);
-        Dual<2> M = vol * density(par, 0, p);
-        const double M0 = vol * density(par, 0, dconst<2>(cur.x0)).v;
-        Dual<2> a = ddiv(M - dconst<2>(M0), dt);
-        ar = a.v;
-        ap = a.d[0];
+      } else if (KIND == JH_LAW_COMPRESSIBLE) {
+        auto p = dvar<0>(xs[tid]);
+        auto M = vol * density(par, 0, p);
+        const double M0 = vol * density(par, 0, dconst(cur.x0[0])).v;
+        auto a = ddiv(M - dconst(M0), dt);
+        ar[0] = a.v;
+        ap[0] = a.d[0];
+      } else if constexpr (N == 2) {
+        const double p = xs[tid * 2], E[2] = {exp(density_arg(par, 0, p)), exp(density_arg(par, 1, p))};
+        accum_twophase(p, xs[tid * 2 + 1], cur.x0[0], cur.x0[1], E, vol, dt, par, ar, ap);
       }
       for (int j = rp[tid]; j < rp[tid + 1]; ++j) {
-        ar = ar + qv[j];
-        ap = ap + dsv[j];
+#pragma unroll
+        for (int e = 0; e < N; ++e) ar[e] = ar[e] + qv[j * N + e];
+#pragma unroll
+        for (int i = 0; i < NN; ++i) ap[i] = ap[i] + dsv[j * NN + i];
       }
-      r[row] = ar;
-      dsv[diagk[tid]] = ap;  // park the diagonal in its LDS slot for the coalesced store
+#pragma unroll
+      for (int e = 0; e < N; ++e) r[(size_t)row * N + e] = ar[e];
+      const int dk = diagk[tid];  // park the diagonal block in its LDS slot for the coalesced store
+#pragma unroll
+      for (int i = 0; i < NN; ++i) dsv[dk * NN + i] = ap[i];
     }
     __syncthreads();
     // phase 3: every lane stores its entries; nzval lines leave the CU complete
+    if constexpr (N == 2) {
+      store_blocks2<KPT>(nz, dsv, off, isdiag, base, cnt, tid);
+    } else {
 #pragma unroll
-    for (int kk = 0; kk < KPT; ++kk) {
-      const int k = tid + kk * TILE_THREADS;
-      if (k < cnt) nz[base + k] = isdiag[kk] ? dsv[k] : off[kk];
+      for (int kk = 0; kk < KPT; ++kk) {
+        const int k = tid + kk * TILE_THREADS;
+        if (k < cnt) nz[base + k] = isdiag[kk] ? dsv[k] : off[kk][0];
+      }
     }
     __syncthreads();  // LDS is reused by the next tile
     cur = nxt;
@@ -478,38 +580,32 @@ void k_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
   par.comp[0] = L->par[2]; par.comp[1] = L->par[3];
   par.mu[0] = L->par[4]; par.mu[1] = L->par[5];
   par.p_ref = L->par[6];
+  par.inv_mu[0] = 1.0 / par.mu[0]; par.inv_mu[1] = 1.0 / par.mu[1];
   int reg_row = P.iperm.empty() ? 0 : P.iperm[0];
   int chunk = (P.ntiles + NUM_XCD - 1) / NUM_XCD;
   dim3 grid(chunk * NUM_XCD), block(TILE_THREADS);
   const double *g = L->has_gdz ? L->gnz.p : nullptr;
-  const double *Eexp = nullptr;
-  // Per-cell exp pre-pass for the two-phase law: measured on MI355X, 5M cells (profiles/r03_twophase_prepass_*): assembly 0.515 ->
-  // 0.579 ms (pre-pass launch included) -- the 16-byte gathers that replace the exponentials cost more than the exponentials.
-  // Opt-in (JH_ASM_PREPASS=1).
-  static const bool prepass = getenv("JH_ASM_PREPASS") != nullptr;
-  if (L->kind == JH_LAW_TWOPHASE && prepass) {
-    if (L->Eexp.n < (size_t)P.n * 2) L->Eexp.alloc((size_t)P.n * 2);
-    hipLaunchKernelGGL(twophase_exp_kernel, dim3((unsigned)std::min<int64_t>((P.n + 255) / 256, 4096)), dim3(256), 0, ctx->stream, L->X.p,
-                       L->Eexp.p, P.n, par);
-    Eexp = L->Eexp.p;
-  }
-#define JH_ASM_ARGS P.d_tile_desc.p, P.ntiles, P.d_rowptr.p, P.d_col.p, P.d_diag.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row, (int)P.n, Eexp
+#define JH_ASM_ARGS P.d_tile_desc.p, P.ntiles, P.d_rowptr.p, P.d_col.p, P.d_diag.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row, (int)P.n
   static const bool pipe = getenv("JH_ASM_NO_PIPE") == nullptr;
   // persistent grid of the pipelined scalar kernels: 8 workgroups per CU like the SpMV
   dim3 pgrid((unsigned)(std::min(chunk, 256) * NUM_XCD));
-#define JH_ASM_PIPE_ARGS P.d_tile_desc.p, P.ntiles, P.d_rowptr.p, P.d_col.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row
+  static const int wg2 = getenv("JH_ASM_PIPE2_WGS") ? atoi(getenv("JH_ASM_PIPE2_WGS")) : 0;  // per XCD; 0 = tile kernel (the default: the pipelined kernel is not faster on 2x2 blocks)
+  static const bool pipe2 = pipe && wg2 > 0;
+  dim3 pgrid2((unsigned)(std::min(chunk, std::max(wg2, 1)) * NUM_XCD));
+#define JH_ASM_PIPE_ARGS P.d_tile_desc.p, P.ntiles, P.d_rowptr.p, P.d_col.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row, (int)P.n
   switch (L->kind) {
     case JH_LAW_POISSON:
       if (pipe) hipLaunchKernelGGL(assemble_pipe_kernel<JH_LAW_POISSON>, pgrid, block, 0, ctx->stream, JH_ASM_PIPE_ARGS);
-      else hipLaunchKernelGGL((assemble_tile_kernel<JH_LAW_POISSON, false>), grid, block, 0, ctx->stream, JH_ASM_ARGS);
+      else hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_POISSON>, grid, block, 0, ctx->stream, JH_ASM_ARGS);
       break;
     case JH_LAW_COMPRESSIBLE:
       if (pipe) hipLaunchKernelGGL(assemble_pipe_kernel<JH_LAW_COMPRESSIBLE>, pgrid, block, 0, ctx->stream, JH_ASM_PIPE_ARGS);
-      else hipLaunchKernelGGL((assemble_tile_kernel<JH_LAW_COMPRESSIBLE, false>), grid, block, 0, ctx->stream, JH_ASM_ARGS);
+      else hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_COMPRESSIBLE>, grid, block, 0, ctx->stream, JH_ASM_ARGS);
       break;
     case JH_LAW_TWOPHASE:
-      if (Eexp) hipLaunchKernelGGL((assemble_tile_kernel<JH_LAW_TWOPHASE, true>), grid, block, 0, ctx->stream, JH_ASM_ARGS);
-      else hipLaunchKernelGGL((assemble_tile_kernel<JH_LAW_TWOPHASE, false>), grid, block, 0, ctx->stream, JH_ASM_ARGS);
+      // 2x2 blocks: 31.5 KB of LDS per workgroup, five of them per CU
+      if (pipe2) hipLaunchKernelGGL(assemble_pipe_kernel<JH_LAW_TWOPHASE>, pgrid2, block, 0, ctx->stream, JH_ASM_PIPE_ARGS);
+      else hipLaunchKernelGGL(assemble_tile_kernel<JH_LAW_TWOPHASE>, grid, block, 0, ctx->stream, JH_ASM_ARGS);
       break;
     default: JH_THROW("unknown law kind");
   }

@@ -154,13 +154,17 @@ extern "C" __global__ __launch_bounds__(JH_THREADS) void jh_custom_assemble(
     for (int i = 0; i < JH_NN; ++i) dsv[dk * JH_NN + i] = ap[i];
   }
   __syncthreads();
+  // off-diagonal blocks into their (free by now) dsv slots next to the parked diagonal blocks; the tile's nzval range then
+  // leaves the CU as one linear copy (a lane storing its own block writes 8 bytes every JH_NN*8: partial lines per instruction)
 #pragma unroll
   for (int kk = 0; kk < KPT; ++kk) {
     const int k = tid + kk * JH_THREADS;
-    if (k >= cnt) continue;
-    double *blk = nz + (size_t)(base + k) * JH_NN;
-    for (int i = 0; i < JH_NN; ++i) blk[i] = isdiag[kk] ? dsv[k * JH_NN + i] : off[kk][i];
+    if (k < cnt && !isdiag[kk])
+      for (int i = 0; i < JH_NN; ++i) dsv[k * JH_NN + i] = off[kk][i];
   }
+  __syncthreads();
+  double *dst = nz + (size_t)base * JH_NN;
+  for (int i = tid; i < cnt * JH_NN; i += JH_THREADS) dst[i] = dsv[i];
 }
 )JHSRC";
 }  // namespace

@@ -100,6 +100,18 @@ void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t npa
                       std::vector<int32_t> &label, int32_t rim_cell);
 
 // ---- tiling constants for the CSR row-segment kernels ------------------------------------------------
+// Value of a vector entry that lives either in an LDS window or in global memory.  Two loads -- an LDS read every lane issues and
+// a global load under the exec mask of the lanes outside the window -- because `in ? lds[i] : g[j]` compiles to ONE flat_load
+// through a selected generic pointer: flat loads count on vmcnt AND lgkmcnt and return out of order with respect to both, so
+// every wait behind them is a wait for everything.
+#ifdef __HIPCC__
+__device__ __forceinline__ double lds_or_global(const double *lds, unsigned i, bool in, const double *g, size_t j) {
+  // explicit address spaces: loads through generic pointers are merged again (SimplifyCFG) before the address spaces are inferred
+  double v = *(const __attribute__((address_space(3))) double *)(lds + (in ? i : 0u));
+  if (!in) v = *(const __attribute__((address_space(1))) double *)(g + j);
+  return v;
+}
+#endif
 constexpr int TILE_THREADS = 256;  // 4 wavefronts
 constexpr int TILE_NNZ = 1024;     // block-nnz staged in LDS per workgroup
 constexpr int TILE_ROWS = 256;     // rows per tile (one row-reduce thread each; row id fits uint8)
@@ -328,7 +340,6 @@ struct jh_law_s {
   jh::DevBuf<double> limits; // 5*N update limits for jh_newton_step (jh_law_set_update_limits); empty: none
   jh::DevBuf<double> Tnz;    // per device nnz: T_f off-diagonal, accumulation coefficient on the diagonal
   jh::DevBuf<double> gnz;    // per device nnz: signed gdz (self -> other); empty when no gravity
-  jh::DevBuf<double> Eexp;   // two-phase law: exp(c_ph (p - p_ref)) per cell and phase, refreshed by every assembly (pre-pass)
   bool has_gdz = false;
   int64_t nsrc = 0;
   jh::DevBuf<int32_t> src_cell;

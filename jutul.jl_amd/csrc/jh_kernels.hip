@@ -366,7 +366,7 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_tile_kernel(const int32_t *
 #pragma unroll
       for (int j = 0; j < KPT; ++j) {
         const unsigned loc = (unsigned)(cidx[j] - w0);
-        xg[j] = (loc < (unsigned)wn) ? xw[loc] : x[cidx[j]];
+        xg[j] = lds_or_global(xw, loc, loc < (unsigned)wn, x, (size_t)cidx[j]);
       }
     } else {
 #pragma unroll
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_pipe_kernel(const int32_t *
 #pragma unroll
       for (int j = 0; j < KPT; ++j) {
         const unsigned loc = (unsigned)(cur.cidx[j] - w0);
-        xg[j] = (loc < (unsigned)wn) ? xw[loc] : x[cur.cidx[j]];
+        xg[j] = lds_or_global(xw, loc, loc < (unsigned)wn, x, (size_t)cur.cidx[j]);
       }
 #pragma unroll
       for (int j = 0; j < KPT; ++j) {

@@ -118,10 +118,33 @@ __global__ __launch_bounds__(256) void bicg_xr_dots_kernel(const double *x_in, d
   const double alpha = sc[rho_slot] / sc[S_CV];
   const double omega = bicg_omega(sc[S_TS], sc[S_TT]);
   double d0 = 0.0, d1 = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  // two entries per lane and access (16-byte loads and stores; the vectors are 256-byte aligned device allocations)
+  const int64_t n2 = n >> 1;
+  for (int64_t i2 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i2 < n2; i2 += (int64_t)gridDim.x * blockDim.x) {
+    const double2 xv = reinterpret_cast<const double2 *>(x_in)[i2], yv = reinterpret_cast<const double2 *>(y)[i2];
+    const double2 zv = reinterpret_cast<const double2 *>(z)[i2], sv = reinterpret_cast<const double2 *>(s)[i2];
+    const double2 tv = reinterpret_cast<const double2 *>(t)[i2];
+    double2 xo, ro;
+    xo.x = (xv.x + alpha * yv.x) + omega * zv.x;  // x_aux = x + alpha*y;  x = x_aux + omega*z
+    xo.y = (xv.y + alpha * yv.y) + omega * zv.y;
+    ro.x = sv.x - omega * tv.x;
+    ro.y = sv.y - omega * tv.y;
+    reinterpret_cast<double2 *>(x_out)[i2] = xo;
+    reinterpret_cast<double2 *>(r)[i2] = ro;
+    const int64_t i = 2 * i2;
+    if (i + 1 < nd) {
+      const double2 cv = reinterpret_cast<const double2 *>(c)[i2];
+      d0 += cv.x * ro.x; d1 += ro.x * ro.x;
+      d0 += cv.y * ro.y; d1 += ro.y * ro.y;
+    } else if (i < nd) {
+      d0 += c[i] * ro.x; d1 += ro.x * ro.x;
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd length: the last entry
+    const int64_t i = n - 1;
     double xi = x_in[i];
-    xi += alpha * y[i];  // x_aux = x + alpha*y
-    xi += omega * z[i];  // x = x_aux + omega*z
+    xi += alpha * y[i];
+    xi += omega * z[i];
     x_out[i] = xi;
     const double ri = s[i] - omega * t[i];
     r[i] = ri;
