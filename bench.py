@@ -58,7 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--law", default="poisson", choices=["poisson", "compressible", "twophase"])
     # lattice: Kuhn-split tet lattice (the headline grid).  delaunay: Delaunay tets of graded random points (odd cycles in the
     # dual graph, varying valence / cell size).  polyhedral: median dual of that tet mesh (~15 faces per cell, rows of 6..50 entries)
-    ap.add_argument("--mesh", default="lattice", choices=["lattice", "delaunay", "polyhedral"])
+    ap.add_argument("--mesh", default="lattice", choices=["lattice", "delaunay", "polyhedral", "cartesian"])
     ap.add_argument("--grading", type=float, default=2.0, help="--mesh delaunay / polyhedral: point density grading (1 = uniform)")
     ap.add_argument("--block-rows", type=int, default=0,
                     help="rows per block-Jacobi ILU(0) block; 0 = the library default for the rank-local size (512, 256 below 2M cells)")
@@ -509,6 +509,9 @@ def make_mesh(ja, args, cells=None, scramble=True):
     if args.mesh == "polyhedral":
         m = ja.polyhedral_dual_mesh(max(64, cells), grading=args.grading, scramble=scramble)
         return m, f"polyhedral median-dual grid of a Delaunay tet mesh ({m['points']} graded random points, grading {args.grading}, scrambled numbering)"
+    if args.mesh == "cartesian":
+        n = max(2, round(cells ** (1.0 / 3.0)))
+        return ja.cartesian_mesh(n, n, n, scramble=scramble), f"Cartesian hexahedral grid ({n}x{n}x{n}, scrambled numbering)"
     nx, ny, nz = dims_for_cells(cells)
     return ja.tet_lattice_mesh(nx, ny, nz, scramble=scramble), f"Kuhn-split tet lattice ({nx}x{ny}x{nz}x6, scrambled numbering)"
 

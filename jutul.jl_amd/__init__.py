@@ -23,11 +23,11 @@ import numpy as np
 from . import _lib
 from ._lib import JutulHIPError, NewtonReport, check, f64, i64, pf, pi, pi32
 from .discretization import compute_face_gdz, compute_face_trans, compute_half_face_trans, half_face_map  # noqa: F401
-from .meshgen import cartesian_neighbors, delaunay_tet_mesh, polyhedral_dual_mesh, tet_lattice_mesh  # noqa: F401
+from .meshgen import cartesian_mesh, cartesian_neighbors, delaunay_tet_mesh, polyhedral_dual_mesh, tet_lattice_mesh  # noqa: F401
 
 __all__ = ["HIPContext", "LocalCommGroup", "TwoPointPotentialFlowHardCoded", "DeviceVector", "StaticSparsityMatrixCSR", "ConservationLaw",
            "ILUZeroPreconditioner", "JacobiPreconditioner", "SPAI0Preconditioner", "IterativeSolverConfig", "GenericKrylov", "LinearizedSystem", "linear_solve", "scale_system",
-           "Simulator", "JutulHIPError", "mul_", "ilu0_csr", "ldiv_", "tet_lattice_mesh", "delaunay_tet_mesh", "polyhedral_dual_mesh", "cartesian_neighbors"]
+           "Simulator", "JutulHIPError", "mul_", "ilu0_csr", "ldiv_", "tet_lattice_mesh", "delaunay_tet_mesh", "polyhedral_dual_mesh", "cartesian_neighbors", "cartesian_mesh"]
 
 REORDER = {"none": 0, "blocks": 1}
 LAYOUT = {"equation_major": 0, "entity_major": 1, "block_major": 2}  # JutulMatrixLayout (core_types.jl:101-165)

@@ -132,6 +132,36 @@ def tet_lattice_mesh(nx, ny, nz, *, jitter=0.2, seed_perm=20260928, seed_jitter=
                 perm_k=K[inv], areas=area, normals=nhat.T.copy(), face_centroids=fc.T.copy(), dim=3)
 
 
+def cartesian_mesh(nx, ny, nz, *, size=None, seed_perm=20260928, seed_perm_k=2, scramble=True, k_range=(1e-14, 1e-12)):
+    """CartesianMesh((nx, ny, nz), size) as the kernels see it (the reference's most common grid: meshes/cart.jl): neighbourship in
+    MRST face order, half-face transmissibilities A K / (h/2) of the regular hexahedra (finite-volume.jl:220-222 with C along the
+    face normal) and their harmonic average (:224-233), log-uniform permeability per cell, optionally scrambled numbering.
+    Six faces per interior cell: rows of 7 entries, triangle-free pattern."""
+    nc = nx * ny * nz
+    if size is None:
+        size = (float(nx), float(ny), float(nz))
+    h = np.array([size[0] / nx, size[1] / ny, size[2] / nz])
+    N0 = cartesian_neighbors((nx, ny, nz)) - 1  # 0-based, natural numbering
+    nfx, nfy = (nx - 1) * ny * nz, nx * (ny - 1) * nz
+    nf = N0.shape[1]
+    axis = np.zeros(nf, dtype=np.int64)
+    axis[nfx:nfx + nfy] = 1
+    axis[nfx + nfy:] = 2
+    area = np.array([h[1] * h[2], h[0] * h[2], h[0] * h[1]])[axis]
+    K = np.exp(np.random.default_rng(seed_perm_k).uniform(np.log(k_range[0]), np.log(k_range[1]), nc))
+    half = 0.5 * h[axis]
+    Tl, Tr = area * K[N0[0]] / half, area * K[N0[1]] / half
+    T = 1.0 / (1.0 / Tl + 1.0 / Tr)
+    new_of_old = _scramble(nc, seed_perm, scramble)
+    N = np.stack([new_of_old[N0[0]], new_of_old[N0[1]]]).astype(np.int64) + 1
+    inv = np.empty(nc, dtype=np.int64)
+    inv[new_of_old] = np.arange(nc)
+    k, j, i = np.unravel_index(np.arange(nc), (nz, ny, nx))
+    cc = (np.stack([i, j, k]).astype(np.float64) + 0.5) * h[:, None]
+    return dict(N=np.ascontiguousarray(N), nc=nc, nf=nf, T=T, volumes=np.full(nc, float(np.prod(h))), cell_centroids=cc[:, inv].copy(),
+                perm_k=K[inv], areas=area, dim=3)
+
+
 def _graded_points(n_points, seed, grading):
     """Seeded points in the unit cube; grading > 1 warps them towards the corner at the origin (x -> x**grading per axis), so
     that the local spacing varies by ~grading * n^(1/3)."""

@@ -114,3 +114,9 @@ def test_polyhedral_dual_mesh_parity(ja, oracle):
     assert deg.max() > 16 and deg.mean() > 12
     run_family(ja, oracle, g, "compressible",
                dict(longest_row=int(deg.max()) + 1, jagged_spmv=False, jagged_ilu=False, factor_kernel="program"))
+
+
+def test_cartesian_mesh_parity(ja, oracle):
+    g = ja.cartesian_mesh(60, 60, 60)                                # 216k hexahedra, the reference's CartesianMesh: 6 faces per cell
+    run_family(ja, oracle, g, "compressible",
+               dict(longest_row=7, jagged_spmv=True, jagged_ilu=True, factor_kernel="pivot-only"))

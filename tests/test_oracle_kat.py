@@ -479,3 +479,20 @@ def test_multigraph_two_cells_two_faces_hand_computed(oracle):
     q = (T1 + T2) * (U[0] - U[1])
     assert np.allclose(r, [(U[0] - U0[0]) / dt + q, (U[1] - U0[1]) / dt - q], rtol=1e-14)
     assert np.allclose(nz, [1 / dt + T1 + T2, -T2, -T2, 1 / dt + T1 + T2], rtol=1e-14)
+
+
+def test_bench_cartesian_mesh_matches_the_oracle_geometry(oracle):
+    """meshgen.cartesian_mesh (bench / GPU parity input) against cartesian_geometry + half_face_trans + face_trans of the oracle:
+    same neighbourship, volumes, centroids and (with its per-cell permeability) the same face transmissibilities."""
+    from jutul_amd import cartesian_mesh
+    dims, size = (5, 4, 3), (2.0, 1.0, 3.0)
+    g = cartesian_mesh(*dims, size=size, scramble=False)
+    geo = oracle.cartesian_geometry(dims, size)
+    assert np.array_equal(g["N"], geo["N"]) and g["nc"] == geo["nc"] and g["nf"] == geo["nf"]
+    assert np.allclose(g["volumes"], geo["volumes"], rtol=1e-14) and np.allclose(g["cell_centroids"], geo["cell_centroids"], rtol=1e-14)
+    h = oracle.half_face_map(geo["N"], geo["nc"])
+    Tf = oracle.face_trans(oracle.half_face_trans(geo, g["perm_k"][None, :], h), h["faces"], geo["nf"])
+    assert np.allclose(g["T"], Tf, rtol=1e-13)
+    gs = cartesian_mesh(*dims, size=size)                     # scrambled numbering: the same grid under a permutation
+    key = lambda N, T: sorted(zip(np.minimum(N[0], N[1]).tolist(), np.maximum(N[0], N[1]).tolist()))
+    assert len(set(key(gs["N"], gs["T"]))) == g["nf"] and np.isclose(np.sort(gs["T"]).sum(), np.sort(g["T"]).sum(), rtol=1e-12)
