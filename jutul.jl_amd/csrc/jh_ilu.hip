@@ -494,138 +494,131 @@ __global__ __launch_bounds__(1024) void ilu_factor_diag_kernel(IluDev F, const d
   }
 }
 
-// The same refactorisation, persistent and software-pipelined over the blocks a workgroup owns (b, b + gridDim, ...): the
-// index loads of the NEXT block (descriptor, row word, pivot slot, L maps / columns / partner maps) -- and for scalar matrices the
-// values behind them -- are in flight while the current block walks its levels, so that a block no longer pays the two dependent
-// memory round trips of its gather (index -> value) in front of its sweep.  Arithmetic and stores are those of
-// ilu_factor_diag_kernel.  PFV: prefetch the values too (scalar: 9 more registers; blocks keep one hop).
+// The same refactorisation with ONE WAVEFRONT per block, shaped like the forward sweep of ilu_apply_jds_kernel: the block is walked
+// chunk by chunk (64 rows in level order); the operands of chunk c+1 -- descriptor, row words, the A values behind the L maps,
+// their partners and the pivots -- are in flight while chunk c walks ITS levels (a few, not the block's 36-51) out of registers
+// and LDS, and nothing waits for a whole block: a workgroup per block holds nine wavefronts at one barrier per level and, with
+// 2x2 blocks (~120 VGPRs), leaves ONE workgroup resident per CU.  Here a CU holds as many blocks as it has wavefront slots.
+// Arithmetic, its order and the stores are those of ilu_factor_diag_kernel, hence the same bits.
+// Measured (profiles/README.md, round 3): 2x2 blocks 1.05 -> 0.53 ms, scalar rows of 7 entries (KU = 8) 0.62 -> 0.54 ms; scalar
+// KU = 4: 0.41 vs 0.40 ms -- the chunk-by-chunk walk spreads the touches of an A line (the row's own L entries, its U entries as
+// partners of later rows, the U copy) over the lifetime of the block, and with ~28 blocks in flight per CU the XCD's L2 no longer
+// holds them: 2.16 GB of HBM traffic per launch instead of 1.13, i.e. the kernel runs at the HBM rate.  (Staging the block's
+// contiguous A range in LDS first removes the re-reads but leaves five wavefronts per CU: 0.64 ms.)  Default: this kernel for
+// blocks and KU = 8, the workgroup-per-block kernel for scalar KU = 4.
 template <int BS, int KU>
-struct FDIdx {
-  int4 D;
+struct FWRow {
   unsigned word;
-  int diag, bslot;
-  int kcol[KU], lmap[KU], tmap[KU];
+  int bslot;
+  Blk<BS> acc;
+  int kcol[KU];
+  bool act[KU];
+  Blk<BS> av[KU], bv[KU];
 };
-template <int BS, int KU, bool SC, bool PFV, int LB>
-__global__ __launch_bounds__(LB) void ilu_factor_diag_pipe_kernel(IluDev F, const double *__restrict__ aval, const int32_t *__restrict__ ubase,
-                                                                    const int32_t *__restrict__ jl_map, const int32_t *__restrict__ jt_map,
-                                                                    const int32_t *__restrict__ ju_map, const int32_t *__restrict__ jf_diag,
-                                                                    const uint16_t *__restrict__ jf_bslot, int nb) {
+template <int BS, int KU, bool SC, bool PF>
+__global__ __launch_bounds__(64) void ilu_factor_wave_kernel(IluDev F, const double *__restrict__ aval, const int32_t *__restrict__ ubase,
+                                                             const int32_t *__restrict__ jl_map, const int32_t *__restrict__ jt_map,
+                                                             const int32_t *__restrict__ ju_map, const int32_t *__restrict__ jf_diag,
+                                                             const uint16_t *__restrict__ jf_bslot) {
   extern __shared__ __attribute__((aligned(16))) double dv[];  // inverted pivots by block-local row
   constexpr int BB = BS * BS;
-  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, ch = tid >> 6;
-  auto load_idx = [&](int b, FDIdx<BS, KU> &I) {
-    const int c0 = F.chunk_ptr[b], nch = F.chunk_ptr[b + 1] - c0;
-    I.D = make_int4(0, 0, 0, 0);
-    I.word = 0xffff0000u;
-    I.diag = -1; I.bslot = 0;
-    if (ch < nch) {
-      const size_t fslot = (size_t)(c0 + ch) * 64 + lane;
-      I.D = F.jf_desc[c0 + ch];
-      I.word = F.jf_row[fslot];
-      if ((I.word >> 16) != 0xffffu) { I.diag = jf_diag[fslot]; I.bslot = (int)jf_bslot[fslot]; }
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int c0 = F.chunk_ptr[b], nch = F.chunk_ptr[b + 1] - c0;
+  auto aload = [&](int slot) { return blk_load_al<BS>(aval + (size_t)slot * BB); };  // A value behind a map entry
+  auto load = [&](const int4 &D, int chunk, FWRow<BS, KU> &R) {
+    const size_t fslot = (size_t)chunk * 64 + lane;
+    R.word = F.jf_row[fslot];
+    const bool has_row = (R.word >> 16) != 0xffffu;
+    R.bslot = 0;
+    if (has_row) { R.acc = aload(jf_diag[fslot]); R.bslot = (int)jf_bslot[fslot]; }
+    int off = D.x;
+#define JH_FW(J)                                                                                       \
+    if (J < KU) {                                                                                      \
+      const int cnt = jd_count<(J < 8 ? J : 0)>(D);                                                    \
+      const bool a = has_row && lane < cnt;                                                            \
+      R.act[J < KU ? J : 0] = a;                                                                       \
+      if (a) {                                                                                         \
+        R.kcol[J < KU ? J : 0] = (int)F.jl_col[off + lane];                                            \
+        R.av[J < KU ? J : 0] = aload(jl_map[off + lane]);                                              \
+        const int mt = jt_map[off + lane];                                                             \
+        if (mt >= 0) R.bv[J < KU ? J : 0] = aload(mt);                                                 \
+        else { _Pragma("unroll") for (int i = 0; i < BB; ++i) R.bv[J < KU ? J : 0].a[i] = 0.0; }       \
+      }                                                                                                \
+      off += cnt;                                                                                      \
     }
-    int off = I.D.x;
-#define JH_FI(J)                                                                                     \
-    if (J < KU) {                                                                                    \
-      const int cnt = jd_count<(J < 8 ? J : 0)>(I.D);                                                \
-      const bool a = I.diag >= 0 && lane < cnt;                                                      \
-      I.kcol[J < KU ? J : 0] = a ? (int)F.jl_col[off + lane] : -1;                                   \
-      I.lmap[J < KU ? J : 0] = a ? jl_map[off + lane] : -1;                                          \
-      I.tmap[J < KU ? J : 0] = a ? jt_map[off + lane] : -1;                                          \
-      off += cnt;                                                                                    \
-    }
-    JH_FI(0) JH_FI(1) JH_FI(2) JH_FI(3) JH_FI(4) JH_FI(5) JH_FI(6) JH_FI(7)
-#undef JH_FI
+    JH_FW(0) JH_FW(1) JH_FW(2) JH_FW(3) JH_FW(4) JH_FW(5) JH_FW(6) JH_FW(7)
+#undef JH_FW
   };
-  auto load_val = [&](const FDIdx<BS, KU> &I, Blk<BS> &acc, Blk<BS> *av, Blk<BS> *bv) {
-    if (I.diag >= 0) acc = blk_load_al<BS>(aval + (size_t)I.diag * BB);
+  const int4 *desc = F.jf_desc;
+  int4 dc = desc[c0], dn = desc[c0 + 1], dnn;  // (the descriptor arrays are padded by two entries)
+  FWRow<BS, KU> cur, nxt;
+  load(dc, c0, cur);
+  const int u0 = ubase[b], nu = ubase[b + 1] - u0;
+  // U holds A's entries (jagged order of the backward sweep), four at a time per lane.  (Copying the entries of backward chunk
+  // nch-1-c -- roughly the rows of forward chunk c -- inside the chunk loop instead: 0.606 vs 0.591 ms on 2x2 blocks, dropped.)
+  auto ucopy = [&](int ustart, int uend) {
+    for (int j0 = ustart + lane; j0 < uend; j0 += 4 * 64) {
+      int m[4];
 #pragma unroll
-    for (int j = 0; j < KU; ++j) {
-      if (I.kcol[j] >= 0) {
-        av[j] = blk_load_al<BS>(aval + (size_t)I.lmap[j] * BB);
-        if (I.tmap[j] >= 0) bv[j] = blk_load_al<BS>(aval + (size_t)I.tmap[j] * BB);
-        else { _Pragma("unroll") for (int i = 0; i < BB; ++i) bv[j].a[i] = 0.0; }
+      for (int u = 0; u < 4; ++u) { const int j = j0 + u * 64; m[u] = j < uend ? ju_map[j] : -1; }
+      Blk<BS> v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (m[u] >= 0) v[u] = aload(m[u]);
+        else { _Pragma("unroll") for (int e = 0; e < BB; ++e) v[u].a[e] = 0.0; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u * 64;
+        if (j < uend) blk_store_al<BS>(F.u_val + (size_t)j * BB, v[u]);
       }
     }
   };
-  FDIdx<BS, KU> In;
-  Blk<BS> accn, avn[KU], bvn[KU];
-  int b = blockIdx.x;
-  if (b < nb) { load_idx(b, In); if (PFV) load_val(In, accn, avn, bvn); }
-  for (; b < nb; b += gridDim.x) {
-    const FDIdx<BS, KU> I = In;
-    Blk<BS> acc, av[KU], bv[KU];
-    if (PFV) {
-      acc = accn;
-#pragma unroll
-      for (int j = 0; j < KU; ++j) { av[j] = avn[j]; bv[j] = bvn[j]; }
-    } else {
-      load_val(I, acc, av, bv);
-    }
-    const Blk<BS> aii = acc;
-    const int c0 = F.chunk_ptr[b];
-    const int lt = (int)(I.word & 0xffffu), lev = (int)(I.word >> 16);
-    const bool has_row = I.diag >= 0;
-    // U (and, D-ILU storage, L) hold A's entries: first batch of four loaded now, stored after the sweep
-    const int u0 = ubase[b], nu = ubase[b + 1] - u0;
-    int um[4];
-    Blk<BS> uv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int j = tid + u * T; um[u] = j < nu ? ju_map[u0 + j] : -1; }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (um[u] >= 0) uv[u] = blk_load_al<BS>(aval + (size_t)um[u] * BB);
-      else { _Pragma("unroll") for (int e = 0; e < BB; ++e) uv[u].a[e] = 0.0; }
-    }
-    // the next block's indices (and values) go out before this block's level loop
-    if (b + (int)gridDim.x < nb) { load_idx(b + gridDim.x, In); if (PFV) load_val(In, accn, avn, bvn); }
+  for (int c = 0; c < nch; ++c) {
+    dnn = desc[c0 + c + 2];
+    if (PF && c + 1 < nch) load(dn, c0 + c + 1, nxt);
+    const int lt = (int)(cur.word & 0xffffu), lev = (int)(cur.word >> 16);
+    const bool has_row = lev != 0xffff;
+    const int lvlo = dc.w & 0xffff, lvhi = (int)((unsigned)dc.w >> 16);
     int pos[KU];
     {
-      int off = I.D.x;
-#define JH_FP(J) if (J < KU) { pos[J < KU ? J : 0] = off + lane; off += jd_count<(J < 8 ? J : 0)>(I.D); }
+      int off = dc.x;
+#define JH_FP(J) if (J < KU) { pos[J < KU ? J : 0] = off + lane; off += jd_count<(J < 8 ? J : 0)>(dc); }
       JH_FP(0) JH_FP(1) JH_FP(2) JH_FP(3) JH_FP(4) JH_FP(5) JH_FP(6) JH_FP(7)
 #undef JH_FP
     }
+    Blk<BS> aii;
     if (SC) {
+      aii = cur.acc;
 #pragma unroll
       for (int j = 0; j < KU; ++j)
-        if (I.kcol[j] >= 0) blk_store_al<BS>(F.l_val + (size_t)pos[j] * BB, av[j]);
+        if (cur.act[j]) blk_store_al<BS>(F.l_val + (size_t)pos[j] * BB, cur.av[j]);
     }
-    const int lev0 = F.flev_off[b], nlev = F.flev_off[b + 1] - 1 - lev0;
-    for (int lv = 0; lv < nlev; ++lv) {
+    for (int lv = lvlo; lv <= lvhi; ++lv) {
       if (has_row && lev == lv) {
 #pragma unroll
         for (int j = 0; j < KU; ++j) {
-          if (I.kcol[j] >= 0) {
-            const Blk<BS> lik = blk_mul<BS>(av[j], blk_load<BS>(dv + (size_t)I.kcol[j] * BB));  // nz_l * inv(A_kk)
+          if (cur.act[j]) {
+            const Blk<BS> lik = blk_mul<BS>(cur.av[j], blk_load<BS>(dv + (size_t)cur.kcol[j] * BB));  // nz_l * inv(A_kk)
             if (!SC) blk_store_al<BS>(F.l_val + (size_t)pos[j] * BB, lik);
-            if (blk_nonzero<BS>(lik)) blk_sub<BS>(acc, blk_mul<BS>(lik, bv[j]));
+            if (blk_nonzero<BS>(lik)) blk_sub<BS>(cur.acc, blk_mul<BS>(lik, cur.bv[j]));
           }
         }
-        const Blk<BS> di = blk_inv<BS>(acc);
+        const Blk<BS> di = blk_inv<BS>(cur.acc);
         blk_store<BS>(dv + (size_t)lt * BB, di);
-        blk_store_al<BS>(F.dinv + ((size_t)c0 * 64 + I.bslot) * BB, di);
+        blk_store_al<BS>(F.dinv + ((size_t)c0 * 64 + cur.bslot) * BB, di);
         if (SC) {
-          blk_store_al<BS>(F.dinv_f + ((size_t)(c0 + ch) * 64 + lane) * BB, di);
-          blk_store_al<BS>(F.kap + ((size_t)c0 * 64 + I.bslot) * BB, aii);
+          blk_store_al<BS>(F.dinv_f + ((size_t)(c0 + c) * 64 + lane) * BB, di);
+          blk_store_al<BS>(F.kap + ((size_t)c0 * 64 + cur.bslot) * BB, aii);
         }
       }
-      __syncthreads();
+      __syncthreads();  // one wavefront: orders this level's LDS writes before the next level's reads
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = tid + u * T;
-      if (j < nu) blk_store_al<BS>(F.u_val + (size_t)(u0 + j) * BB, uv[u]);
-    }
-    for (int j0 = tid + 4 * T; j0 < nu; j0 += T) {  // (only blocks with more than 4 U entries per thread)
-      const int m = ju_map[u0 + j0];
-      Blk<BS> v;
-      if (m >= 0) v = blk_load_al<BS>(aval + (size_t)m * BB);
-      else { _Pragma("unroll") for (int e = 0; e < BB; ++e) v.a[e] = 0.0; }
-      blk_store_al<BS>(F.u_val + (size_t)(u0 + j0) * BB, v);
-    }
+    dc = dn; dn = dnn;
+    if (PF) cur = nxt;
+    else if (c + 1 < nch) load(dc, c0 + c + 1, cur);
   }
+  ucopy(u0, u0 + nu);
 }
 
 // WPR (wave per row; long rows, i.e. the row-major programs of polyhedral cells): a block of ~160 rows of ~15 entries has ~90
@@ -2234,26 +2227,25 @@ void ilu_factor(jh_ilu M) {
                                                    M->d_blk_ubase.p, M->d_jl_map.p, M->d_jt_map.p, M->d_ju_map.p, M->d_jf_diag.p, M->d_jf_bslot.p)
 #define JH_DIAGK(BSV) do { if (M->uscaled) { if (M->jag_ku == 4) JH_DIAG(BSV, 4, true); else JH_DIAG(BSV, 8, true); } \
                            else { if (M->jag_ku == 4) JH_DIAG(BSV, 4, false); else JH_DIAG(BSV, 8, false); } } while (0)
-      // Persistent, software-pipelined variant (ilu_factor_diag_pipe_kernel): measured on MI355X (profiles/r03_factor_pipe_*): scalar
-      // 10M cells 0.408 -> 0.514 ms (indices prefetched) / 0.763 ms (values too: 86 VGPRs, two blocks per CU); 2x2 blocks 5M cells
-      // 1.047 -> 0.976 ms.  Opt-in (JH_ILU_FACTOR_PIPE=1), default: one workgroup per block.
-      static const int pipe = getenv("JH_ILU_FACTOR_PIPE") ? atoi(getenv("JH_ILU_FACTOR_PIPE")) : 0;
-      if (pipe) {
-        // persistent workgroups: as many as are resident at once (waves of a workgroup = chunks of the largest block)
-        int ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        const int per_cu = std::max(1, std::min(8, 32 / std::max(1, M->max_chunks)));
-        const int pg = (int)std::min<int64_t>(nb, (int64_t)ncu * per_cu * (pipe > 1 ? pipe : 1));
-#define JH_DPL(BSV, KUV, SCV, PFVV, LBV) hipLaunchKernelGGL((ilu_factor_diag_pipe_kernel<BSV, KUV, SCV, PFVV, LBV>), dim3((unsigned)pg), dim3(dthreads), dlds, s, F, aval, \
-                                                       M->d_blk_ubase.p, M->d_jl_map.p, M->d_jt_map.p, M->d_ju_map.p, M->d_jf_diag.p, M->d_jf_bslot.p, (int)nb)
-#define JH_DP(BSV, KUV, SCV, PFVV) do { if (dthreads <= 640) JH_DPL(BSV, KUV, SCV, PFVV, 640); else JH_DPL(BSV, KUV, SCV, PFVV, 1024); } while (0)
-#define JH_DPK(BSV, PFVV) do { if (M->uscaled) { if (M->jag_ku == 4) JH_DP(BSV, 4, true, PFVV); else JH_DP(BSV, 8, true, PFVV); } \
-                               else { if (M->jag_ku == 4) JH_DP(BSV, 4, false, PFVV); else JH_DP(BSV, 8, false, PFVV); } } while (0)
-        static const bool pfv = !getenv("JH_ILU_FACTOR_NO_PFV");
-        switch (M->bs) { case 1: if (pfv) JH_DPK(1, true); else JH_DPK(1, false); break; case 2: JH_DPK(2, false); break; case 3: JH_DPK(3, false); break; }
-#undef JH_DPK
-#undef JH_DP
-#undef JH_DPL
+      // One wavefront per block (ilu_factor_wave_kernel) or one workgroup per block (ilu_factor_diag_kernel).  JH_ILU_FACTOR_WAVE:
+      // unset = by block size and row length (see the kernel), 0 = never, 1 = always, 2 / 3 = always, with / without the prefetch of
+      // the next chunk's operands
+      static const int wave_env = getenv("JH_ILU_FACTOR_WAVE") ? atoi(getenv("JH_ILU_FACTOR_WAVE")) : -1;
+      const int wave = wave_env >= 0 ? wave_env : ((M->bs > 1 || M->jag_ku > 4) ? 1 : 0);
+      if (wave) {
+#define JH_FWL(BSV, KUV, SCV, PFV) hipLaunchKernelGGL((ilu_factor_wave_kernel<BSV, KUV, SCV, PFV>), dim3((unsigned)nb), dim3(64), dlds, s, F, aval, \
+                                                      M->d_blk_ubase.p, M->d_jl_map.p, M->d_jt_map.p, M->d_ju_map.p, M->d_jf_diag.p, M->d_jf_bslot.p)
+#define JH_FWK(BSV, PFV) do { if (M->uscaled) { if (M->jag_ku == 4) JH_FWL(BSV, 4, true, PFV); else JH_FWL(BSV, 8, true, PFV); } \
+                              else { if (M->jag_ku == 4) JH_FWL(BSV, 4, false, PFV); else JH_FWL(BSV, 8, false, PFV); } } while (0)
+        // prefetch: scalar matrices only by default (blocks: the registers of a second chunk cost more wavefronts per SIMD than
+        // the prefetch hides: 0.532 vs 0.532 ms measured, 2 instead of 3 wavefronts per SIMD)
+        switch (M->bs) {
+          case 1: if (wave != 3) JH_FWK(1, true); else JH_FWK(1, false); break;
+          case 2: if (wave == 2) JH_FWK(2, true); else JH_FWK(2, false); break;
+          case 3: if (wave == 2) JH_FWK(3, true); else JH_FWK(3, false); break;
+        }
+#undef JH_FWK
+#undef JH_FWL
       } else {
         switch (M->bs) { case 1: JH_DIAGK(1); break; case 2: JH_DIAGK(2); break; case 3: JH_DIAGK(3); break; }
       }
