@@ -2230,7 +2230,7 @@ void ilu_factor(jh_ilu M) {
       // One wavefront per block (ilu_factor_wave_kernel) or one workgroup per block (ilu_factor_diag_kernel).  JH_ILU_FACTOR_WAVE:
       // unset = by block size and row length (see the kernel), 0 = never, 1 = always, 2 / 3 = always, with / without the prefetch of
       // the next chunk's operands
-      static const int wave_env = getenv("JH_ILU_FACTOR_WAVE") ? atoi(getenv("JH_ILU_FACTOR_WAVE")) : -1;
+      const int wave_env = getenv("JH_ILU_FACTOR_WAVE") ? atoi(getenv("JH_ILU_FACTOR_WAVE")) : -1;  // (per call: the tests switch it)
       const int wave = wave_env >= 0 ? wave_env : ((M->bs > 1 || M->jag_ku > 4) ? 1 : 0);
       if (wave) {
 #define JH_FWL(BSV, KUV, SCV, PFV) hipLaunchKernelGGL((ilu_factor_wave_kernel<BSV, KUV, SCV, PFV>), dim3((unsigned)nb), dim3(64), dlds, s, F, aval, \

@@ -475,14 +475,21 @@ def test_device_blocks_come_from_graph_bisection(ja, ctx):
     assert perm2[sub["n_owned"]:].min() > sub["n_owned"] and perm2[: sub["n_owned"]].max() <= sub["n_owned"]
 
 
+@pytest.mark.parametrize("wave", [None, "0", "1", "2", "3"])
 @pytest.mark.parametrize("bs", [1, 2, 3])
 @pytest.mark.parametrize("grid", ["bipartite", "bipartite7", "triangles"])
-def test_ilu0_factor_kernels_pivot_only_and_program(ja, ctx, oracle, grid, bs):
+def test_ilu0_factor_kernels_pivot_only_and_program(ja, ctx, oracle, grid, bs, wave, monkeypatch):
     """The refactorisation picks its kernel from the pattern: on a triangle-free pattern (Cartesian / tet-lattice grids) no
     elimination step updates an off-diagonal entry and the sweep-shaped pivot-only kernel runs; a pattern with triangles (a
     Cartesian grid with one diagonal per cell pair) needs the general program-driven kernel.  Both give the oracle's ILU(0)
     (ilu0.jl:108-144) on the device-ordered matrix to 1e-11, scalar and 2x2 blocks, after a refactorisation with new values."""
     import scipy.sparse as sp
+    # the pivot-only refactorisation has two kernels (one workgroup / one wavefront per block; the default picks by block size and
+    # row length): JH_ILU_FACTOR_WAVE = 0 / 1 forces one, 2 / 3 the wavefront kernel with / without its operand prefetch
+    if wave is not None:
+        if grid == "triangles":
+            pytest.skip("the switch only concerns the pivot-only kernels")
+        monkeypatch.setenv("JH_ILU_FACTOR_WAVE", wave)
     dims = (13, 11, 1)
     N = ja.cartesian_neighbors(dims)
     nc = int(np.prod(dims))
@@ -496,7 +503,8 @@ def test_ilu0_factor_kernels_pivot_only_and_program(ja, ctx, oracle, grid, bs):
         a = np.arange(h)
         N = np.concatenate([np.stack([a + 1, (a + o) % h + h + 1]) for o in (0, 1, 5, 17, 40, 111, 290)], axis=1)
     rng = np.random.default_rng(31 + bs)
-    disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, block_n=bs, reorder="blocks", block_rows=64)
+    # forced kernels: blocks of several 64-row chunks (the chunk pipeline of the wavefront kernel, several waves in the other)
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, block_n=bs, reorder="blocks", block_rows=256 if (wave is not None and grid == "bipartite7") else 64)
     A = ja.StaticSparsityMatrixCSR(disc)
     rowptr, colidx = disc.pattern()
     perm, bp = disc.ordering()
