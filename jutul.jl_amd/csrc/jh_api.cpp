@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <unordered_map>
 
 #include "jh_internal.hpp"
@@ -10,6 +11,88 @@ namespace jh {
 void halo_exchange(jh_tpfa d, double *v, int bs, bool packed = false, bool push = false);
 }
 using namespace jh;
+
+// ---- copies of pageable host memory through a page-locked bounce buffer (see jh_internal.hpp) -----------------------------------
+namespace jh {
+namespace {
+struct Bounce {
+  std::mutex m;
+  void *buf[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  static constexpr size_t CAP = (size_t)16 << 20;  // two halves of 16 MB
+  void ensure() {
+    if (buf[0]) return;
+    for (int i = 0; i < 2; ++i) {
+      JH_HIP(hipHostMalloc(&buf[i], CAP, hipHostMallocDefault));
+      JH_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    }
+  }
+};
+Bounce &bounce() {
+  static Bounce *b = new Bounce();  // never destroyed: the runtime may be gone before static destructors run
+  return *b;
+}
+bool page_locked(const void *host) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, host) != hipSuccess) {
+    (void)hipGetLastError();  // "invalid value" for ordinary host memory: not an error of ours
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+}  // namespace
+void copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s) {
+  if (!bytes) return;
+  if (page_locked(src_host)) {
+    JH_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
+    JH_HIP(hipStreamSynchronize(s));
+    return;
+  }
+  Bounce &B = bounce();
+  std::lock_guard<std::mutex> lk(B.m);
+  B.ensure();
+  size_t off = 0;
+  for (int k = 0; off < bytes; ++k) {
+    const int i = k & 1;
+    const size_t len = std::min(Bounce::CAP, bytes - off);
+    if (k >= 2) JH_HIP(hipEventSynchronize(B.ev[i]));  // the DMA that last read this half
+    std::memcpy(B.buf[i], (const char *)src_host + off, len);
+    JH_HIP(hipMemcpyAsync((char *)dst_dev + off, B.buf[i], len, hipMemcpyHostToDevice, s));
+    JH_HIP(hipEventRecord(B.ev[i], s));
+    off += len;
+  }
+  JH_HIP(hipStreamSynchronize(s));
+}
+void copy_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s) {
+  if (!bytes) return;
+  if (page_locked(dst_host)) {
+    JH_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
+    JH_HIP(hipStreamSynchronize(s));
+    return;
+  }
+  Bounce &B = bounce();
+  std::lock_guard<std::mutex> lk(B.m);
+  B.ensure();
+  // chunk k+1 is on its way into one half while chunk k is copied out of the other
+  size_t off = 0, prev_off = 0, prev_len = 0;
+  int k = 0;
+  for (; off < bytes; ++k) {
+    const int i = k & 1;
+    const size_t len = std::min(Bounce::CAP, bytes - off);
+    JH_HIP(hipMemcpyAsync(B.buf[i], (const char *)src_dev + off, len, hipMemcpyDeviceToHost, s));
+    JH_HIP(hipEventRecord(B.ev[i], s));
+    if (k >= 1) {
+      JH_HIP(hipEventSynchronize(B.ev[i ^ 1]));
+      std::memcpy((char *)dst_host + prev_off, B.buf[i ^ 1], prev_len);
+    }
+    prev_off = off; prev_len = len;
+    off += len;
+  }
+  const int last = (k - 1) & 1;
+  JH_HIP(hipEventSynchronize(B.ev[last]));
+  std::memcpy((char *)dst_host + prev_off, B.buf[last], prev_len);
+}
+}  // namespace jh
 
 namespace {
 inline void check(int32_t rc) {  // nested C-ABI call failed: the message is already in the thread-local slot
@@ -124,10 +207,10 @@ extern "C" int32_t jh_vec_destroy(jh_vec v) {
 static void upload_cells(jh_context ctx, const Pattern &P, double *dst, const double *host, int64_t n, int bs) {
   JH_HIP(hipSetDevice(ctx->device));
   if (P.perm.empty()) {
-    JH_HIP(hipMemcpyAsync(dst, host, n * bs * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    jh::copy_h2d(dst, host, n * bs * sizeof(double), ctx->stream);
   } else {
     ctx->ensure_stage(n * bs);
-    JH_HIP(hipMemcpyAsync(ctx->stage.p, host, n * bs * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    jh::copy_h2d(ctx->stage.p, host, n * bs * sizeof(double), ctx->stream);
     k_permute_in(ctx->stream, dst, ctx->stage.p, P.d_perm.p, n, bs);
   }
   JH_HIP(hipStreamSynchronize(ctx->stream));
@@ -135,11 +218,11 @@ static void upload_cells(jh_context ctx, const Pattern &P, double *dst, const do
 static void download_cells(jh_context ctx, const Pattern &P, double *host, const double *src, int64_t n, int bs) {
   JH_HIP(hipSetDevice(ctx->device));
   if (P.perm.empty()) {
-    JH_HIP(hipMemcpyAsync(host, src, n * bs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    jh::copy_d2h(host, src, n * bs * sizeof(double), ctx->stream);
   } else {
     ctx->ensure_stage(n * bs);
     k_permute_out(ctx->stream, ctx->stage.p, src, P.d_perm.p, n, bs);
-    JH_HIP(hipMemcpyAsync(host, ctx->stage.p, n * bs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    jh::copy_d2h(host, ctx->stage.p, n * bs * sizeof(double), ctx->stream);
   }
   JH_HIP(hipStreamSynchronize(ctx->stream));
 }
@@ -236,7 +319,7 @@ extern "C" int32_t jh_csr_create_from_pattern(jh_context ctx, int64_t n, int32_t
     A->pat = pat;
     size_t cnt = (size_t)pat->nnzb * bs * bs;
     A->val.alloc(cnt);
-    if (nz) JH_HIP(hipMemcpyAsync(A->val.p, nz, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (nz) jh::copy_h2d(A->val.p, nz, cnt * sizeof(double), ctx->stream);
     else JH_HIP(hipMemsetAsync(A->val.p, 0, cnt * sizeof(double), ctx->stream));
     JH_HIP(hipStreamSynchronize(ctx->stream));
     *out = A.release();
@@ -262,10 +345,10 @@ extern "C" int32_t jh_csr_set_values(jh_csr A, const double *nz) {
     int bb = P.bs * P.bs;
     size_t cnt = (size_t)P.nnzb_host * bb;  // the host pattern; shadow slots of a multigraph read the zeroed spare slot behind it
     if (P.nz_hslot.empty()) {
-      JH_HIP(hipMemcpyAsync(A->val.p, nz, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      jh::copy_h2d(A->val.p, nz, cnt * sizeof(double), ctx->stream);
     } else {
       ctx->ensure_stage(cnt + bb);
-      JH_HIP(hipMemcpyAsync(ctx->stage.p, nz, cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      jh::copy_h2d(ctx->stage.p, nz, cnt * sizeof(double), ctx->stream);
       JH_HIP(hipMemsetAsync(ctx->stage.p + cnt, 0, bb * sizeof(double), ctx->stream));
       k_gather_blocks(ctx->stream, A->val.p, ctx->stage.p, P.d_nz_hslot.p, P.nnzb, bb, false);
     }
@@ -281,11 +364,11 @@ extern "C" int32_t jh_csr_get_values(jh_csr A, double *nz) {
     int bb = P.bs * P.bs;
     size_t cnt = (size_t)P.nnzb_host * bb;
     if (P.nz_hslot.empty()) {
-      JH_HIP(hipMemcpyAsync(nz, A->val.p, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      jh::copy_d2h(nz, A->val.p, cnt * sizeof(double), ctx->stream);
     } else {
       ctx->ensure_stage(cnt + bb);  // + the spare slot the shadow slots of a multigraph scatter into
       k_gather_blocks(ctx->stream, ctx->stage.p, A->val.p, P.d_nz_hslot.p, P.nnzb, bb, true);
-      JH_HIP(hipMemcpyAsync(nz, ctx->stage.p, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      jh::copy_d2h(nz, ctx->stage.p, cnt * sizeof(double), ctx->stream);
     }
     JH_HIP(hipStreamSynchronize(ctx->stream));
   });
@@ -386,7 +469,7 @@ extern "C" int32_t jh_law_set_data(jh_law L, int32_t which, const double *host) 
     hipStream_t s = ctx->stream;
     if (which == JH_FACE_TRANS || which == JH_FACE_GDZ) {
       ctx->ensure_stage(std::max<size_t>(d->nf, 1));
-      JH_HIP(hipMemcpyAsync(ctx->stage.p, host, d->nf * sizeof(double), hipMemcpyHostToDevice, s));
+      jh::copy_h2d(ctx->stage.p, host, d->nf * sizeof(double), s);
       if (which == JH_FACE_TRANS) {
         k_gather_face_data(s, L->Tnz.p, d->d_nz_face.p, ctx->stage.p, d->nnzb, false);
       } else {
@@ -396,7 +479,7 @@ extern "C" int32_t jh_law_set_data(jh_law L, int32_t which, const double *host) 
       }
     } else if (which == JH_CELL_VOLUME) {
       ctx->ensure_stage(d->nc);
-      JH_HIP(hipMemcpyAsync(ctx->stage.p, host, d->nc * sizeof(double), hipMemcpyHostToDevice, s));
+      jh::copy_h2d(ctx->stage.p, host, d->nc * sizeof(double), s);
       k_set_diag_data(s, L->Tnz.p, d->pat->d_diag.p, d->pat->perm.empty() ? nullptr : d->pat->d_perm.p, ctx->stage.p, d->nc, false, 0.0);
     } else {
       JH_THROW("unknown data id");
@@ -433,7 +516,7 @@ extern "C" int32_t jh_law_get_variable(jh_law L, int32_t which, int32_t e, doubl
     JH_HIP(hipSetDevice(ctx->device));
     ctx->ensure_stage(nc);
     k_component_out(ctx->stream, ctx->stage.p, which ? L->X0.p : L->X.p, P.perm.empty() ? nullptr : P.d_perm.p, nc, L->N, e);
-    JH_HIP(hipMemcpyAsync(out, ctx->stage.p, nc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    jh::copy_d2h(out, ctx->stage.p, nc * sizeof(double), ctx->stream);
     JH_HIP(hipStreamSynchronize(ctx->stream));
   });
 }
@@ -520,7 +603,7 @@ extern "C" int32_t jh_update_primary(jh_law L, jh_vec dx, double w, const double
     JH_HIP(hipSetDevice(L->ctx->device));
     const double *lim_dev = nullptr;
     if (limits) {
-      JH_HIP(hipMemcpyAsync(L->ctx->scalars.p + 16, limits, 5 * L->N * sizeof(double), hipMemcpyHostToDevice, L->ctx->stream));
+      jh::copy_h2d(L->ctx->scalars.p + 16, limits, 5 * L->N * sizeof(double), L->ctx->stream);
       lim_dev = L->ctx->scalars.p + 16;
       JH_HIP(hipStreamSynchronize(L->ctx->stream));
     }

@@ -152,7 +152,7 @@ void comm_allreduce_dev(jh_context ctx, double *p, int n, int op) {
     LocalGroup &G = *ctx->comm->local;
     const int r = ctx->comm->rank;
     std::vector<double> mine(n);
-    JH_HIP(hipMemcpyAsync(mine.data(), p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    jh::copy_d2h(mine.data(), p, sizeof(double) * n, ctx->stream);
     JH_HIP(hipStreamSynchronize(ctx->stream));
     G.slot[r] = mine;
     G.barrier();
@@ -163,7 +163,7 @@ void comm_allreduce_dev(jh_context ctx, double *p, int n, int op) {
       out[i] = acc;
     }
     G.barrier();  // everyone has read the slots
-    JH_HIP(hipMemcpyAsync(p, out.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    jh::copy_h2d(p, out.data(), sizeof(double) * n, ctx->stream);
     JH_HIP(hipStreamSynchronize(ctx->stream));
     return;
   }
@@ -209,7 +209,7 @@ static void halo_exchange_on(jh_tpfa d, double *v, int bs, hipStream_t s, bool p
     LocalGroup &G = *ctx->comm->local;
     const int me = ctx->comm->rank;
     std::vector<double> hs((size_t)H.n_send * bs), hr((size_t)H.n_recv * bs);
-    if (H.n_send) JH_HIP(hipMemcpyAsync(hs.data(), H.d_send_buf.p, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (H.n_send) jh::copy_d2h(hs.data(), H.d_send_buf.p, hs.size() * sizeof(double), s);
     JH_HIP(hipStreamSynchronize(s));
     for (size_t i = 0; i < H.nbr.size(); ++i)
       G.box[me][H.nbr[i]].assign(hs.begin() + H.send_ptr[i] * bs, hs.begin() + H.send_ptr[i + 1] * bs);
@@ -221,7 +221,7 @@ static void halo_exchange_on(jh_tpfa d, double *v, int bs, hipStream_t s, bool p
     }
     G.barrier();
     if (H.n_recv) {
-      JH_HIP(hipMemcpyAsync(H.d_recv_buf.p, hr.data(), hr.size() * sizeof(double), hipMemcpyHostToDevice, s));
+      jh::copy_h2d(H.d_recv_buf.p, hr.data(), hr.size() * sizeof(double), s);
       halo_unpack_launch(s, v, H.d_recv_buf.p, H.d_recv_idx.p, H.n_recv, bs);
       JH_HIP(hipStreamSynchronize(s));
     }
@@ -231,12 +231,12 @@ static void halo_exchange_on(jh_tpfa d, double *v, int bs, hipStream_t s, bool p
     Comm &c = *ctx->comm;
     c.cb_send.resize((size_t)H.n_send * bs);
     c.cb_recv.resize((size_t)H.n_recv * bs);
-    if (H.n_send) JH_HIP(hipMemcpyAsync(c.cb_send.data(), H.d_send_buf.p, c.cb_send.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (H.n_send) jh::copy_d2h(c.cb_send.data(), H.d_send_buf.p, c.cb_send.size() * sizeof(double), s);
     JH_HIP(hipStreamSynchronize(s));
     if (c.halo_cb(c.halo_cb_user, c.cb_send.data(), (int64_t)c.cb_send.size(), c.cb_recv.data(), (int64_t)c.cb_recv.size(), bs) != 0)
       JH_THROW("halo callback reported an error");
     if (H.n_recv) {
-      JH_HIP(hipMemcpyAsync(H.d_recv_buf.p, c.cb_recv.data(), c.cb_recv.size() * sizeof(double), hipMemcpyHostToDevice, s));
+      jh::copy_h2d(H.d_recv_buf.p, c.cb_recv.data(), c.cb_recv.size() * sizeof(double), s);
       halo_unpack_launch(s, v, H.d_recv_buf.p, H.d_recv_idx.p, H.n_recv, bs);
       JH_HIP(hipStreamSynchronize(s));  // cb_recv is reused by the next exchange
     }
@@ -458,9 +458,9 @@ extern "C" int32_t jh_comm_ipc_attach(jh_context ctx, const char *handles, int32
         for (int r = 1; r < c.nranks; ++r) acc = op ? std::max(acc, f(r)) : acc + f(r);
         want[i] = acc;
       }
-      JH_HIP(hipMemcpyAsync(dev, mine, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+      jh::copy_h2d(dev, mine, sizeof(double) * n, ctx->stream);
       mailbox_allreduce(ctx, dev, n, op, 500000000ull);  // 5 s
-      JH_HIP(hipMemcpyAsync(got, dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+      jh::copy_d2h(got, dev, sizeof(double) * n, ctx->stream);
       JH_HIP(hipStreamSynchronize(ctx->stream));
       if (c.mail_err->code) good = false;
       for (int i = 0; i < n; ++i) good = good && got[i] == want[i];
@@ -548,7 +548,7 @@ extern "C" int32_t jh_halo_ipc_selftest(jh_tpfa d, jh_vec v, const double *expec
     std::vector<double> got((size_t)H.n_recv * v->bs);
     if (H.n_recv) {
       halo_pack_launch(s, H.d_recv_buf.p, v->d.p, H.d_recv_idx.p, H.n_recv, v->bs);  // gather the ghost rows
-      JH_HIP(hipMemcpyAsync(got.data(), H.d_recv_buf.p, got.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+      jh::copy_d2h(got.data(), H.d_recv_buf.p, got.size() * sizeof(double), s);
     }
     JH_HIP(hipStreamSynchronize(s));
     bool good = c.mail_err->code == 0;
@@ -589,9 +589,9 @@ extern "C" int32_t jh_allreduce(jh_context ctx, double *values, int32_t n, int32
     if (n > 16) JH_THROW("jh_allreduce handles at most 16 scalars");
     JH_HIP(hipSetDevice(ctx->device));
     double *dev = ctx->scalars.p + 16;
-    JH_HIP(hipMemcpyAsync(dev, values, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    jh::copy_h2d(dev, values, sizeof(double) * n, ctx->stream);
     comm_allreduce_dev(ctx, dev, n, op);
-    JH_HIP(hipMemcpyAsync(values, dev, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    jh::copy_d2h(values, dev, sizeof(double) * n, ctx->stream);
     JH_HIP(hipStreamSynchronize(ctx->stream));
     comm_check_errors(ctx);
   });

@@ -2537,9 +2537,9 @@ extern "C" int32_t jh_ilu0_get_factor(jh_ilu M, double *lu) {
     if (M->jag) {  // chunk-jagged storage: every entry knows the slot of A it came from
       std::vector<double> l(M->jl_val.n), u(M->ju_val.n), d(M->jdinv.n);
       JH_HIP(hipStreamSynchronize(M->ctx->stream));
-      JH_HIP(hipMemcpy(l.data(), M->jl_val.p, l.size() * sizeof(double), hipMemcpyDeviceToHost));
-      JH_HIP(hipMemcpy(u.data(), M->ju_val.p, u.size() * sizeof(double), hipMemcpyDeviceToHost));
-      JH_HIP(hipMemcpy(d.data(), M->jdinv.p, d.size() * sizeof(double), hipMemcpyDeviceToHost));
+      jh::copy_d2h(l.data(), M->jl_val.p, l.size() * sizeof(double), M->ctx->stream);
+      jh::copy_d2h(u.data(), M->ju_val.p, u.size() * sizeof(double), M->ctx->stream);
+      jh::copy_d2h(d.data(), M->jdinv.p, d.size() * sizeof(double), M->ctx->stream);
       if (M->uscaled) {  // D-ILU storage: l holds A's entries; the factor's L_ik = A_ik inv(D~_k) (ilu0.jl:108-144)
         const int64_t nbk = (int64_t)M->blk_ptr.size() - 1;
         for (int64_t bk = 0; bk < nbk; ++bk) {
@@ -2570,9 +2570,9 @@ extern "C" int32_t jh_ilu0_get_factor(jh_ilu M, double *lu) {
     }
     std::vector<double> l(M->l_val.n), u(M->u_val.n), d(M->dinv.n);
     JH_HIP(hipStreamSynchronize(M->ctx->stream));
-    JH_HIP(hipMemcpy(l.data(), M->l_val.p, l.size() * sizeof(double), hipMemcpyDeviceToHost));
-    JH_HIP(hipMemcpy(u.data(), M->u_val.p, u.size() * sizeof(double), hipMemcpyDeviceToHost));
-    JH_HIP(hipMemcpy(d.data(), M->dinv.p, d.size() * sizeof(double), hipMemcpyDeviceToHost));
+    jh::copy_d2h(l.data(), M->l_val.p, l.size() * sizeof(double), M->ctx->stream);
+    jh::copy_d2h(u.data(), M->u_val.p, u.size() * sizeof(double), M->ctx->stream);
+    jh::copy_d2h(d.data(), M->dinv.p, d.size() * sizeof(double), M->ctx->stream);
     for (size_t j = 0; j < M->l_map.size(); ++j)
       for (int e = 0; e < bb; ++e) lu[hslot(M->l_map[j]) * bb + e] = l[j * bb + e];
     for (size_t j = 0; j < M->u_map.size(); ++j)

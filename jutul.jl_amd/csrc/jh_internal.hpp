@@ -120,6 +120,15 @@ constexpr int JH_NSCALARS = 64;   // device scalars of a context
 constexpr int S_STATS = 32;       // [32, 44): k_absstats results (4 per variable, N <= 3)
 
 // ---- device buffer helper ----------------------------------------------------------------------------
+// Host <-> device copies of caller-owned (pageable) memory.  They go through a page-locked bounce buffer of the library instead of
+// handing the caller's pointer to hipMemcpyAsync: for pageable memory the runtime pins the range on the fly and caches the pinning,
+// and a heap that shrinks and grows again under it (large numpy / std::vector buffers come from the brk heap once glibc has raised
+// its mmap threshold) ends in "Memory access fault by GPU ... on address <host heap page>" -- seen once in ~10 runs of the GPU
+// test suite (round 3), always inside an upload of a freshly computed array.  Memory that IS page-locked (jh_host_register,
+// hipHostMalloc) is copied directly.  Both calls return when the copy is complete; `s` orders it after earlier work of the stream.
+void copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s);
+void copy_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s);
+
 template <class T>
 struct DevBuf {
   T *p = nullptr;
@@ -140,11 +149,11 @@ struct DevBuf {
   }
   void upload(const T *h, size_t count, hipStream_t s) {
     if (count > n) alloc(count);
-    if (count) JH_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+    if (count) jh::copy_h2d(p, h, count * sizeof(T), s);
   }
   void upload(const std::vector<T> &h, hipStream_t s) {
     alloc(h.size());
-    if (!h.empty()) JH_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    if (!h.empty()) jh::copy_h2d(p, h.data(), h.size() * sizeof(T), s);
   }
 };
 
