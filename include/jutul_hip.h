@@ -175,11 +175,13 @@ int32_t jh_law_set_state0(jh_law L, const double *X0); /* previous-step state (s
 int32_t jh_law_get_state(jh_law L, double *X);
 /* One primary variable as Jutul stores it -- state[k] / state0[k], a contiguous Float64 array over the cells (host numbering):
  * which 0 = state, 1 = state0; e = 0-based index of the variable.  get_output_state (models.jl:1048-1058) copies state0[k] at
- * every report step: this call is the device -> host transfer behind it (straight into the host array, no staging pass on
- * the host).  With the target registered (jh_host_register) the copy is one DMA at PCIe speed. */
+ * every report step: this call is the device -> host transfer behind it.  With the target registered (jh_host_register) the
+ * copy is one DMA straight into the host array at PCIe speed. */
 int32_t jh_law_get_variable(jh_law L, int32_t which, int32_t e, double *out);
 /* hipHostRegister / hipHostUnregister of a host array the caller keeps alive (Jutul's state0[k] arrays live as long as the
- * simulator storage): page-locks it so that uploads / downloads are DMA transfers instead of pageable copies. */
+ * simulator storage): page-locks it so that uploads / downloads are direct DMA transfers.  Every other caller-owned array that
+ * crosses this interface is ordinary (pageable) memory: the library copies it through its own page-locked bounce buffer and the
+ * call returns when the copy is complete -- the caller may free or reuse the array at once. */
 int32_t jh_host_register(void *ptr, int64_t bytes);
 int32_t jh_host_unregister(void *ptr);
 int32_t jh_law_update_state0(jh_law L);                /* state0 <- state (update_after_step!, models.jl:983-1011) */
