@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 #include <unordered_map>
 
 #include "jh_internal.hpp"
@@ -15,22 +16,43 @@ using namespace jh;
 // ---- copies of pageable host memory through a page-locked bounce buffer (see jh_internal.hpp) -----------------------------------
 namespace jh {
 namespace {
+// One per host thread at a time: a copy waits for its stream while it owns the buffer, and the stream of one rank may hold a
+// kernel that waits for another rank (push halo, mailbox all-reduce) -- ranks that are threads of one process (the in-process test
+// backend) must not queue behind each other here.  A thread leases a buffer from a pool on its first copy and hands it back when it
+// exits; the buffers themselves live as long as the process (no runtime calls from thread-exit or process-exit destructors).
 struct Bounce {
-  std::mutex m;
-  void *buf[2] = {nullptr, nullptr};
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  static constexpr size_t CAP = (size_t)16 << 20;  // two halves of 16 MB
+  void *buf = nullptr;
+  static constexpr size_t CAP = (size_t)16 << 20;
   void ensure() {
-    if (buf[0]) return;
-    for (int i = 0; i < 2; ++i) {
-      JH_HIP(hipHostMalloc(&buf[i], CAP, hipHostMallocDefault));
-      JH_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
-    }
+    if (!buf) JH_HIP(hipHostMalloc(&buf, CAP, hipHostMallocPortable));  // usable with the streams of any device
+  }
+};
+struct BouncePool {
+  std::mutex m;
+  std::vector<Bounce *> idle;
+};
+BouncePool &bounce_pool() {
+  static BouncePool *p = new BouncePool();  // never destroyed
+  return *p;
+}
+struct BounceLease {
+  Bounce *b = nullptr;
+  ~BounceLease() {
+    if (!b) return;
+    BouncePool &P = bounce_pool();
+    std::lock_guard<std::mutex> lk(P.m);
+    P.idle.push_back(b);
   }
 };
 Bounce &bounce() {
-  static Bounce *b = new Bounce();  // never destroyed: the runtime may be gone before static destructors run
-  return *b;
+  static thread_local BounceLease lease;
+  if (!lease.b) {
+    BouncePool &P = bounce_pool();
+    std::lock_guard<std::mutex> lk(P.m);
+    if (!P.idle.empty()) { lease.b = P.idle.back(); P.idle.pop_back(); }
+    else lease.b = new Bounce();
+  }
+  return *lease.b;
 }
 bool page_locked(const void *host) {
   hipPointerAttribute_t a;
@@ -49,19 +71,13 @@ void copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s) 
     return;
   }
   Bounce &B = bounce();
-  std::lock_guard<std::mutex> lk(B.m);
   B.ensure();
-  size_t off = 0;
-  for (int k = 0; off < bytes; ++k) {
-    const int i = k & 1;
+  for (size_t off = 0; off < bytes; off += Bounce::CAP) {
     const size_t len = std::min(Bounce::CAP, bytes - off);
-    if (k >= 2) JH_HIP(hipEventSynchronize(B.ev[i]));  // the DMA that last read this half
-    std::memcpy(B.buf[i], (const char *)src_host + off, len);
-    JH_HIP(hipMemcpyAsync((char *)dst_dev + off, B.buf[i], len, hipMemcpyHostToDevice, s));
-    JH_HIP(hipEventRecord(B.ev[i], s));
-    off += len;
+    std::memcpy(B.buf, (const char *)src_host + off, len);
+    JH_HIP(hipMemcpyAsync((char *)dst_dev + off, B.buf, len, hipMemcpyHostToDevice, s));
+    JH_HIP(hipStreamSynchronize(s));  // (the host copy dominates: 16 MB take ~2 ms to copy and 0.3 ms to transfer)
   }
-  JH_HIP(hipStreamSynchronize(s));
 }
 void copy_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s) {
   if (!bytes) return;
@@ -71,26 +87,13 @@ void copy_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s) 
     return;
   }
   Bounce &B = bounce();
-  std::lock_guard<std::mutex> lk(B.m);
   B.ensure();
-  // chunk k+1 is on its way into one half while chunk k is copied out of the other
-  size_t off = 0, prev_off = 0, prev_len = 0;
-  int k = 0;
-  for (; off < bytes; ++k) {
-    const int i = k & 1;
+  for (size_t off = 0; off < bytes; off += Bounce::CAP) {
     const size_t len = std::min(Bounce::CAP, bytes - off);
-    JH_HIP(hipMemcpyAsync(B.buf[i], (const char *)src_dev + off, len, hipMemcpyDeviceToHost, s));
-    JH_HIP(hipEventRecord(B.ev[i], s));
-    if (k >= 1) {
-      JH_HIP(hipEventSynchronize(B.ev[i ^ 1]));
-      std::memcpy((char *)dst_host + prev_off, B.buf[i ^ 1], prev_len);
-    }
-    prev_off = off; prev_len = len;
-    off += len;
+    JH_HIP(hipMemcpyAsync(B.buf, (const char *)src_dev + off, len, hipMemcpyDeviceToHost, s));
+    JH_HIP(hipStreamSynchronize(s));
+    std::memcpy((char *)dst_host + off, B.buf, len);
   }
-  const int last = (k - 1) & 1;
-  JH_HIP(hipEventSynchronize(B.ev[last]));
-  std::memcpy((char *)dst_host + prev_off, B.buf[last], prev_len);
 }
 }  // namespace jh
 
