@@ -78,6 +78,8 @@ def parse_args(argv=None):
     # update_linearized_system_equation! -> convergence_criterion -> linear_solve! -> update_primary_variables! ->
     # update_after_step! [-> get_output_state]) through its call-for-call twin jutul.jl_amd/julia_mirror.py -- what simulate!
     # would get through the binding
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="context option (jh_context_set_option, include/jutul_hip.h), repeatable: A/B runs")
     ap.add_argument("--path", default="fused", choices=["fused", "seams"])
     ap.add_argument("--report-every", type=int, default=1,
                     help="--path seams: get_output_state (device -> host copy of the state, models.jl:1048-1058) after every n-th "
@@ -139,9 +141,6 @@ def main():
         del os.environ["NCCL_DEBUG"]
     os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/jutul_hip_rccl_%h_%p.log")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
-    # the library's default limit for a wait inside a solve is generous (600 s: JIT / lazy set-up skew); the ranks of a benchmark
-    # start together, so a peer that is 60 s late is a failure to report, not to sit out
-    os.environ.setdefault("JH_COMM_TIMEOUT_S", "60")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -191,7 +190,13 @@ def main():
     T = mesh["T"] / mesh["T"].mean()
     vol = mesh["volumes"]
     U0 = initial_state(np, args.law, nc_g)
-    ctx = ja.HIPContext(device)
+    # the library's default limit for a wait inside a solve is generous (600 s: JIT / lazy set-up skew); the ranks of a benchmark
+    # start together, so a peer that is 60 s late is a failure to report, not to sit out
+    options = {"comm_timeout_ms": 60000}
+    for kv in args.option:
+        k, _, v = kv.partition("=")
+        options[k.strip()] = int(v) if v else 1
+    ctx = ja.HIPContext(device, **options)
     mailbox = push = attached_all = False
     force_dist = os.environ.get("JH_BENCH_FORCE_DIST") == "1"  # exercise the distributed code path on one rank
     host_halo = False
@@ -467,7 +472,7 @@ def main():
                        "cells": nc_g, "faces": nf_g, "mesh": args.mesh, "law": args.law, "block_n": N, "dt": args.dt,
                        "block_rows": args.block_rows or "library default", "ilu_max_block_rows": info["max_block_rows"],
                        "parallelism": f"dd{world}" if world > 1 else "single", "precond_side": ks.config.precond_side,
-                       "path": args.path, "seams": seams_extra,
+                       "path": args.path, "seams": seams_extra, "options": {k: v for k, v in options.items() if k != "comm_timeout_ms"},
                        "launcher": os.environ.get("JH_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
                        "ranks_seen": ranks_seen, "devices_used": devices_used, "rccl_ranks": cinfo["rccl_ranks"],
                        "scalar_allreduce": ("mailbox" if mailbox else "rccl") if world > 1 else None,
@@ -489,7 +494,8 @@ def main():
             "timing": {"assembly_ms": round(asm_ms, 4),
                        "precond_update_ms": round(fac_ms, 4),
                        "linear_solve_ms": round(float(np.mean([r.linear_solve_ms for r in reps])), 4),
-                       "update_ms": round(float(np.mean([r.update_ms for r in reps])), 4)},
+                       "update_ms": round(float(np.mean([r.update_ms for r in reps])), 4),
+                       "us_per_krylov_iteration": round(float(np.sum([r.linear_solve_ms for r in reps])) * 1e3 / max(1.0, float(np.sum(lin_its))), 2)},
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

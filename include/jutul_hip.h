@@ -44,6 +44,23 @@ int32_t jh_version(void);
 int32_t jh_context_create(int32_t device_id, jh_context *out);
 int32_t jh_context_destroy(jh_context ctx);
 int32_t jh_synchronize(jh_context ctx); /* synchronize(ctx), context.jl:72 */
+/* Named integer options of a context -- the role of the keyword arguments of the reference's contexts and solver set-up
+ * (ParallelCSRContext(nthreads; matrix_layout, minbatch), contexts/csr.jl:3-23; ILUZeroPreconditioner / GenericKrylov kwargs,
+ * precond/ilu.jl:1-20, linsolve/krylov.jl:27-58): kernel and path choices a caller may make, read per handle.  Options that
+ * shape a layout are read when the object is created (set them before jh_tpfa_create / jh_ilu0_create / the first solve).
+ * Unknown key: error.  The environment variable JH_OPTIONS="key=value,key=value" seeds every new context (A/B runs).
+ *   consumer_reduce (1)   BiCGStab: the kernel that needs a fused dot product sums its partials itself (no reduction launch)
+ *   spmv_jagged (1), spmv_col_bits (0 = by size | 16 | 32), spmv_waves_per_xcd (0 = resident),
+ *   spmv_waves (0 = auto | 4 | 8 | 16 wavefronts per workgroup), spmv_window (1), spmv_pipe (1)
+ *   sync_loop (0)         1: no speculative Krylov iteration
+ *   halo_overlap (0), fused_pack (1), comm_timeout_ms (600000; 0 = wait like a collective)
+ *   fused_product (0), fuse_gather (1)
+ *   ilu_jagged (1), ilu_threads (0), ilu_factor_kernel (-1 = by pattern | 0 workgroup | 1 wavefront per block),
+ *   ilu_factor_threads (512), ilu_factor_wave_per_row (1), ilu_diag_factor (1), ilu_prog (1), ilu_factor_global (0)
+ *   asm_pipe (1), asm_pipe2_wgs (0), block_order (0 bisection | 1 onion)
+ *   read_sync (0), setup_timing (0), jds_keep (0) */
+int32_t jh_context_set_option(jh_context ctx, const char *key, int64_t value);
+int32_t jh_context_get_option(jh_context ctx, const char *key, int64_t *value);
 /* GPU timer on the context stream (HIP events) -- feeds report[:equations_time] & co (simulator.jl:427-433) */
 int32_t jh_timer_start(jh_context ctx);
 int32_t jh_timer_stop_ms(jh_context ctx, double *ms);

@@ -65,11 +65,23 @@ class HIPContext(_Handle):
     scalar CSR, float_type = Float64, index_type = Int64 on the host side, context.jl:76-78)."""
     _destroy = "jh_context_destroy"
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, **options):
+        """options: named integer options of the context (jh_context_set_option, include/jutul_hip.h), e.g.
+        HIPContext(0, consumer_reduce=0, spmv_col_bits=16)."""
         super().__init__()
         check(_L().jh_context_create(int(device), C.byref(self.h)))
         self.device = device
         self.comm_size, self.comm_rank = 1, 0
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    def set_option(self, key, value):
+        check(_L().jh_context_set_option(self.h, str(key).encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int64()
+        check(_L().jh_context_get_option(self.h, str(key).encode(), C.byref(v)))
+        return v.value
 
     def synchronize(self):
         check(_L().jh_synchronize(self.h))

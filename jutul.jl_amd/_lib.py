@@ -33,6 +33,8 @@ SIGNATURES = {
     "jh_context_create": [C.c_int32, C.POINTER(H)],
     "jh_context_destroy": [H],
     "jh_synchronize": [H],
+    "jh_context_set_option": [H, C.c_char_p, C.c_int64],
+    "jh_context_get_option": [H, C.c_char_p, C.POINTER(C.c_int64)],
     "jh_timer_start": [H],
     "jh_timer_stop_ms": [H, F64P],
     "jh_tpfa_create": [H, C.c_int64, C.c_int64, I64P, C.c_int32, C.c_int32, I64P, C.c_int64, C.c_int64, C.POINTER(H)],

@@ -107,6 +107,51 @@ inline void check(int32_t rc) {  // nested C-ABI call failed: the message is alr
 }
 }  // namespace
 
+// ---- options ----------------------------------------------------------------------------------------------------
+namespace jh {
+bool Options::set(const char *key, int64_t v) {
+#define JH_OPT_SET(name, def) if (std::strcmp(key, #name) == 0) { name = v; return true; }
+  JH_OPTION_LIST(JH_OPT_SET)
+#undef JH_OPT_SET
+  return false;
+}
+bool Options::get(const char *key, int64_t *v) const {
+#define JH_OPT_GET(name, def) if (std::strcmp(key, #name) == 0) { *v = name; return true; }
+  JH_OPTION_LIST(JH_OPT_GET)
+#undef JH_OPT_GET
+  return false;
+}
+void Options::seed_from_env() {
+  const char *e = getenv("JH_OPTIONS");
+  if (!e) return;
+  std::string str(e);
+  size_t pos = 0;
+  while (pos < str.size()) {
+    size_t end = str.find(',', pos);
+    if (end == std::string::npos) end = str.size();
+    const std::string item = str.substr(pos, end - pos);
+    pos = end + 1;
+    if (item.empty()) continue;
+    const size_t eq = item.find('=');
+    const std::string key = item.substr(0, eq);
+    const int64_t val = eq == std::string::npos ? 1 : atoll(item.c_str() + eq + 1);
+    if (!set(key.c_str(), val)) JH_THROW("JH_OPTIONS: unknown option '" + key + "'");
+  }
+}
+}  // namespace jh
+extern "C" int32_t jh_context_set_option(jh_context ctx, const char *key, int64_t value) {
+  return guard([&] {
+    if (!ctx || !key) JH_THROW("null argument");
+    if (!ctx->opt.set(key, value)) JH_THROW(std::string("unknown option '") + key + "'");
+  });
+}
+extern "C" int32_t jh_context_get_option(jh_context ctx, const char *key, int64_t *value) {
+  return guard([&] {
+    if (!ctx || !key || !value) JH_THROW("null argument");
+    if (!ctx->opt.get(key, value)) JH_THROW(std::string("unknown option '") + key + "'");
+  });
+}
+
 // ---- context --------------------------------------------------------------------------------------------------
 extern "C" int32_t jh_context_create(int32_t device_id, jh_context *out) {
   return guard([&] {
@@ -117,6 +162,7 @@ extern "C" int32_t jh_context_create(int32_t device_id, jh_context *out) {
     JH_HIP(hipSetDevice(device_id));
     auto c = std::make_unique<jh_context_s>();
     c->device = device_id;
+    c->opt.seed_from_env();
     JH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     JH_HIP(hipEventCreate(&c->ev0));
     JH_HIP(hipEventCreate(&c->ev1));
@@ -126,8 +172,6 @@ extern "C" int32_t jh_context_create(int32_t device_id, jh_context *out) {
     JH_HIP(hipHostMalloc((void **)&c->h_scalars, jh::JH_NSCALARS * sizeof(double), hipHostMallocDefault));
     JH_HIP(hipHostMalloc((void **)&c->h_pub, 2 * jh::JH_PUB_LEN * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->h_pub, 0, 2 * jh::JH_PUB_LEN * sizeof(double));
-    c->ticket.alloc(128);
-    JH_HIP(hipMemsetAsync(c->ticket.p, 0, 128 * sizeof(unsigned), c->stream));
     JH_HIP(hipHostMalloc((void **)&c->h_rd, jh::JH_NSCALARS * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->h_rd, 0, jh::JH_NSCALARS * sizeof(double));
     JH_HIP(hipStreamSynchronize(c->stream));
@@ -154,7 +198,6 @@ extern "C" int32_t jh_context_destroy(jh_context ctx) {
     }
     ctx->partials.release();
     ctx->scalars.release();
-    ctx->ticket.release();
     ctx->stage.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -394,7 +437,7 @@ extern "C" int32_t jh_spmv_jagged(jh_csr A, jh_vec x, jh_vec y, double alpha, do
     if (x->len != len || y->len != len) JH_THROW("DimensionMismatch (mat.jl:27-28)");
     if (x == y) JH_THROW("x and y must not alias");
     JH_HIP(hipSetDevice(A->ctx->device));
-    const bool keep = getenv("JH_JDS_KEEP") != nullptr;  // tools/spmv_probe.py: time the product without the refresh
+    const bool keep = A->ctx->opt.jds_keep != 0;  // tools/spmv_probe.py: time the product without the refresh
     if (!(keep && A->jval_fresh) && !sell_refresh(A)) JH_THROW("matrix has no jagged-slice form (block size > 1 or more than 8 entries in a row)");
     k_spmv_sell(A, x->d.p, y->d.p, alpha, beta, nullptr, nullptr);
     if (!keep) A->jval_fresh = false;
@@ -408,7 +451,7 @@ extern "C" int32_t jh_spmv_info(jh_csr A, int64_t *out6) {
     if (!P.jag.built) P.build_jagged();
     int32_t kmax = 0;
     for (int64_t i = 0; i < P.n; ++i) kmax = std::max(kmax, P.rowptr[i + 1] - P.rowptr[i]);
-    out6[0] = (P.jag.usable && !getenv("JH_SPMV_NO_JAGGED")) ? 1 : 0;
+    out6[0] = (P.jag.usable && A->ctx->opt.spmv_jagged) ? 1 : 0;
     out6[1] = (P.jag.usable && P.jag.d_col.n == 0) ? 1 : 0;
     out6[2] = kmax;
     out6[3] = P.jag.usable ? P.jag.nslices : 0;

@@ -586,11 +586,11 @@ void k_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
   dim3 grid(chunk * NUM_XCD), block(TILE_THREADS);
   const double *g = L->has_gdz ? L->gnz.p : nullptr;
 #define JH_ASM_ARGS P.d_tile_desc.p, P.ntiles, P.d_rowptr.p, P.d_col.p, P.d_diag.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row, (int)P.n
-  static const bool pipe = getenv("JH_ASM_NO_PIPE") == nullptr;
+  const bool pipe = ctx->opt.asm_pipe != 0;
   // persistent grid of the pipelined scalar kernels: 8 workgroups per CU like the SpMV
   dim3 pgrid((unsigned)(std::min(chunk, 256) * NUM_XCD));
-  static const int wg2 = getenv("JH_ASM_PIPE2_WGS") ? atoi(getenv("JH_ASM_PIPE2_WGS")) : 0;  // per XCD; 0 = tile kernel (the default: the pipelined kernel is not faster on 2x2 blocks)
-  static const bool pipe2 = pipe && wg2 > 0;
+  const int wg2 = (int)ctx->opt.asm_pipe2_wgs;  // per XCD; 0 = tile kernel (the default: the pipelined kernel is not faster on 2x2 blocks)
+  const bool pipe2 = pipe && wg2 > 0;
   dim3 pgrid2((unsigned)(std::min(chunk, std::max(wg2, 1)) * NUM_XCD));
 #define JH_ASM_PIPE_ARGS P.d_tile_desc.p, P.ntiles, P.d_rowptr.p, P.d_col.p, L->Tnz.p, g, L->X.p, L->X0.p, A->val.p, r->d.p, dt, par, reg_row, (int)P.n
   switch (L->kind) {

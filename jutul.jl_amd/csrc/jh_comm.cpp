@@ -413,7 +413,7 @@ extern "C" int32_t jh_comm_ipc_export(jh_context ctx, char *handle64) {
       std::memset((void *)c.mail_err, 0, sizeof(MailErr));
       c.mail_ctr.alloc(1);
       JH_HIP(hipMemset(c.mail_ctr.p, 0, sizeof(unsigned long long)));
-      if (const char *e = getenv("JH_COMM_TIMEOUT_S")) c.wait_ticks = (uint64_t)(std::max(0.0, atof(e)) * 1e8);  // 0 = unbounded
+      c.wait_ticks = (uint64_t)std::max<int64_t>(0, ctx->opt.comm_timeout_ms) * 100000ull;  // 100 MHz ticks; 0 = unbounded
     }
     hipIpcMemHandle_t h;
     JH_HIP(hipIpcGetMemHandle(&h, c.mail_self));

@@ -1021,25 +1021,45 @@ __device__ __forceinline__ void chunk_sweep(const IluDev &F, double *xs, int b0,
 // gather (the kernel is latency-, not bandwidth-bound, so the extra streams ride along):
 //   1:  s = r - alpha*q            (alpha = rho/<c,q>)             input := s, s stored
 //   2:  p = r + beta*(p - omega*q) (beta = (rho'/rho)(alpha/omega)) input := p, p stored
-template <int BS, int GM>
-__global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec,
-                                                              IluGather G) {
-  extern __shared__ __attribute__((aligned(16))) double xs[];
+// Start of a one-wavefront-per-block apply with a fused BiCGStab update (GM 1 / 2): the pending second reduction stage (PendSum),
+// the previous iteration's record (workgroup 0) and the coefficients -- GM 1: ca = alpha; GM 2: ca = beta, cb = omega.
+// false: the launch is a no-op (speculative iteration after the solve has converged); the answer is uniform over the wavefront.
+template <int GM>
+__device__ __forceinline__ bool apply_prologue(const IluGather &G, double &ca, double &cb) {
+  if (GM == 0) return true;
+  double p0 = 0.0, p1 = 0.0;
+  const bool pend = G.pend.part != nullptr;
+  if (pend) {
+    pend_sum_wave(G.pend, p0, p1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // for the kernels behind this one
+      G.sc_rw[G.pend.out_slot] = p0;
+      if (G.pend.count == 2) G.sc_rw[G.pend.out_slot + 1] = p1;
+    }
+  }
   if (GM == 2 && G.pub_rec && blockIdx.x == 0 && threadIdx.x == 0)
     publish_record(G.sc_rw, G.pub_pair, G.pub_eps, G.pub_rec, G.pub_seq);  // raises the done flag on convergence
-  if (GM != 0 && G.done && *G.done != 0.0) return;  // speculative launch after the Krylov solve has converged
-  const int b = blockIdx.x;
-  const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
-  const int nr = b1 - b0;
-  double ca = 0.0, cb = 0.0;
+  double dn = G.done ? *G.done : 0.0;
+  dn = __shfl(dn, 0, 64);  // (workgroup 0: lane 0 has just written the flag)
+  if (dn != 0.0) return false;  // speculative launch after the Krylov solve has converged
   if (GM == 1) {
-    ca = G.sc[G.rho_slot] / G.sc[G.cv_slot];  // alpha
+    ca = G.sc[G.rho_slot] / (pend ? p0 : G.sc[G.cv_slot]);  // alpha
   } else if (GM == 2) {
-    const double rho = G.sc[G.rho_slot], rho_next = G.sc[G.rho_next_slot];
+    const double rho = G.sc[G.rho_slot], rho_next = pend ? p0 : G.sc[G.rho_next_slot];
     const double alpha = rho / G.sc[G.cv_slot];
     cb = G.sc[G.ts_slot + 1] == 0.0 ? 0.0 : G.sc[G.ts_slot] / G.sc[G.ts_slot + 1];  // omega (0/0 guard, see bicg_omega)
     ca = (rho_next / rho) * (alpha / cb);        // beta
   }
+  return true;
+}
+template <int BS, int GM>
+__global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec,
+                                                              IluGather G) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];
+  double ca = 0.0, cb = 0.0;
+  if (!apply_prologue<GM>(G, ca, cb)) return;
+  const int b = blockIdx.x;
+  const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
+  const int nr = b1 - b0;
   // the block's rows are the device rows [b0, b1): they are read coalesced in device order and dropped at their ilu position
   // (rowmap16[dev] = position inside the block), so the vector loads do not wait for the map
   for (int t = threadIdx.x; t < nr; t += 64) {
@@ -1270,23 +1290,13 @@ struct IluMul {
 template <int BS, int GM, int KU, bool SC, int MUL>
 __global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec, IluGather G, IluMul Q) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
-  if (GM == 2 && G.pub_rec && blockIdx.x == 0 && threadIdx.x == 0)
-    publish_record(G.sc_rw, G.pub_pair, G.pub_eps, G.pub_rec, G.pub_seq);  // raises the done flag on convergence
-  if (GM != 0 && G.done && *G.done != 0.0) return;  // speculative launch after the Krylov solve has converged
+  double ca = 0.0, cb = 0.0;
+  if (!apply_prologue<GM>(G, ca, cb)) return;
   if (GM == 0 && MUL && G.done && *G.done != 0.0) return;
   const int b = blockIdx.x, lane = threadIdx.x;
   const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
   const int nr = b1 - b0;
   const int c0 = F.chunk_ptr[b], nch = F.chunk_ptr[b + 1] - c0;
-  double ca = 0.0, cb = 0.0;
-  if (GM == 1) {
-    ca = G.sc[G.rho_slot] / G.sc[G.cv_slot];  // alpha
-  } else if (GM == 2) {
-    const double rho = G.sc[G.rho_slot], rho_next = G.sc[G.rho_next_slot];
-    const double alpha = rho / G.sc[G.cv_slot];
-    cb = G.sc[G.ts_slot + 1] == 0.0 ? 0.0 : G.sc[G.ts_slot] / G.sc[G.ts_slot + 1];  // omega (0/0 guard, see bicg_omega)
-    ca = (rho_next / rho) * (alpha / cb);        // beta
-  }
   // the block's rows are the device rows [b0, b1): read coalesced in device order, dropped at their ilu position
   for (int t = lane; t < nr; t += 64) {
     const int dev = b0 + t;
@@ -1510,7 +1520,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     auto M = std::make_unique<jh_ilu_s>();
     M->ctx = A->ctx; M->A = A; M->pat = A->pat; M->bs = P.bs; M->n = n;
     JH_HIP(hipSetDevice(M->ctx->device));
-    const bool timing = getenv("JH_SETUP_TIMING") != nullptr;
+    const bool timing = M->ctx->opt.setup_timing != 0;
     auto tlast = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
       if (!timing) return;
@@ -1702,7 +1712,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       bytes = (bytes + 15) & ~(size_t)15;
       // (not beyond 64 KB: with the 160 KB opt-in the LDS row kernel took 151 ms on 512-row blocks of a 2M-cell polyhedral grid,
       // the global-memory row kernels 33 ms; long rows take the program-driven kernel instead, below)
-      if (mxl < 65536 && mxu < 65536 && maxrows < 65536 && bytes <= LDS_CAP_BYTES && !getenv("JH_ILU_FACTOR_GLOBAL")) {
+      if (mxl < 65536 && mxu < 65536 && maxrows < 65536 && bytes <= LDS_CAP_BYTES && !M->ctx->opt.ilu_factor_global) {
         M->max_blk_l = (int)mxl;
         M->max_blk_u = (int)mxu;
         M->factor_lds_bytes = bytes;
@@ -1735,10 +1745,10 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     lap("sizes, halo lists");
     // one wavefront per small block keeps many blocks resident per CU (the level loop is latency-bound)
     M->threads = maxrows <= 1024 ? 64 : (maxrows <= 2048 ? 128 : 256);
-    if (const char *e = getenv("JH_ILU_THREADS")) { int t = atoi(e); if (t == 64 || t == 128 || t == 256 || t == 512) M->threads = t; }
+    { const int t = (int)M->ctx->opt.ilu_threads; if (t == 64 || t == 128 || t == 256 || t == 512) M->threads = t; }
     // ---- chunk-jagged layout (ilu_apply_jds_kernel): per sweep and 64-row chunk, lanes sorted by entry count, entries stored
     // diagonal by diagonal.  Needs block-local 16-bit ids and at most 8 strict-L / strict-U entries per row.
-    if (lds && M->threads == 64 && maxrows < 65536 && maxlev < 0xffff && !getenv("JH_ILU_NO_JAGGED")) {
+    if (lds && M->threads == 64 && maxrows < 65536 && maxlev < 0xffff && M->ctx->opt.ilu_jagged) {
       int maxcnt = 0;
       for (int64_t t = 0; t < n; ++t) maxcnt = std::max({maxcnt, M->l_ptr[t + 1] - M->l_ptr[t], M->u_ptr[t + 1] - M->u_ptr[t]});
       if (maxcnt <= 8) {
@@ -1887,7 +1897,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
             // the sweep kernel keeps the block's inverted pivots in dynamic LDS (8 * rows * bs^2 bytes): blocks beyond the 64 KB a launch
             // gets without an opt-in (e.g. > 910 rows of 3x3 blocks from a caller's partition) take the program kernel
             M->diag_only = all_diag && mxc * 64 <= 1024 && sizeof(double) * (size_t)M->max_block_rows * M->bs * M->bs <= 64 * 1024 &&
-                           !getenv("JH_ILU_NO_DIAG_FACTOR");
+                           M->ctx->opt.ilu_diag_factor != 0;
             if (M->diag_only) {
               hipStream_t sd = M->ctx->stream;
               M->d_jt_map.upload(jt_map, sd); M->d_jf_diag.upload(jf_diag, sd); M->d_jf_bslot.upload(jf_bslot, sd);
@@ -1898,7 +1908,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
             // jagged SpMV.  The factor / matrix ENTRIES read twice today (0.41 GB) are saved, but the per-row streams the fusion
             // adds -- A_ii, the second copy of the pivots, the partial product written and read back, dot weights and q touched
             // again by the out-of-block rows at sector granularity -- cost as much: 1.8 GB either way.
-            M->uscaled = M->diag_only && M->blk_ptr.size() > 1 && getenv("JH_FUSED_PRODUCT") != nullptr;
+            M->uscaled = M->diag_only && M->blk_ptr.size() > 1 && M->ctx->opt.fused_product != 0;
             if (M->uscaled) {
               // device row (relative to its block) of every forward / backward lane, flagged when the row has entries outside the block;
               // the list of those entries ("E": what ilu_eprod_kernel adds after the apply)
@@ -1962,7 +1972,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
           }
           size_t bytes = sizeof(double) * P.bs * P.bs * (size_t)max_vals + sizeof(uint16_t) * (size_t)max_words;
           bytes = (bytes + 15) & ~(size_t)15;
-          if (ok && total < (size_t)INT32_MAX && bytes <= 160 * 1024 - 512 && !getenv("JH_ILU_NO_PROG")) {
+          if (ok && total < (size_t)INT32_MAX && bytes <= 160 * 1024 - 512 && M->ctx->opt.ilu_prog) {
             std::vector<uint16_t> prog(std::max<size_t>(total, 1), 0);
             parallel_ranges(nb, 64, [&](int64_t bb0, int64_t bb1) {
               for (int64_t b = bb0; b < bb1; ++b)
@@ -1993,7 +2003,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         JH_HIP(hipMemsetAsync(M->jl_val.p, 0, M->jl_val.n * sizeof(double), sj));
         JH_HIP(hipMemsetAsync(M->ju_val.p, 0, M->ju_val.n * sizeof(double), sj));
         JH_HIP(hipMemsetAsync(M->jdinv.p, 0, M->jdinv.n * sizeof(double), sj));
-      } else if (!getenv("JH_ILU_NO_PROG")) {
+      } else if (M->ctx->opt.ilu_prog) {
         // Rows with more than 8 strict-L / strict-U entries (polyhedral / PEBI cells): no jagged layout, the triangular sweeps keep
         // the row-major kernels -- but the refactorisation still runs program-driven (ilu_factor_prog_kernel over the row-major
         // arrays: value index = old entry position, pivot slot = U-order position).  The per-row factor kernels it replaces
@@ -2142,7 +2152,7 @@ extern "C" int32_t jh_ilu0_stats(jh_ilu M, int64_t *stats4) {
     stats4[1] = (int64_t)M->u_col.size();
     stats4[2] = (int64_t)M->blk_ptr.size() - 1;
     stats4[3] = (M->lds_mode ? 1 : 0) | (M->jag ? 2 : 0) | (((M->jag && M->prog) || M->prog_rowmajor) ? 4 : 0) | (M->jag && M->prog && M->diag_only ? 8 : 0) |
-                ((M->jag && M->uscaled && !getenv("JH_NO_FUSED_PRODUCT")) ? 16 : 0);
+                ((M->jag && M->uscaled && M->ctx->opt.fused_product) ? 16 : 0);
   });
 }
 
@@ -2230,7 +2240,7 @@ void ilu_factor(jh_ilu M) {
       // One wavefront per block (ilu_factor_wave_kernel) or one workgroup per block (ilu_factor_diag_kernel).  JH_ILU_FACTOR_WAVE:
       // unset = by block size and row length (see the kernel), 0 = never, 1 = always, 2 / 3 = always, with / without the prefetch of
       // the next chunk's operands
-      const int wave_env = getenv("JH_ILU_FACTOR_WAVE") ? atoi(getenv("JH_ILU_FACTOR_WAVE")) : -1;  // (per call: the tests switch it)
+      const int wave_env = (int)ctx->opt.ilu_factor_kernel;  // (per call: the tests switch it)
       const int wave = wave_env >= 0 ? wave_env : ((M->bs > 1 || M->jag_ku > 4) ? 1 : 0);
       if (wave) {
 #define JH_FWL(BSV, KUV, SCV, PFV) hipLaunchKernelGGL((ilu_factor_wave_kernel<BSV, KUV, SCV, PFV>), dim3((unsigned)nb), dim3(64), dlds, s, F, aval, \
@@ -2255,7 +2265,7 @@ void ilu_factor(jh_ilu M) {
       M->factored = true;
       return;
     }
-    static const int pthreads = getenv("JH_ILU_FACTOR_THREADS") ? atoi(getenv("JH_ILU_FACTOR_THREADS")) : 512;
+    const int pthreads = (int)ctx->opt.ilu_factor_threads;
 #define JH_PROG(BSV)                                                                                                             \
     do {                                                                                                                          \
       if (M->prog_lds_bytes > 64 * 1024)                                                                                          \
@@ -2272,8 +2282,8 @@ void ilu_factor(jh_ilu M) {
   if (M->prog_rowmajor && M->lds_mode) {  // long rows: the program-driven refactorisation over the row-major arrays
     IluDev F = dev_view(M);
     const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
-    static const int pthreads = getenv("JH_ILU_FACTOR_THREADS") ? atoi(getenv("JH_ILU_FACTOR_THREADS")) : 512;
-    static const bool wpr = getenv("JH_ILU_FACTOR_NO_WPR") == nullptr;  // wave per row (long rows); 0: thread per row
+    const int pthreads = (int)ctx->opt.ilu_factor_threads;
+    const bool wpr = ctx->opt.ilu_factor_wave_per_row != 0;  // wave per row (long rows); 0: thread per row
 #define JH_PROGR(BSV)                                                                                                            \
     do {                                                                                                                          \
       if (M->prog_lds_bytes > 64 * 1024)                                                                                          \
@@ -2295,7 +2305,7 @@ void ilu_factor(jh_ilu M) {
     const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
     const int mr = (int)M->max_block_rows;
     // the bulk load/store phases want many lanes (memory-level parallelism); the level loop only needs a few
-    static const int fthreads = getenv("JH_ILU_FACTOR_THREADS") ? atoi(getenv("JH_ILU_FACTOR_THREADS")) : 512;
+    const int fthreads = (int)ctx->opt.ilu_factor_threads;
     if (M->factor_lds_bytes > 64 * 1024) {
       const int fb = (int)M->factor_lds_bytes;
       switch (M->bs) {
@@ -2398,14 +2408,12 @@ void ilu_apply(jh_ilu M, const double *b, double *x) {
 #undef JH_BS_SWITCH
 }
 bool ilu_can_fuse_gather(jh_ilu M) {
-  static const bool off = getenv("JH_ILU_NO_CHUNK") != nullptr || getenv("JH_NO_FUSE") != nullptr;
-  return M && M->kind == 0 && M->lds_mode && M->threads == 64 && M->rowmap_local && !off;
+  return M && M->kind == 0 && M->lds_mode && M->threads == 64 && M->rowmap_local && M->ctx->opt.fuse_gather;
 }
 // x = M^-1 * (fused vector update), see IluGather / ilu_apply_chunked_kernel
 // true if ilu_apply_fused(..., pack = true) can fill the halo send buffer of the matrix' discretisation
 bool ilu_can_pack_halo(jh_ilu M) {
-  static const bool off = getenv("JH_NO_FUSED_PACK") != nullptr;
-  return !off && M && !M->send_ptr.empty() && M->A->disc && M->A->disc->halo.active && M->A->disc->halo.epoch == M->halo_epoch;
+  return M && M->ctx->opt.fused_pack && !M->send_ptr.empty() && M->A->disc && M->A->disc->halo.active && M->A->disc->halo.epoch == M->halo_epoch;
 }
 void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x, bool pack) {
   if (!M->factored) JH_THROW("ILU(0) applied before jh_ilu0_factor");
@@ -2437,8 +2445,8 @@ void ilu_apply_fused(jh_ilu M, const IluGather &G, double *x, bool pack) {
 // per block) and ilu_eprod_kernel (out-of-block entries, partials behind them).  Returns the number of partials; the caller
 // runs the second reduction stage.  done: the launches are no-ops once *done != 0.
 bool ilu_can_fuse_product(jh_ilu M) {
-  const bool off = getenv("JH_NO_FUSED_PRODUCT") != nullptr;  // (read per solve: the parity tests compare both paths in one process)
-  return !off && M && M->kind == 0 && M->jag && M->uscaled && M->factored;
+  // (the option is read per solve: the parity tests compare both paths in one process)
+  return M && M->ctx->opt.fused_product && M->kind == 0 && M->jag && M->uscaled && M->factored;
 }
 // the out-of-block entries' values in the order ilu_eprod_kernel reads them: once per solve (the matrix is constant inside one)
 void ilu_eprod_refresh(jh_ilu M) {

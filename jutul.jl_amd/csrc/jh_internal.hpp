@@ -159,6 +159,47 @@ struct DevBuf {
 
 struct Comm;  // RCCL state (jh_comm.cpp)
 
+// ---- per-context options (jh_context_set_option / jh_context_get_option; include/jutul_hip.h lists them) ------------------------
+// Every choice a caller can legitimately make about kernels and paths is a named integer option of the CONTEXT, read where the
+// object that depends on it is built (layouts: jh_tpfa_create / jh_ilu0_create / first solve) or per call (launch geometry, paths).
+// JH_OPTIONS="key=value,key=value" in the environment seeds the options of every new context (one getenv: A/B runs of bench.py).
+#define JH_OPTION_LIST(X)                                                                                                      \
+  X(consumer_reduce, 1)       /* BiCGStab: second stage of the fused dots inside the consuming kernel (PendSum) */            \
+  X(spmv_jagged, 1)           /* Krylov loop multiplies out of the jagged-slice copy when the matrix has one */               \
+  X(spmv_col_bits, 0)         /* jagged column ids: 16 / 32, 0 = by size (16 from 3M rows) */                                  \
+  X(spmv_waves_per_xcd, 0)    /* persistent wavefronts per XCD of the SpMV kernels, 0 = what is resident at once */            \
+  X(spmv_waves, 0)            /* wavefronts per workgroup of the jagged SpMV: 4 / 8 / 16, 0 = 4, or 8 with consumer_reduce */  \
+  X(spmv_window, 1)           /* CSR tile SpMV: LDS window of x */                                                             \
+  X(spmv_pipe, 1)             /* CSR tile SpMV with a fused dot: software-pipelined variant */                                 \
+  X(sync_loop, 0)             /* 1: the host waits for iteration k before enqueueing k+1 (no speculative iteration) */         \
+  X(halo_overlap, 0)          /* ghost exchange on a second stream behind the interior SpMV tiles */                           \
+  X(fused_product, 0)         /* D-ILU storage + product inside the preconditioner apply (set before jh_ilu0_create) */        \
+  X(fuse_gather, 1)           /* BiCGStab vector updates inside the gather phase of the ILU(0) apply */                        \
+  X(fused_pack, 1)            /* the ILU(0) apply fills the halo send buffer */                                                \
+  X(ilu_jagged, 1)            /* chunk-jagged factor layout (set before jh_ilu0_create) */                                     \
+  X(ilu_threads, 0)           /* threads per block of the row-major sweeps: 64 / 128 / 256 / 512, 0 = default */               \
+  X(ilu_factor_kernel, -1)    /* pivot-only refactorisation: 0 workgroup per block, 1 wavefront per block, -1 = by pattern */  \
+  X(ilu_factor_threads, 512)  /* program-driven refactorisation: threads per block */                                          \
+  X(ilu_factor_wave_per_row, 1)                                                                                                \
+  X(ilu_diag_factor, 1)       /* pivot-only kernels for triangle-free block patterns (set before jh_ilu0_create) */            \
+  X(ilu_prog, 1)              /* factorisation programs (set before jh_ilu0_create) */                                         \
+  X(ilu_factor_global, 0)     /* force the per-level refactorisation kernels (set before jh_ilu0_create) */                    \
+  X(asm_pipe, 1)              /* persistent pipelined assembly kernel (scalar laws) */                                         \
+  X(asm_pipe2_wgs, 0)         /* 2x2-block laws: workgroups per XCD of the pipelined kernel, 0 = tile kernel */                \
+  X(block_order, 0)           /* device blocks: 0 recursive bisection, 1 breadth-first "onion" (set before jh_tpfa_create) */  \
+  X(read_sync, 0)             /* device scalars through copy + stream synchronise instead of the pinned record */              \
+  X(comm_timeout_ms, 600000)  /* limit of the mailbox / push-halo waits inside kernels, 0 = wait like a collective */          \
+  X(setup_timing, 0)          /* print the set-up phases */                                                                    \
+  X(jds_keep, 0)              /* jh_spmv_jagged: do not refresh the jagged copy (timing probe) */
+struct Options {
+#define JH_OPT_FIELD(name, def) int64_t name = def;
+  JH_OPTION_LIST(JH_OPT_FIELD)
+#undef JH_OPT_FIELD
+  bool set(const char *key, int64_t v);         // false: unknown key
+  bool get(const char *key, int64_t *v) const;
+  void seed_from_env();                         // JH_OPTIONS
+};
+
 // Mailbox of the node-local scalar all-reduce / push halo (jh_comm_ipc_*, jh_halo_ipc_*; protocol in jh_halo.hip)
 constexpr int MAIL_R = 16, MAIL_V = 8;
 struct Mailbox {
@@ -185,21 +226,12 @@ struct MailArgs {
   MailErr *err = nullptr;
 };
 
-// Second stage of a fused dot product INSIDE the kernel that produces the partials: the last workgroup to arrive (two-level
-// arrival counters, so that no counter sees more than 64 arrivals) sums the partials in a fixed order, all-reduces over the
-// ranks through the mailboxes and writes the result -- instead of a one-workgroup kernel of its own (4.8 us per launch, three
-// per BiCGStab iteration: 10 % of an iteration at 1.25M cells per GPU).  tick == nullptr: off.
-struct TailArgs {
-  unsigned *tick = nullptr;
-  double *out = nullptr;   // count results
-  MailArgs mail;
-};
-
 }  // namespace jh
 
 // ---- handle structs ------------------------------------------------------------------------------------
 struct jh_context_s {
   int device = 0;
+  jh::Options opt;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_step[6] = {};  // jh_newton_step: factor / solve / update brackets, read once at the end of the step
@@ -211,7 +243,6 @@ struct jh_context_s {
   jh::DevBuf<double> stage;    // staging for permuted uploads/downloads
   double *h_pub = nullptr;     // pinned + coherent: 2 records of JH_PUB_LEN doubles the solver loop publishes to (see jh_krylov.hip)
   uint64_t pub_seq = 0;        // sequence number of the last published record
-  jh::DevBuf<unsigned> ticket; // arrival counters of the in-kernel second reduction stage (TailArgs): [0] groups done, [1 + g] workgroups of group g
   double *h_rd = nullptr;      // pinned + coherent: JH_NSCALARS doubles read_scalars publishes to, [JH_NSCALARS - 1] = sequence number
   uint64_t rd_seq = 0;
   jh::Comm *comm = nullptr;
@@ -411,8 +442,7 @@ constexpr int JDS_FAR = 0xE000;   // first 16-bit column code that is an index i
 constexpr int JDS_BACK = 0x7000;  // the slice's column window starts this many rows before its first row
 bool sell_refresh(jh_csr A);  // false: the matrix has no jagged form (block size > 1 or long rows) -> CSR tile kernels
 int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done,
-                bool reduce_now = true, const TailArgs *tail = nullptr);
-bool tail_args(jh_context ctx, int count, double *out, bool allreduce, TailArgs *t);  // false: use the separate reduction launch
+                bool reduce_now = true, int waves = 4);
 void spmv_dot_reduce(jh_context ctx, const SpmvDot *dot, int nparts, const double *done);
 void ensure_partials(jh_context ctx, size_t min_stride);
 void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max, const double *done = nullptr,
@@ -435,6 +465,19 @@ void k_update_primary(jh_law L, const double *dx, double w, const double *limits
 }  // namespace jh
 
 namespace jh {
+// Second stage of a fused dot product, run by its CONSUMER: the kernel that needs the scalar next sums the producer's partials
+// itself -- every wavefront redundantly, in one fixed order (per-lane left to right, then an xor butterfly), so all of them hold
+// the same bits -- instead of a one-workgroup kernel between producer and consumer (4.8 us + a kernel boundary each, four per
+// BiCGStab iteration: 16 % of an iteration at 1.25M cells per GPU).  No atomics, no flags, no spinning: the kernel boundary that
+// is there anyway orders partials and consumer.  Workgroup 0 of the consumer also stores the sums to sc[out_slot (, +1)] for the
+// kernels behind it.  Producers that feed a PendSum run with at most PEND_MAX workgroups (16 loads per lane and sum).
+constexpr int PEND_MAX = 1024;
+struct PendSum {
+  const double *part = nullptr;  // nullptr: nothing pending, the scalars are in sc[]
+  unsigned stride = 0;           // second sum at part + stride
+  int nparts = 0, count = 0;     // count 1 or 2
+  int out_slot = 0;
+};
 // BiCGStab vector update fused into the gather phase of the ILU(0) apply (see ilu_apply_chunked_kernel)
 struct IluGather {
   int mode = 0;             // 1: s = r - alpha*q ; 2: p = r + beta*(p - omega*q)
@@ -449,6 +492,9 @@ struct IluGather {
   double *pub_rec = nullptr, *sc_rw = nullptr;
   double pub_seq = 0.0, pub_eps = 0.0;
   int pub_pair = 0;
+  // mode 1: <c, A y> (-> cv_slot) still lies in the product's partials; mode 2: (rho_next, ||r||^2) (-> rho_next_slot, +1) in the
+  // partials of bicg_xr_dots_kernel -- summed by every wavefront of the apply, stored (and, mode 2, published) by workgroup 0
+  PendSum pend;
 };
 }  // namespace jh
 
@@ -464,6 +510,27 @@ __device__ __forceinline__ void publish_record(double *sc, int pair_slot, double
   __hip_atomic_store(rec + 8, conv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence_system();
   __hip_atomic_store(rec + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// PendSum: called by all 64 lanes of a wavefront; every lane returns the same sums (s1 only when count == 2)
+__device__ __forceinline__ void pend_sum_wave(const PendSum &P, double &s0, double &s1) {
+  const int lane = threadIdx.x & 63;
+  double v0[PEND_MAX / 64], v1[PEND_MAX / 64];
+#pragma unroll
+  for (int j = 0; j < PEND_MAX / 64; ++j) {  // all loads first
+    const int i = lane + 64 * j;
+    v0[j] = (i < P.nparts) ? P.part[i] : 0.0;
+    v1[j] = (P.count == 2 && i < P.nparts) ? P.part[P.stride + i] : 0.0;
+  }
+  double a0 = v0[0], a1 = v1[0];
+#pragma unroll
+  for (int j = 1; j < PEND_MAX / 64; ++j) { a0 += v0[j]; a1 += v1[j]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {  // a + b == b + a: both partners of an exchange end with the same bits
+    a0 += __shfl_xor(a0, off, 64);
+    a1 += __shfl_xor(a1, off, 64);
+  }
+  s0 = a0;
+  s1 = a1;
 }
 // All-reduce of p[0..n) (n <= MAIL_V, global or LDS memory, in place) over the ranks of the node.  Called by ALL threads of a
 // workgroup of >= 64 threads (threads 0..63 work, everybody joins the barrier); op 0 sum, 1 max (NaN propagating).  Each rank
@@ -562,63 +629,6 @@ __device__ __forceinline__ void final_reduce_body(const double *part, size_t str
     if (threadIdx.x == 0) {
       double r = sm[0];
       for (int w = 1; w < FIN_THREADS / 64; ++w) r = MAX ? ((sm[w] > r || sm[w] != sm[w]) ? sm[w] : r) : r + sm[w];
-      out[k] = r;
-    }
-    __syncthreads();
-  }
-}
-// ---- in-kernel second reduction stage (TailArgs) ------------------------------------------------------------------------------
-// A partial that another workgroup (possibly on another XCD, whose L2 is not coherent with ours) will read inside this kernel:
-// written through to the memory side, and complete before the arrival counter is touched.
-__device__ __forceinline__ void tail_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// Called by ALL threads of every workgroup after thread 0 has tail_store'd the workgroup's partials; true in exactly one
-// workgroup, the last to arrive, after which every partial of the launch is visible to tail_load.  The counters are left at zero.
-__device__ __forceinline__ bool tail_arrive(unsigned *tick, unsigned nblocks) {
-  __shared__ unsigned tail_last;
-  if (threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores above have been acknowledged
-    const unsigned g = blockIdx.x >> 6, ng = (nblocks + 63u) >> 6;
-    const unsigned gsize = min(64u, nblocks - (g << 6));
-    unsigned last = 0;
-    if (__hip_atomic_fetch_add(tick + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
-      __hip_atomic_store(tick + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1u) {
-        __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = 1;
-      }
-    }
-    tail_last = last;
-  }
-  __syncthreads();
-  // The winner reads partials other XCDs wrote through to memory: drop what this XCD's L2 / L1 may still hold of those lines
-  // from an earlier reduction (round 3: without this the compressible 10M-cell run read stale partials now and then -- 100
-  // instead of 60 BiCGStab iterations per step, then a diverging solve)
-  if (tail_last != 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return tail_last != 0;
-}
-// ordered sum (or max) of nparts partials of `count` slots by the NT threads of one workgroup, reading past the local L2
-template <bool MAX, int NT>
-__device__ __forceinline__ void tail_reduce(const double *part, size_t stride, int nparts, int count, double *out) {
-  __shared__ double tail_sm[NT / 64];
-  for (int k = 0; k < count; ++k) {
-    const double *p = part + k * stride;
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
-    int j = 0;
-    for (int i = threadIdx.x; i < nparts; i += NT, ++j) {
-      const double v = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      a[j & 3] = MAX ? ((v > a[j & 3] || v != v) ? v : a[j & 3]) : a[j & 3] + v;
-    }
-    double s = MAX ? fmax(fmax(a[0], a[1]), fmax(a[2], a[3])) : (a[0] + a[1]) + (a[2] + a[3]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double o = __shfl_down(s, off, 64);
-      s = MAX ? ((o > s || o != o) ? o : s) : s + o;
-    }
-    if ((threadIdx.x & 63) == 0) tail_sm[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double r = tail_sm[0];
-      for (int w = 1; w < NT / 64; ++w) r = MAX ? ((tail_sm[w] > r || tail_sm[w] != tail_sm[w]) ? tail_sm[w] : r) : r + tail_sm[w];
       out[k] = r;
     }
     __syncthreads();

@@ -238,7 +238,7 @@ void k_absstats(jh_context ctx, const double *a, const double *b, int64_t ncell,
 // Device scalars -> host.  A D2H copy + hipStreamSynchronize costs a DMA packet and an interrupt-driven wake-up per read;
 // the seam path reads scalars three times per Newton iteration (convergence, increment norms, change report).  Instead a
 // one-wavefront kernel stores the values into pinned, host-coherent memory followed by a sequence number, and the host spins
-// on that (the protocol of the Krylov loop's iteration records).  JH_READ_SYNC=1 restores the copy + synchronise.
+// on that (the protocol of the Krylov loop's iteration records).  Option read_sync = 1 restores the copy + synchronise.
 __global__ void publish_scalars_kernel(const double *sc, int count, double *dst, double seq) {
   if ((int)threadIdx.x < count) __hip_atomic_store(dst + threadIdx.x, sc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence_system();
@@ -246,7 +246,7 @@ __global__ void publish_scalars_kernel(const double *sc, int count, double *dst,
   if (threadIdx.x == 0) __hip_atomic_store(dst + (JH_NSCALARS - 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 void read_scalars(jh_context ctx, int slot, int count, double *out) {
-  static const bool use_sync = getenv("JH_READ_SYNC") != nullptr;
+  const bool use_sync = ctx->opt.read_sync != 0;
   if (use_sync || !ctx->h_rd || count >= JH_NSCALARS - 1) {
     JH_HIP(hipMemcpyAsync(ctx->h_scalars + slot, ctx->scalars.p + slot, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
     JH_HIP(hipStreamSynchronize(ctx->stream));
@@ -537,17 +537,6 @@ __global__ __launch_bounds__(TILE_THREADS) void spmv_pipe_kernel(const int32_t *
 }
 
 // second stage of a fused SpMV dot; with dot->allreduce also over the ranks (same launch if the mailboxes are on)
-// TailArgs for a reduction of `count` doubles into `out` (summed over the ranks if allreduce): usable on one rank, or when the
-// mailboxes carry the scalar all-reduces (an RCCL all-reduce cannot run inside a kernel).  The caller decides whether it pays.
-bool tail_args(jh_context ctx, int count, double *out, bool allreduce, TailArgs *t) {
-  if (!ctx->ticket.p) return false;
-  TailArgs a;
-  a.tick = ctx->ticket.p;
-  a.out = out;
-  if (allreduce && comm_size(ctx) > 1 && !comm_mail_args(ctx, count, &a.mail)) return false;
-  *t = a;
-  return true;
-}
 void spmv_dot_reduce(jh_context ctx, const SpmvDot *dot, int nparts, const double *done) {
   const int cnt = dot->mode == 2 ? 2 : 1;
   MailArgs ma;
@@ -568,7 +557,7 @@ int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x,
     return 0;
   }
   int chunk = (ntl + NUM_XCD - 1) / NUM_XCD;
-  static const int wg_per_xcd = getenv("JH_SPMV_WGS") ? atoi(getenv("JH_SPMV_WGS")) : 256;  // 32 CUs x 8 workgroups
+  const int wg_per_xcd = ctx->opt.spmv_waves_per_xcd > 0 ? std::max<int>(1, (int)ctx->opt.spmv_waves_per_xcd / 4) : 256;  // default: 32 CUs x 8 workgroups
   const int mode = dot ? dot->mode : 0;
   const int per_xcd = mode ? std::min(chunk, wg_per_xcd) : chunk;  // plain SpMV: one tile per workgroup
   dim3 grid(per_xcd * NUM_XCD), block(TILE_THREADS);
@@ -577,11 +566,11 @@ int k_spmv(jh_context ctx, const Pattern &P, const double *val, const double *x,
   const int drows = dot ? (int)dot->n_rows : 0;
   double *part = ctx->partials.p + part_off;
   const size_t ps = ctx->partial_stride;
-  static const bool xwin = getenv("JH_SPMV_NO_WINDOW") == nullptr;
+  const bool xwin = ctx->opt.spmv_window != 0;
 #define JH_SPMV(BSV, DV)                                                                                                      \
   if (BSV == 1 && xwin) JH_SPMV_X(BSV, DV, true); else JH_SPMV_X(BSV, DV, false)
 #define JH_SPMV_X(BSV, DV, XWV) hipLaunchKernelGGL((spmv_tile_kernel<BSV, DV, (BSV == 1) && XWV>), grid, block, 0, ctx->stream, P.d_tile_desc.p, ntl, (int)P.n, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta, dw, drows, part, ps, done, t_begin)
-  static const bool pipe = getenv("JH_SPMV_NO_PIPE") == nullptr;
+  const bool pipe = ctx->opt.spmv_pipe != 0;
 #define JH_SPMV_PIPE(DV) hipLaunchKernelGGL((spmv_pipe_kernel<DV>), grid, block, 0, ctx->stream, P.d_tile_desc.p, ntl, (int)P.n, P.d_rowptr.p, P.d_col.p, val, x, y, alpha, beta, dw, drows, part, ps, done, t_begin)
   switch (P.bs * 10 + mode) {
     case 10: JH_SPMV(1, 0); break;

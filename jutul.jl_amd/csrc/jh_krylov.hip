@@ -107,16 +107,22 @@ __global__ void bicg_publish_kernel(double *sc, int pair_slot, double eps, doubl
 }
 // fused: x_out = x_in + alpha*y + omega*z ; r = s - omega*t ; partial sums of <c,r> and <r,r> over the first nd entries.
 // x ping-pongs between two buffers so that the iterate of iteration k survives the speculatively enqueued iteration k+1.
-// tail.tick != nullptr: the last workgroup to arrive also runs the second reduction stage -- (rho_next, ||r||^2) -> sc[out_slot..+1],
-// all-reduce over the ranks through the mailboxes, stopping test and the iteration's record (what bicg_reduce_publish_kernel does)
-__global__ __launch_bounds__(256) void bicg_xr_dots_kernel(const double *x_in, double *x_out, double *r, const double *y, const double *z,
-                                                           const double *s, const double *t, const double *c, double *sc,
-                                                           int rho_slot, int64_t n, int64_t nd, double *part, size_t stride,
-                                                           const double *done, TailArgs tail, int out_slot, double eps, double *rec, double seq) {
+// pend.part != nullptr: (<t,s>, <t,t>) still lie in the partials of the second product -- every wavefront sums them itself
+// (PendSum), workgroup 0 stores them to sc[S_TS], sc[S_TT].  NT threads; one partial per workgroup and sum.
+template <int NT>
+__global__ __launch_bounds__(NT) void bicg_xr_dots_kernel(const double *x_in, double *x_out, double *r, const double *y, const double *z,
+                                                          const double *s, const double *t, const double *c, double *sc,
+                                                          int rho_slot, int64_t n, int64_t nd, double *part, size_t stride,
+                                                          const double *done, PendSum pend) {
   if (done && *done != 0.0) return;
-  __shared__ double sm[4];
+  __shared__ double sm[2 * (NT / 64)];
+  double ts = sc[S_TS], tt = sc[S_TT];
+  if (pend.part) {
+    pend_sum_wave(pend, ts, tt);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[S_TS] = ts; sc[S_TT] = tt; }
+  }
   const double alpha = sc[rho_slot] / sc[S_CV];
-  const double omega = bicg_omega(sc[S_TS], sc[S_TT]);
+  const double omega = bicg_omega(ts, tt);
   double d0 = 0.0, d1 = 0.0;
   // two entries per lane and access (16-byte loads and stores; the vectors are 256-byte aligned device allocations)
   const int64_t n2 = n >> 1;
@@ -150,25 +156,36 @@ __global__ __launch_bounds__(256) void bicg_xr_dots_kernel(const double *x_in, d
     r[i] = ri;
     if (i < nd) { d0 += c[i] * ri; d1 += ri * ri; }
   }
-  // block reduction (4 wavefronts)
+  // block reduction in a fixed order
+  constexpr int NWV = NT / 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); d1 += __shfl_down(d1, off, 64); }
-  if (lane == 0) sm[w] = d0;
+  if (lane == 0) { sm[w] = d0; sm[NWV + w] = d1; }
   __syncthreads();
-  const double p0 = (sm[0] + sm[1]) + (sm[2] + sm[3]);
-  __syncthreads();
-  if (lane == 0) sm[w] = d1;
-  __syncthreads();
-  const double p1 = (sm[0] + sm[1]) + (sm[2] + sm[3]);
   if (threadIdx.x == 0) {
-    if (tail.tick) { tail_store(part + blockIdx.x, p0); tail_store(part + stride + blockIdx.x, p1); }
-    else { part[blockIdx.x] = p0; part[stride + blockIdx.x] = p1; }
+    double a[NWV], b[NWV];
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) { a[i] = sm[i]; b[i] = sm[NWV + i]; }
+#pragma unroll
+    for (int m = NWV; m > 1; m >>= 1) {
+#pragma unroll
+      for (int i = 0; i < m / 2; ++i) { a[i] = a[2 * i] + a[2 * i + 1]; b[i] = b[2 * i] + b[2 * i + 1]; }
+    }
+    part[blockIdx.x] = a[0];
+    part[stride + blockIdx.x] = b[0];
   }
-  if (tail.tick && tail_arrive(tail.tick, gridDim.x)) {
-    tail_reduce<false, 256>(part, stride, (int)gridDim.x, 2, sc + out_slot);
-    if (tail.mail.self) mailbox_allreduce_body(tail.mail, sc + out_slot, 2, 0);
-    if (rec && threadIdx.x == 0) publish_record(sc, out_slot, eps, rec, seq);
+}
+// (rho_next, ||r||^2) of the LAST enqueued iteration, whose partials no later kernel consumes: the same sums in the same order as
+// a consuming kernel would form them (pend_sum_wave), then the iteration's record.  One wavefront.
+__global__ __launch_bounds__(64) void bicg_pend_publish_kernel(PendSum pend, double *sc, const double *done, double eps, double *rec, double seq) {
+  if (done && *done != 0.0) return;
+  double p0, p1;
+  pend_sum_wave(pend, p0, p1);
+  if (threadIdx.x == 0) {
+    sc[pend.out_slot] = p0;
+    sc[pend.out_slot + 1] = p1;
+    publish_record(sc, pend.out_slot, eps, rec, seq);
   }
 }
 // second stage of the reduction above: (rho_next, ||r||^2) -> sc[out_slot..+1]; without a communicator the same launch
@@ -294,17 +311,11 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     comm_allreduce_dev(ctx, sc + slot, c2 ? 2 : 1, 0);
   };
   const int64_t rows_dot = nd / P.bs;
-  // Second reduction stage inside the producing kernel (TailArgs) instead of a one-workgroup launch: measured on MI355X
-  // (profiles/r03_tail_reduce_*): 10M cells +1.5 % Newton it/s on one box, -0.8 % on another (box-to-box spread is +-3 %); 1.25M
-  // cells -21 % -- the workgroups of a 28 us kernel all arrive within a few microseconds and the memory-side arrival counters
-  // cost ~0.25 us per contended increment (SpMV 27.9 -> 43.6 us).  Opt-in: JH_TAIL_REDUCE=1 (read per solve: the tests compare
-  // both paths).
-  const bool tail_pays = getenv("JH_TAIL_REDUCE") && atoi(getenv("JH_TAIL_REDUCE")) != 0;
   // Right preconditioning with column-scaled pivot-only factors: every product of the loop is A * (M^-1 v), and its in-block part
   // is formed inside the apply (ilu_apply_mul); the out-of-block entries -- ghost columns among them, hence after the ghost
   // exchange -- follow in ilu_eprod.  No SpMV launch, no jagged copy of the matrix.
-  static const bool want_overlap_ = getenv("JH_HALO_OVERLAP") != nullptr;
-  const bool fmul = right && ilu_can_fuse_gather(M) && ilu_can_fuse_product(M) && !(dist && want_overlap_);
+  const bool want_overlap = ctx->opt.halo_overlap != 0;
+  const bool fmul = right && ilu_can_fuse_gather(M) && ilu_can_fuse_product(M) && !(dist && want_overlap);
   const bool fmul_pack = fmul && dist && ilu_can_pack_halo(M);
   // the matrix does not change during the solve: multiply out of its jagged-slice copy when it has one (jh_sell.hip)
   const bool jagged = !fmul && sell_refresh(K->A);
@@ -321,17 +332,30 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     K->mark(0, st);
     spmv_dot_reduce(ctx, &dot, nparts, done);
   };
+  // One rank, fused right preconditioning, jagged product: nobody has to exchange the dots, so the kernel that needs a dot next
+  // sums its partials itself (PendSum) -- <c, A y> in the s-update apply, (<t,s>, <t,t>) in the x,r kernel, (rho', ||r||^2) in the
+  // next iteration's p-update apply, whose workgroup 0 also publishes the record.  Four one-workgroup launches per iteration gone;
+  // the producers run with larger workgroups so that a full-chip launch leaves at most PEND_MAX partials.
+  const bool pend_ok = ctx->opt.consumer_reduce && !fmul && jagged && right && ilu_can_fuse_gather(M) && !dist && comm_size(ctx) == 1;
+  PendSum pend_spmv;  // partials of the last product with a fused dot
+  const int spmv_waves = ctx->opt.spmv_waves ? (int)ctx->opt.spmv_waves : (pend_ok ? 8 : 4);
   auto spmv = [&](double *in, double *out, const SpmvDot *dot, bool packed = false) {
     if (dist) halo_exchange(disc, in, P.bs, packed, true);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
     K->mark(0, st);
     if (jagged) {
       // the event pair brackets the product kernel alone (what rocprofv3 reports for it); the second stage of its fused dot,
-      // with the all-reduce over the ranks, follows
-      TailArgs ta;
-      const bool tail = tail_pays && dot && dot->mode && tail_args(ctx, dot->mode == 2 ? 2 : 1, sc + dot->slot, dot->allreduce, &ta);
-      const int nparts = k_spmv_sell(K->A, in, out, 1.0, 0.0, dot, done, false, tail ? &ta : nullptr);
+      // with the all-reduce over the ranks, follows -- or is left to the consuming kernel
+      const int nparts = k_spmv_sell(K->A, in, out, 1.0, 0.0, dot, done, false, spmv_waves);
       K->mark(0, st);
-      if (dot && dot->mode && !tail) spmv_dot_reduce(ctx, dot, nparts, done);
+      if (dot && dot->mode) {
+        if (pend_ok && nparts <= PEND_MAX) {
+          pend_spmv.part = ctx->partials.p; pend_spmv.stride = (unsigned)ctx->partial_stride; pend_spmv.nparts = nparts;
+          pend_spmv.count = dot->mode == 2 ? 2 : 1; pend_spmv.out_slot = dot->slot;
+        } else {
+          pend_spmv = PendSum();
+          spmv_dot_reduce(ctx, dot, nparts, done);
+        }
+      }
       return;
     }
     k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done);  // dot->allreduce: summed over the ranks in there
@@ -372,16 +396,15 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   // right preconditioning: the s- and p-updates are fused into the gather phase of the ILU(0) apply
   const bool fuse = right && ilu_can_fuse_gather(M);
   const int ghost_from = dist ? (int)(nd / P.bs) : 0x7fffffff;
-  static const int lag = getenv("JH_SYNC_LOOP") ? 0 : 1;
+  const int lag = ctx->opt.sync_loop ? 0 : 1;
   // Rank-local subdomain: the device order is [interior blocks | boundary blocks | ghost blocks].  Opt-in
-  // (JH_HALO_OVERLAP=1): a fused half-iteration "v = A * N^-1(update)" runs as
+  // (option halo_overlap = 1): a fused half-iteration "v = A * N^-1(update)" runs as
   //   compute stream: ILU(0) apply | SpMV(interior tiles) | wait | SpMV(boundary tiles)
   //   comm stream   :              | pack, send/recv, unpack |
   // hiding the ghost exchange of the preconditioned vector (consistent!, linalg.jl:46) behind the interior SpMV.
   // Off by default: on one GPU with a real RCCL self send/recv (tools/overlap_probe.py, the 1.25M-cell share of the 8-GPU
   // run) the two cross-stream event hops (~8 us each) and the second SpMV launch cost more than the 22 us exchange they
   // hide (247 vs 214 us per iteration); also splitting the ILU apply doubled its latency-bound time (261 us).
-  static const bool want_overlap = getenv("JH_HALO_OVERLAP") != nullptr;
   const bool overlap = dist && fuse && want_overlap && P.interior_tiles >= 0 && !disc->halo.push_enabled;
   // the fused ILU(0) apply also fills the halo send buffer with the rows neighbouring ranks hold as ghosts
   const bool pack = dist && fuse && ilu_can_pack_halo(M);
@@ -401,8 +424,9 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     K->mark(2, st);
   };
   double seq_of[2] = {0, 0};
-  double *pend_rec = nullptr, pend_seq = 0, pend_eps = 0;  // record of the previous iteration still to be published (distributed runs)
+  double *pend_rec = nullptr, pend_seq = 0, pend_eps = 0;  // record of the previous iteration still to be published (by the next apply)
   int pend_pair = 0;
+  PendSum pend_xr;  // partials of the last x,r kernel still to be summed (by the next apply)
   // pair holding (rho, rr) at the start of iteration k; the next one goes to the other pair
   auto pair_of = [](int64_t k) { return (k & 1) ? (int)S_PAIR0 : (int)S_PAIR1; };
   auto enqueue = [&](int64_t k) {
@@ -417,6 +441,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       G.mode = 2; G.r = K->r.p; G.q = K->q.p; G.out = K->p.p; G.sc = sc; G.done = done;
       G.rho_slot = pair_of(k - 1); G.rho_next_slot = rs; G.cv_slot = S_CV; G.ts_slot = S_TS; G.n_owned_rows = ghost_from;
       if (pend_rec) { G.pub_rec = pend_rec; G.pub_seq = pend_seq; G.pub_pair = pend_pair; G.pub_eps = pend_eps; G.sc_rw = sc; pend_rec = nullptr; }
+      if (pend_xr.part) { G.pend = pend_xr; G.sc_rw = sc; pend_xr = PendSum(); }
       yy = K->y.p;
       if (fmul) {
         SpmvDot d1{1, K->c.p, S_CV, rows_dot, true};
@@ -456,6 +481,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       IluGather G;
       G.mode = 1; G.r = K->r.p; G.q = vv; G.out = K->s.p; G.sc = sc; G.done = done;
       G.rho_slot = rs; G.cv_slot = S_CV; G.n_owned_rows = ghost_from;
+      if (pend_spmv.part) { G.pend = pend_spmv; G.sc_rw = sc; pend_spmv = PendSum(); }  // <c, A y> of the product just enqueued
       zz = K->z.p;
       if (fmul) {
         SpmvDot d2{2, K->s.p, S_TS, rows_dot, true};
@@ -489,18 +515,31 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     const double seq = (double)(++ctx->pub_seq);
     seq_of[k & 1] = seq;
     double *rec = ctx->h_pub + (k & 1) * JH_PUB_LEN;
+    // (rho_next, ||r||^2) -> the other pair
+    if (pend_ok) {
+      // 512-thread workgroups, at most 512 of them: the partials are summed by the kernel that needs rho_next -- the next
+      // iteration's first apply, which also publishes this iteration's record -- or, behind the last enqueued iteration, by a
+      // one-wavefront kernel that forms the same sums in the same order
+      const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>(((n >> 1) + 511) / 512, 512)));
+      double *xpart = ctx->partials.p + 2 * ctx->partial_stride;  // (the product's partials are still being read by this launch)
+      hipLaunchKernelGGL(bicg_xr_dots_kernel<512>, g, dim3(512), 0, st, xin, xout, K->r.p, yy, zz, K->s.p, tt, K->c.p, sc, rs, n, nd,
+                         xpart, ctx->partial_stride, done, pend_spmv);
+      pend_spmv = PendSum();
+      PendSum px;
+      px.part = xpart; px.stride = (unsigned)ctx->partial_stride; px.nparts = (int)g.x; px.count = 2; px.out_slot = rn;
+      if (lag == 1 && k < itmax) { pend_xr = px; pend_rec = rec; pend_seq = seq; pend_pair = rn; pend_eps = eps_at(k); }
+      else hipLaunchKernelGGL(bicg_pend_publish_kernel, dim3(1), dim3(64), 0, st, px, sc, done, eps_at(k), rec, seq);
+      return;
+    }
     dim3 g = vgrid(n);
-    // (rho_next, ||r||^2) -> the other pair; without a communicator the kernel also publishes the record
-    TailArgs ta;
-    const bool tail = tail_pays && tail_args(ctx, 2, sc + rn, true, &ta);  // one rank, or mailboxes on: second stage, all-reduce and publish in the kernel itself
-    hipLaunchKernelGGL(bicg_xr_dots_kernel, g, dim3(256), 0, st, xin, xout, K->r.p, yy, zz, K->s.p, tt, K->c.p, sc, rs, n, nd,
-                       ctx->partials.p, ctx->partial_stride, done, tail ? ta : TailArgs(), rn, eps_at(k), tail ? rec : (double *)nullptr, seq);
+    hipLaunchKernelGGL(bicg_xr_dots_kernel<256>, g, dim3(256), 0, st, xin, xout, K->r.p, yy, zz, K->s.p, tt, K->c.p, sc, rs, n, nd,
+                       ctx->partials.p, ctx->partial_stride, done, PendSum());
     MailArgs ma;
-    const bool fused_ar = !tail && comm_mail_args(ctx, 2, &ma);  // mailboxes on: all-reduce + publish in the reduction launch itself
-    if (!tail)
-      hipLaunchKernelGGL(bicg_reduce_publish_kernel, dim3(1), dim3(FIN_THREADS), 0, st, ctx->partials.p, ctx->partial_stride, (int)g.x,
-                         sc, rn, done, eps_at(k), (ctx->comm && !fused_ar) ? nullptr : rec, seq, fused_ar ? ma : MailArgs());
-    if (!tail && ctx->comm && !fused_ar) {
+    const bool fused_ar = comm_mail_args(ctx, 2, &ma);  // mailboxes on: all-reduce + publish in the reduction launch itself
+    // without a communicator the reduction launch also publishes the record
+    hipLaunchKernelGGL(bicg_reduce_publish_kernel, dim3(1), dim3(FIN_THREADS), 0, st, ctx->partials.p, ctx->partial_stride, (int)g.x,
+                       sc, rn, done, eps_at(k), (ctx->comm && !fused_ar) ? nullptr : rec, seq, fused_ar ? ma : MailArgs());
+    if (ctx->comm && !fused_ar) {
       comm_allreduce_dev(ctx, sc + rn, 2, 0);
       // the record needs the all-reduced pair: it is published by the first kernel of the next iteration (fused ILU gather)
       // when there is one, otherwise by a one-thread kernel

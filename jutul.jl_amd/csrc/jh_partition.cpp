@@ -202,7 +202,7 @@ struct Bisector {
     // iterations per step at 2.5M / 5M / 10M / 20M cells: 23.7 / 24.25 / 24.03 / 24.1 without, 22.05 / 25.0 / 22.2 / 24.12 with
     // a limit of 40 000 cells, 24.0 / 24.0 / 23.5 / 23.25 with 300 000, 24.0 / 23.6 / 22.7 / 24.0 for all jobs (the count of a
     // single solve is an integer that moves by one for any change: averages 24.0, 23.3, 23.7, 23.6).
-    static const int64_t two_ended_max = getenv("JH_PART_TWO_MAX") ? atoll(getenv("JH_PART_TWO_MAX")) : 40000;
+    constexpr int64_t two_ended_max = 40000;
     if (n <= two_ended_max) {
       // Order the cells by (distance from one end) - (distance from the other end) and cut at the share: the cut is the
       // bisector between the two ends -- flat -- instead of a sphere around one of them.

@@ -15,7 +15,9 @@
 // entries of slice i+1 are in flight while slice i gathers x and accumulates.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <numeric>
+#include <unordered_map>
 
 #include "jh_internal.hpp"
 
@@ -84,8 +86,8 @@ void Pattern::build_jagged() {
   jag.d_perm.upload(perm, st);
   // 16-bit codes pay where the product streams from HBM for long (10M rows: 0.177 instead of 0.181-0.188 ms); on a small matrix
   // the extra pipeline stage costs more than the bytes save (1.25M rows: 28.5 instead of 27.1 us)
-  const char *force = getenv("JH_SPMV_COL");  // "16" / "32": development / test switch (read when the layout is built)
-  const bool col16 = force ? atoi(force) == 16 : n >= 3000000;
+  const int64_t force = ctx->opt.spmv_col_bits;  // 16 / 32: test switch (read when the layout is built)
+  const bool col16 = force ? force == 16 : n >= 3000000;
   if (col16) {
     far.resize(far.size() + (0x10000 - JDS_FAR), 0);  // any code of any slice decodes to a valid position
     jag.d_col16.upload(jc16, st);
@@ -129,25 +131,47 @@ __device__ __forceinline__ int jcount(const uint4 &c) {
 // trip cost more than the vector L1 serving the gathers); with every column served from LDS it would be 145 us, i.e. the
 // 18% far columns cost ~15 us.  The four wavefronts of a workgroup take four consecutive slices and meet at one barrier per
 // step: kept in step they share the vector-L1 lines of their neighbouring rows' x entries (free-running wavefronts: 165 us).
-template <int KU, int DOT>
-__global__ __launch_bounds__(256) void spmv_jds_kernel(const int32_t *__restrict__ base, const uint4 *__restrict__ cnt16,
+// NW: wavefronts per workgroup = slices per step.  One dot partial per workgroup: 16 wavefronts keep the partials of a full-chip
+// launch within PEND_MAX, so that the kernel that consumes the dot can sum them itself (PendSum) instead of a reduction launch.
+template <int NW>
+__device__ __forceinline__ void jds_dot_partial(double d0, double d1, int dotv, double *red, double *part, size_t pstride) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); if (dotv == 2) d1 += __shfl_down(d1, off, 64); }
+  if (lane == 0) { red[w] = d0; red[NW + w] = d1; }
+  __syncthreads();
+  if (tid == 0) {  // fixed order: pairs of neighbours, then pairs of pairs, ...
+    double a[NW], b[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { a[i] = red[i]; b[i] = red[NW + i]; }
+#pragma unroll
+    for (int m = NW; m > 1; m >>= 1) {
+#pragma unroll
+      for (int i = 0; i < m / 2; ++i) { a[i] = a[2 * i] + a[2 * i + 1]; b[i] = b[2 * i] + b[2 * i + 1]; }
+    }
+    part[blockIdx.x] = a[0];
+    if (dotv == 2) part[pstride + blockIdx.x] = b[0];
+  }
+}
+template <int KU, int DOT, int NW>
+__global__ __launch_bounds__(64 * NW) void spmv_jds_kernel(const int32_t *__restrict__ base, const uint4 *__restrict__ cnt16,
                                                        const uint8_t *__restrict__ perm, const int32_t *__restrict__ jcol,
                                                        const double *__restrict__ jval, int nslices, int nrows,
                                                        const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
                                                        const double *__restrict__ dw, int dot_rows, double *__restrict__ part,
-                                                       size_t pstride, const double *done, TailArgs tail) {
+                                                       size_t pstride, const double *done) {
   if (done && *done != 0.0) return;
-  __shared__ double tr[4][64];
-  __shared__ double red[8];
+  __shared__ double tr[NW][64];
+  __shared__ double red[2 * NW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // workgroup b runs on XCD b % 8 (observed placement, performance only): each XCD sweeps one contiguous eighth of the slices
-  const int nsup = (nslices + 3) / 4;  // steps: four slices = 256 rows each
+  const int nsup = (nslices + NW - 1) / NW;  // steps: NW slices = 64 NW rows each
   const int chunk = (nsup + NUM_XCD - 1) / NUM_XCD;
   const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, wgs = gridDim.x / NUM_XCD;
-  const int stride = wgs * 4;
-  const int s_end = min(nslices, 4 * min(nsup, (xcd + 1) * chunk));
-  const int s_loop_end = 4 * min(nsup, (xcd + 1) * chunk);  // uniform over the workgroup (the barrier below)
+  const int stride = wgs * NW;
+  const int s_end = min(nslices, NW * min(nsup, (xcd + 1) * chunk));
+  const int s_loop_end = NW * min(nsup, (xcd + 1) * chunk);  // uniform over the workgroup (the barrier below)
   double d0 = 0.0, d1 = 0.0;
   auto ldesc = [&](int s, JDesc &D) {
     if (s < s_end) { D.base = base[s]; D.c = cnt16[s]; }
@@ -165,7 +189,7 @@ __global__ __launch_bounds__(256) void spmv_jds_kernel(const int32_t *__restrict
 #undef JH_LENT
     E.prow = (int)perm[(size_t)min(s, nslices - 1) * 64 + lane];
   };
-  int s = 4 * (xcd * chunk + wg) + w;
+  int s = NW * (xcd * chunk + wg) + w;
   JDesc dc, dn, dnn;
   JEnt<KU> ec, en;
   ldesc(s, dc);
@@ -174,7 +198,7 @@ __global__ __launch_bounds__(256) void spmv_jds_kernel(const int32_t *__restrict
   for (; s - w < s_loop_end; s += stride) {
     ldesc(s + 2 * stride, dnn);
     lent(s + stride, dn, en);
-    __syncthreads();  // keeps the four wavefronts on neighbouring slices
+    __syncthreads();  // keeps the wavefronts of the workgroup on neighbouring slices
     double xg[KU];
     // (unconditional as well: an unused lane holds some other entry's column id, a valid index)
 #define JH_GATH(J) if (J < KU) xg[J < KU ? J : 0] = x[ec.col[J < KU ? J : 0]];
@@ -202,21 +226,7 @@ __global__ __launch_bounds__(256) void spmv_jds_kernel(const int32_t *__restrict
     dc = dn; dn = dnn;
     ec = en;
   }
-  if (DOT) {  // one partial per workgroup, reduced in a fixed order
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); if (DOT == 2) d1 += __shfl_down(d1, off, 64); }
-    if (lane == 0) { red[w] = d0; red[4 + w] = d1; }
-    __syncthreads();
-    if (tid == 0) {
-      const double p0 = (red[0] + red[1]) + (red[2] + red[3]), p1 = (red[4] + red[5]) + (red[6] + red[7]);
-      if (tail.tick) { tail_store(part + blockIdx.x, p0); if (DOT == 2) tail_store(part + pstride + blockIdx.x, p1); }
-      else { part[blockIdx.x] = p0; if (DOT == 2) part[pstride + blockIdx.x] = p1; }
-    }
-    if (tail.tick && tail_arrive(tail.tick, gridDim.x)) {  // second stage here: no one-workgroup kernel behind every product
-      tail_reduce<false, 256>(part, pstride, (int)gridDim.x, DOT == 2 ? 2 : 1, tail.out);
-      if (tail.mail.self) mailbox_allreduce_body(tail.mail, tail.out, DOT == 2 ? 2 : 1, 0);
-    }
-  }
+  if (DOT) jds_dot_partial<NW>(d0, d1, DOT, red, part, pstride);  // one partial per workgroup, reduced in a fixed order
 }
 
 // The same product with 16-bit column codes (Pattern::Jagged::d_col16): 10 instead of 12 bytes per entry.  One more pipeline
@@ -233,25 +243,25 @@ struct JDesc16 {
   int base, cb, fo;
   uint4 c;
 };
-template <int KU, int DOT>
-__global__ __launch_bounds__(256) void spmv_jds16_kernel(const int32_t *__restrict__ base, const uint4 *__restrict__ cnt16,
+template <int KU, int DOT, int NW>
+__global__ __launch_bounds__(64 * NW) void spmv_jds16_kernel(const int32_t *__restrict__ base, const uint4 *__restrict__ cnt16,
                                                          const uint8_t *__restrict__ perm, const uint16_t *__restrict__ jcol,
                                                          const int2 *__restrict__ win, const int32_t *__restrict__ far,
                                                          const double *__restrict__ jval, int nslices, int nrows,
                                                          const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
                                                          const double *__restrict__ dw, int dot_rows, double *__restrict__ part,
-                                                         size_t pstride, const double *done, TailArgs tail) {
+                                                         size_t pstride, const double *done) {
   if (done && *done != 0.0) return;
-  __shared__ double tr[4][64];
-  __shared__ double red[8];
+  __shared__ double tr[NW][64];
+  __shared__ double red[2 * NW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nsup = (nslices + 3) / 4;
+  const int nsup = (nslices + NW - 1) / NW;
   const int chunk = (nsup + NUM_XCD - 1) / NUM_XCD;
   const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, wgs = gridDim.x / NUM_XCD;
-  const int stride = wgs * 4;
-  const int s_end = min(nslices, 4 * min(nsup, (xcd + 1) * chunk));
-  const int s_loop_end = 4 * min(nsup, (xcd + 1) * chunk);  // uniform over the workgroup (the barrier below)
+  const int stride = wgs * NW;
+  const int s_end = min(nslices, NW * min(nsup, (xcd + 1) * chunk));
+  const int s_loop_end = NW * min(nsup, (xcd + 1) * chunk);  // uniform over the workgroup (the barrier below)
   double d0 = 0.0, d1 = 0.0;
   auto ldesc = [&](int s, JDesc16 &D) {
     if (s < s_end) { D.base = base[s]; D.c = cnt16[s]; const int2 wf = win[s]; D.cb = wf.x; D.fo = wf.y; }
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(256) void spmv_jds16_kernel(const int32_t *__restri
     }
     E.prow = R.prow;
   };
-  int s = 4 * (xcd * chunk + wg) + w;
+  int s = NW * (xcd * chunk + wg) + w;
   JDesc16 dc, dn, dnn, dnnn;
   JRaw<KU> rn, rnn;
   JEnt<KU> ec, en;
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(256) void spmv_jds16_kernel(const int32_t *__restri
     ldesc(s + 3 * stride, dnnn);
     lraw(s + 2 * stride, dnn, rnn);
     decode(dn, rn, en);  // (its far-list loads complete during this slice's gathers)
-    __syncthreads();  // keeps the four wavefronts on neighbouring slices
+    __syncthreads();  // keeps the wavefronts of the workgroup on neighbouring slices
     double xg[KU];
 #define JH_GATH(J) if (J < KU) xg[J < KU ? J : 0] = x[ec.col[J < KU ? J : 0]];
     JH_GATH(0) JH_GATH(1) JH_GATH(2) JH_GATH(3) JH_GATH(4) JH_GATH(5) JH_GATH(6) JH_GATH(7)
@@ -320,30 +330,15 @@ __global__ __launch_bounds__(256) void spmv_jds16_kernel(const int32_t *__restri
     ec = en;
     rn = rnn;
   }
-  if (DOT) {  // one partial per workgroup, reduced in a fixed order
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { d0 += __shfl_down(d0, off, 64); if (DOT == 2) d1 += __shfl_down(d1, off, 64); }
-    if (lane == 0) { red[w] = d0; red[4 + w] = d1; }
-    __syncthreads();
-    if (tid == 0) {
-      const double p0 = (red[0] + red[1]) + (red[2] + red[3]), p1 = (red[4] + red[5]) + (red[6] + red[7]);
-      if (tail.tick) { tail_store(part + blockIdx.x, p0); if (DOT == 2) tail_store(part + pstride + blockIdx.x, p1); }
-      else { part[blockIdx.x] = p0; if (DOT == 2) part[pstride + blockIdx.x] = p1; }
-    }
-    if (tail.tick && tail_arrive(tail.tick, gridDim.x)) {  // second stage here: no one-workgroup kernel behind every product
-      tail_reduce<false, 256>(part, pstride, (int)gridDim.x, DOT == 2 ? 2 : 1, tail.out);
-      if (tail.mail.self) mailbox_allreduce_body(tail.mail, tail.out, DOT == 2 ? 2 : 1, 0);
-    }
-  }
+  if (DOT) jds_dot_partial<NW>(d0, d1, DOT, red, part, pstride);  // one partial per workgroup, reduced in a fixed order
 }
 
 }  // namespace
 
 // Copies the current values of A into the jagged-slice order; true if the Krylov loop can multiply with k_spmv_sell.
 bool sell_refresh(jh_csr A) {
-  static const bool off = getenv("JH_SPMV_NO_JAGGED") != nullptr;
   A->jval_fresh = false;
-  if (off) return false;
+  if (!A->ctx->opt.spmv_jagged) return false;
   Pattern &P = *A->pat;
   if (!P.jag.built) P.build_jagged();
   if (!P.jag.usable) return false;
@@ -354,45 +349,64 @@ bool sell_refresh(jh_csr A) {
   return true;
 }
 
-// reduce_now = false: the caller launches the second stage of the fused dot itself (spmv_dot_reduce with the returned count)
+// Resident workgroups per CU of a kernel (occupancy query, cached per kernel): the persistent grids are sized by it, so that no
+// workgroup of a launch has to wait for another one to finish (with 68-70 VGPRs the 16-bit kernels hold 7, not 8, wavefronts per SIMD).
+template <class KernelT>
+static int resident_per_cu(KernelT kernel, int threads) {
+  static std::mutex m;
+  static std::unordered_map<const void *, int> cache;
+  std::lock_guard<std::mutex> lk(m);
+  auto it = cache.find((const void *)kernel);
+  if (it != cache.end()) return it->second;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+  cache[(const void *)kernel] = nb;
+  return nb;
+}
+
+// reduce_now = false: the caller launches the second stage of the fused dot itself (spmv_dot_reduce with the returned count) or
+// hands the partials to the consuming kernel (PendSum).  waves: wavefronts per workgroup, 4 / 8 / 16 (see spmv_jds_kernel).
 int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done, bool reduce_now,
-                const TailArgs *tail) {
+                int waves) {
   jh_context ctx = A->ctx;
   const Pattern &P = *A->pat;
   const auto &J = P.jag;
   if (!A->jval_fresh) JH_THROW("jagged-slice SpMV without fresh values (sell_refresh)");
+  if (waves != 4 && waves != 8 && waves != 16) JH_THROW("jagged-slice SpMV: 4, 8 or 16 wavefronts per workgroup");
   const int mode = dot ? dot->mode : 0;
-  static const int wg_per_xcd = getenv("JH_SPMV_WGS") ? atoi(getenv("JH_SPMV_WGS")) : 256;  // 32 CUs x 8 workgroups
-  const int nsup = (J.nslices + 3) / 4;
+  const int nsup = (J.nslices + waves - 1) / waves;
   const int chunk = (nsup + NUM_XCD - 1) / NUM_XCD;
-  const int per_xcd = std::max(1, std::min(chunk, wg_per_xcd));
-  dim3 grid(per_xcd * NUM_XCD), block(256);
-  if (mode) ensure_partials(ctx, (size_t)grid.x);
   const double *dw = dot ? dot->w : nullptr;
   const int drows = dot ? (int)dot->n_rows : 0;
-  const TailArgs ta = (mode && tail) ? *tail : TailArgs();
-#define JH_JDS(KU, DV)                                                                                                          \
-  hipLaunchKernelGGL((spmv_jds_kernel<KU, DV>), grid, block, 0, ctx->stream, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), \
-                     J.d_perm.p, J.d_col.p, A->jval.p, J.nslices, (int)P.n, x, y, alpha, beta, dw, drows, ctx->partials.p, ctx->partial_stride, done, ta)
-#define JH_JDS16(KU, DV)                                                                                                        \
-  hipLaunchKernelGGL((spmv_jds16_kernel<KU, DV>), grid, block, 0, ctx->stream, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), \
-                     J.d_perm.p, J.d_col16.p, reinterpret_cast<const int2 *>(J.d_win.p), J.d_far.p, A->jval.p, J.nslices, (int)P.n, x, y, \
-                     alpha, beta, dw, drows, ctx->partials.p, ctx->partial_stride, done, ta)
+  dim3 block(64 * waves);
+  int nparts = 0;
+  auto launch = [&](auto kernel, auto... args) {
+    // persistent grid: what is resident at once (32 CUs per XCD), or option spmv_waves_per_xcd
+    const int cap = ctx->opt.spmv_waves_per_xcd > 0 ? std::max<int>(1, (int)ctx->opt.spmv_waves_per_xcd / waves)
+                                                    : 32 * resident_per_cu(kernel, 64 * waves);
+    dim3 grid((unsigned)(std::max(1, std::min(chunk, cap)) * NUM_XCD));
+    if (mode) ensure_partials(ctx, (size_t)grid.x);
+    hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, args..., A->jval.p, J.nslices, (int)P.n, x, y, alpha, beta, dw, drows,
+                       ctx->partials.p, ctx->partial_stride, done);
+    nparts = (int)grid.x;
+  };
+#define JH_JDS(KU, DV, NWV) launch(spmv_jds_kernel<KU, DV, NWV>, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), J.d_perm.p, J.d_col.p)
+#define JH_JDS16(KU, DV, NWV)                                                                                               \
+  launch(spmv_jds16_kernel<KU, DV, NWV>, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), J.d_perm.p, J.d_col16.p, \
+         reinterpret_cast<const int2 *>(J.d_win.p), J.d_far.p)
+#define JH_JDS_M(K, KU, NWV) do { if (mode == 0) K(KU, 0, NWV); else if (mode == 1) K(KU, 1, NWV); else K(KU, 2, NWV); } while (0)
+#define JH_JDS_W(K, KU) do { if (waves == 4) JH_JDS_M(K, KU, 4); else if (waves == 8) JH_JDS_M(K, KU, 8); else JH_JDS_M(K, KU, 16); } while (0)
   if (J.d_col.n == 0) {  // 16-bit column codes (default)
-    if (J.kmax <= 5) {
-      if (mode == 0) JH_JDS16(5, 0); else if (mode == 1) JH_JDS16(5, 1); else JH_JDS16(5, 2);
-    } else {
-      if (mode == 0) JH_JDS16(8, 0); else if (mode == 1) JH_JDS16(8, 1); else JH_JDS16(8, 2);
-    }
-  } else if (J.kmax <= 5) {
-    if (mode == 0) JH_JDS(5, 0); else if (mode == 1) JH_JDS(5, 1); else JH_JDS(5, 2);
+    if (J.kmax <= 5) JH_JDS_W(JH_JDS16, 5); else JH_JDS_W(JH_JDS16, 8);
   } else {
-    if (mode == 0) JH_JDS(8, 0); else if (mode == 1) JH_JDS(8, 1); else JH_JDS(8, 2);
+    if (J.kmax <= 5) JH_JDS_W(JH_JDS, 5); else JH_JDS_W(JH_JDS, 8);
   }
+#undef JH_JDS_W
+#undef JH_JDS_M
 #undef JH_JDS
 #undef JH_JDS16
-  if (mode && reduce_now && !ta.tick) spmv_dot_reduce(ctx, dot, (int)grid.x, done);
-  return (int)grid.x;
+  if (mode && reduce_now) spmv_dot_reduce(ctx, dot, nparts, done);
+  return nparts;
 }
 
 }  // namespace jh

@@ -160,7 +160,8 @@ static void centre_bfs_order(const Adj &A, const std::vector<int32_t> &lab, int3
 namespace {
 // JH_SETUP_TIMING=1: seconds per set-up phase on stderr
 struct PhaseTimer {
-  bool on = getenv("JH_SETUP_TIMING") != nullptr;
+  bool on = false;
+  explicit PhaseTimer(bool enabled) : on(enabled) {}
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
   void lap(const char *what) {
     if (!on) return;
@@ -176,13 +177,13 @@ struct PhaseTimer {
 // half-faces at 512 cells per block on the tet lattice = 24.0 instead of 26.6 BiCGStab iterations at 2M cells, and a
 // dependency depth of the radius, not the diameter.  Block ids follow the bisection tree (neighbouring blocks are close in
 // memory); inside a block the cells are ordered breadth-first from a centre.
-static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, std::vector<int32_t> &perm, std::vector<int32_t> &block_ptr) {
+static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, std::vector<int32_t> &perm, std::vector<int32_t> &block_ptr, bool timing) {
   const int64_t nparts = std::max<int64_t>(1, (nc + block_rows / 2) / block_rows);
   const int64_t max_part = std::max<int64_t>(block_rows + block_rows / 8, (nc + nparts - 1) / nparts);
   std::vector<int32_t> label;
   resize_parallel(label, A.ptr.size() - 1);
   parallel_ranges((int64_t)label.size(), 1 << 18, [&](int64_t b, int64_t e) { std::fill(label.begin() + b, label.begin() + e, -1); });
-  PhaseTimer pt;
+  PhaseTimer pt(timing);
   {
     // The input numbering may be arbitrary (the bench grid's is scrambled): every sweep of the partitioner would miss the
     // cache on every cell.  One breadth-first renumbering first (neighbours end up close in memory), the bisections run on the
@@ -259,34 +260,24 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
 }
 
 static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block_rows, std::vector<int32_t> &perm,
-                         std::vector<int32_t> &block_ptr, int64_t &interior_rows, int32_t &interior_blocks) {
+                         std::vector<int32_t> &block_ptr, int64_t &interior_rows, int32_t &interior_blocks, bool onion, bool timing) {
   // cells >= nc (ghosts of a rank-local subdomain) are never absorbed; they form the last block
   perm.clear();
   perm.reserve(nc_all);
   block_ptr.assign(1, 0);
-  // JH_BLOCK_ORDER (development switch): unset / "bisect" = blocks by graph bisection (the default, above); "onion", "layers",
-  // "bfs", "center" = round 1's blocks grown along the rim of the assigned region, with the in-block order named below
-  static const bool onion = [] { const char *e = getenv("JH_BLOCK_ORDER"); return e && std::string(e) != "bisect"; }();
-  if (!onion) blocks_by_bisection(A, nc, block_rows, perm, block_ptr);
+  // onion (option block_order = 1): round 1's blocks grown along the rim of the assigned region; default: graph bisection (above)
+  if (!onion) blocks_by_bisection(A, nc, block_rows, perm, block_ptr, timing);
   std::vector<int32_t> blk(nc_all, -1);
   for (int64_t c = nc; c < nc_all; ++c) blk[c] = INT32_MAX;
   std::vector<int32_t> cand;  // frontier candidates for the next seed (FIFO)
   size_t cand_head = 0;
   std::vector<int32_t> q;
   q.reserve(block_rows);
-  // Order inside an onion block: "bfs" = growth order; "layers" / "onion" = by BFS layer from the seed and, inside a
-  // layer, by a greedy colouring of the layer's own adjacencies.  ILU(0) depends on the ordering only through the orientation
-  // of the edges (which endpoint is eliminated first); growth order chains the cells of a layer one after the other (a
-  // 512-cell block has ~65 dependency levels), colouring the layer keeps every cross-layer orientation and leaves
-  // (layers x colours) ~ 25 levels for the level-scheduled triangular solves.
-  static const int order_mode = [] {
-    const char *e = getenv("JH_BLOCK_ORDER");
-    if (e && std::string(e) == "bfs") return 0;
-    if (e && std::string(e) == "center") return 2;  // experiment: layers counted from the block's centre, not from its seed
-    return 1;
-  }();
-  std::vector<int32_t> bq;  // scratch queue of the in-block searches
-  std::vector<int32_t> depth(order_mode ? nc_all : 0, 0), colour(order_mode ? nc_all : 0, -1), qpos(order_mode ? nc_all : 0, 0);
+  // Order inside an onion block: by BFS layer from the seed and, inside a layer, by a greedy colouring of the layer's own
+  // adjacencies.  ILU(0) depends on the ordering only through the orientation of the edges (which endpoint is eliminated first);
+  // growth order would chain the cells of a layer one after the other (a 512-cell block has ~65 dependency levels), colouring the
+  // layer keeps every cross-layer orientation and leaves (layers x colours) ~ 25 levels for the level-scheduled triangular solves.
+  std::vector<int32_t> depth(onion ? nc_all : 0, 0), colour(onion ? nc_all : 0, -1), qpos(onion ? nc_all : 0, 0);
   std::vector<int32_t> qsorted;
   int64_t next_unassigned = 0;
   int32_t b = 0;
@@ -304,47 +295,16 @@ static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block
     q.clear();
     q.push_back(seed);
     blk[seed] = b;
-    if (order_mode) depth[seed] = 0;
+    depth[seed] = 0;
     size_t head = 0;
     while (head < q.size() && (int64_t)q.size() < block_rows) {
       int32_t c = q[head++];
       for (int64_t k = A.ptr[c]; k < A.ptr[c + 1] && (int64_t)q.size() < block_rows; ++k) {
         int32_t o = A.nbr[k];
-        if (blk[o] < 0) { blk[o] = b; q.push_back(o); if (order_mode) depth[o] = depth[c] + 1; }
+        if (blk[o] < 0) { blk[o] = b; q.push_back(o); depth[o] = depth[c] + 1; }
       }
     }
-    if (order_mode == 2 && q.size() > 2) {
-      // the block was grown from a cell on its rim: its dependency depth is its diameter.  Re-root the layers at a centre (the
-      // middle of a longest shortest path found by two sweeps): the depth becomes the radius.
-      auto sweep = [&](int32_t start) {  // breadth-first search inside the block; depth[] from start, returns the last cell reached
-        bq.clear();
-        bq.push_back(start);
-        for (int32_t c : q) colour[c] = -2;  // visited marker (colour is recomputed below)
-        colour[start] = -1;
-        depth[start] = 0;
-        for (size_t h = 0; h < bq.size(); ++h) {
-          const int32_t c = bq[h];
-          for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k) {
-            const int32_t o = A.nbr[k];
-            if (blk[o] == b && colour[o] == -2) { colour[o] = -1; depth[o] = depth[c] + 1; bq.push_back(o); }
-          }
-        }
-        return bq.back();
-      };
-      const int32_t u = sweep(q[0]);
-      const int32_t w = sweep(u);
-      // walk back from w towards u for half of the path length
-      int32_t m = w;
-      for (int32_t step = depth[w] / 2; step > 0; --step)
-        for (int64_t k = A.ptr[m]; k < A.ptr[m + 1]; ++k) {
-          const int32_t o = A.nbr[k];
-          if (blk[o] == b && depth[o] == depth[m] - 1) { m = o; break; }
-        }
-      sweep(m);
-      if (bq.size() == q.size()) q = bq;  // (a block that is not connected keeps its growth order and depths from the seed)
-      else { for (size_t i = 0; i < q.size(); ++i) depth[q[i]] = 0; sweep(q[0]); for (int32_t c : q) if (colour[c] == -2) depth[c] = 0; }
-    }
-    if (order_mode) {
+    {
       for (size_t i = 0; i < q.size(); ++i) { qpos[q[i]] = (int32_t)i; colour[q[i]] = -1; }
       for (int32_t c : q) {  // greedy colouring inside the BFS layer, in growth order
         unsigned used = 0;
@@ -371,8 +331,7 @@ static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block
       cand.erase(cand.begin(), cand.begin() + cand_head);
       cand_head = 0;
     }
-    if (order_mode) perm.insert(perm.end(), qsorted.begin(), qsorted.end());
-    else perm.insert(perm.end(), q.begin(), q.end());
+    perm.insert(perm.end(), qsorted.begin(), qsorted.end());
     block_ptr.push_back((int32_t)perm.size());
     ++b;
   }
@@ -478,7 +437,7 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
     d->nf = nf;
     d->nhf = 2 * nf;
     d->N = block_n;
-    PhaseTimer pt;
+    PhaseTimer pt(ctx->opt.setup_timing != 0);
     resize_parallel(d->Nhost, (size_t)(2 * nf));
     parallel_ranges(2 * nf, 1 << 18, [&](int64_t b, int64_t e) { std::copy(N + b, N + e, d->Nhost.begin() + b); });
     Adj A = build_adjacency(nc, nf, N);
@@ -504,7 +463,8 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
         // 192 rows the factorisation program of a block exceeds 64 KB of LDS: 3.1 -> 4.5 ms)
         if (deg > 7.0) block_rows = std::max<int64_t>(64, (int64_t)(block_rows * 5.0 / deg) / 32 * 32);
       }
-      order_blocks(A, nc, n_owned, block_rows, pat->perm, pat->block_ptr, pat->interior_rows, pat->interior_blocks);
+      order_blocks(A, nc, n_owned, block_rows, pat->perm, pat->block_ptr, pat->interior_rows, pat->interior_blocks,
+                   ctx->opt.block_order == 1, ctx->opt.setup_timing != 0);
     } else if (reorder != JH_REORDER_NONE) {
       JH_THROW("unknown reorder mode");
     }

@@ -15,7 +15,8 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 import jutul_amd as ja
 
-ctx = ja.HIPContext(0)  # every process on the same device
+tmo = float(os.environ.get("JH_TEST_COMM_TIMEOUT_S", "600"))
+ctx = ja.HIPContext(0, comm_timeout_ms=int(tmo * 1000))  # every process on the same device; the option bounds the in-kernel waits
 ctx.comm_init_ipc_only(world, rank)
 handles = [None] * world
 dist.all_gather_object(handles, ctx.comm_ipc_export())
@@ -43,10 +44,9 @@ assert all(r == res[0] for r in res)
 dist.barrier()
 if os.environ.get("JH_TEST_TIMEOUT") == "1":
     # the last rank never enters the next reduction: every other rank must get an error naming it instead of hanging
-    # (JH_COMM_TIMEOUT_S bounds the in-kernel wait)
     import time
     if rank == world - 1:
-        time.sleep(float(os.environ["JH_COMM_TIMEOUT_S"]) + 3.0)
+        time.sleep(tmo + 3.0)
     else:
         t0 = time.time()
         try:
@@ -55,7 +55,7 @@ if os.environ.get("JH_TEST_TIMEOUT") == "1":
         except ja.JutulHIPError as e:
             msg = str(e)
             assert "timed out" in msg and f"waiting for rank {world - 1}" in msg and f"rank {rank} of {world}" in msg, msg
-        assert time.time() - t0 < float(os.environ["JH_COMM_TIMEOUT_S"]) + 2.5
+        assert time.time() - t0 < tmo + 2.5
         assert ctx.comm_info()["timeouts"] >= 1
     dist.barrier()
     if rank == 0:

@@ -209,10 +209,10 @@ def test_interior_boundary_split_of_a_subdomain(ja):
 
 
 def test_overlapped_halo_exchange_path():
-    """The opt-in overlapped ghost exchange (JH_HALO_OVERLAP=1: second stream, split interior/boundary SpMV) must give the
+    """The opt-in overlapped ghost exchange (option halo_overlap = 1: second stream, split interior/boundary SpMV) must give the
     same distributed Newton results; the switch is read once per process, hence the subprocess."""
     import os, subprocess, sys
-    env = dict(os.environ, JH_HALO_OVERLAP="1")
+    env = dict(os.environ, JH_OPTIONS="halo_overlap=1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_distributed.py"), "-q", "-x", "-m", "gpu",
                         "-k", "test_distributed_newton_matches_single_rank or test_eight_ranks_many_neighbours"],

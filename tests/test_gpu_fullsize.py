@@ -189,9 +189,10 @@ def test_3M_cells_oracle_parity_where_the_defaults_switch(ja, oracle):
     import os
     import scipy.sparse as sp
     from bench import dims_for_cells
-    assert "JH_SPMV_COL" not in os.environ and "JH_SPMV_NO_JAGGED" not in os.environ
+    assert "JH_OPTIONS" not in os.environ
     eps = np.finfo(np.float64).eps
     ctx = ja.HIPContext(0)
+    assert ctx.get_option("spmv_col_bits") == 0 and ctx.get_option("spmv_jagged") == 1
     g = ja.tet_lattice_mesh(*dims_for_cells(3_200_000))
     nc, nf, N = g["nc"], g["nf"], g["N"]
     assert nc >= 3_000_000
@@ -268,15 +269,18 @@ def test_3M_cells_oracle_parity_where_the_defaults_switch(ja, oracle):
     assert (fi["l_entries"], fi["u_entries"]) == kept, (fi, kept)
 
 
-def test_3M_cells_in_kernel_reduction_stage_is_deterministic_and_matches_the_separate_launch(ja):
-    """Opt-in JH_TAIL_REDUCE=1: the second stage of the fused dot products runs inside the producing kernel (the last workgroup
-    to arrive reads the partials other XCDs wrote, TailArgs).  A stale partial would show as a run-to-run difference: four long
-    BiCGStab solves of the same system must give bit-identical residual histories, and they must follow the history of the
-    separate-launch path (default; a different but fixed summation tree) to rounding."""
-    import os
+@pytest.mark.parametrize("cells", [3_200_000, 400_000])
+def test_consumer_side_reduction_stage_is_deterministic_and_matches_the_separate_launch(ja, cells):
+    """Default (option consumer_reduce = 1): the second stage of the fused dot products of BiCGStab runs inside the kernel that
+    needs the scalar next -- every wavefront of the consumer sums the producer's partials itself, in one fixed order (PendSum,
+    csrc/jh_internal.hpp) -- instead of a one-workgroup launch.  Ordered sums, no atomics: four long solves of the same system
+    must give bit-identical residual histories and solutions, and they must follow the history of the separate-launch path
+    (consumer_reduce = 0; a different but fixed summation tree) to rounding.  3.2M cells: 16-bit column codes, 512-row blocks,
+    a chip-filling launch; 0.4M cells: 32-bit columns, 256-row blocks, fewer workgroups than the chip holds."""
     from bench import dims_for_cells
     ctx = ja.HIPContext(0)
-    g = ja.tet_lattice_mesh(*dims_for_cells(3_200_000))
+    assert ctx.get_option("consumer_reduce") == 1
+    g = ja.tet_lattice_mesh(*dims_for_cells(cells))
     nc = g["nc"]
     rng = np.random.default_rng(5)
     disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, reorder="blocks")
@@ -295,16 +299,25 @@ def test_3M_cells_in_kernel_reduction_stage_is_deterministic_and_matches_the_sep
     def solve():
         out = ja.linear_solve(lsys, ks, update_preconditioner=False)
         return out["iterations"], out["residuals"].copy(), lsys.dx.download()
-    assert "JH_TAIL_REDUCE" not in os.environ
-    it0, hist0, dx0 = solve()
-    assert it0 > 8
-    os.environ["JH_TAIL_REDUCE"] = "1"
-    try:
-        runs = [solve() for _ in range(4)]
-    finally:
-        os.environ.pop("JH_TAIL_REDUCE", None)
+    runs = [solve() for _ in range(4)]
+    assert runs[0][0] > 8
     for it, hist, dx in runs[1:]:
         assert it == runs[0][0] and np.array_equal(hist, runs[0][1]) and np.array_equal(dx, runs[0][2])
+    for waves in (4, 16):   # other workgroup shapes of the product (other partial counts): same solve to rounding
+        ctx.set_option("spmv_waves", waves)
+        it, hist, dx = solve()
+        assert abs(it - runs[0][0]) <= max(3, 0.15 * it)
+        assert np.allclose(hist[:12], runs[0][1][:12], rtol=1e-9)
+    ctx.set_option("spmv_waves", 0)
+    ctx.set_option("consumer_reduce", 0)
+    it0, hist0, dx0 = solve()
+    ctx.set_option("consumer_reduce", 1)
     k = 12
     assert np.allclose(runs[0][1][:k], hist0[:k], rtol=1e-9), (runs[0][1][:k], hist0[:k])
     assert abs(it0 - runs[0][0]) <= max(3, 0.15 * it0)
+    assert np.abs(dx0 - runs[0][2]).max() <= 1e-6 * np.abs(dx0).max()
+    # an iteration limit that ends the solve inside the loop: the last iteration's sums are formed by the one-wavefront kernel,
+    # in the same order as a consuming kernel forms them -> the same residual history up to there
+    ks2 = ja.GenericKrylov("bicgstab", preconditioner=prec, relative_tolerance=1e-30, max_iterations=7)
+    out = ja.linear_solve(lsys, ks2, update_preconditioner=False)
+    assert out["iterations"] == 7 and not out["ok"] and np.array_equal(out["residuals"][:8], runs[0][1][:8])

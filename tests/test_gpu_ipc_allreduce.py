@@ -25,7 +25,7 @@ def test_mailbox_timeout_names_the_missing_peer():
     """A rank that never arrives in a mailbox all-reduce: the others fail within the time limit with a jh_last_error message
     naming themselves, the missing peer and the epoch (no hang until the job's own time-out)."""
     world = 3
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JH_TEST_TIMEOUT="1", JH_COMM_TIMEOUT_S="2")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", JH_TEST_TIMEOUT="1", JH_TEST_COMM_TIMEOUT_S="2")
     env.pop("NCCL_DEBUG", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", "29657", os.path.join(ROOT, "tests", "ipc_allreduce_worker.py")]

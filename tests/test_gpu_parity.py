@@ -1,12 +1,27 @@
 """GPU parity tests: the HIP path (through the C ABI of libjutul_hip.so) against the CPU oracle on the same
 seeded inputs.  Integer tables bit-exact; floating point within the tolerances written in each test
 (fp64; reductions are re-associated on the GPU, hence relative 1e-12 .. 1e-10, not bit equality)."""
+import contextlib
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-12  # fp64 assembly / SpMV / ILU tolerance (relative to the largest entry of the compared array)
+
+
+@contextlib.contextmanager
+def options(ctx, **kv):
+    """Context options (jh_context_set_option) for the duration of a block; the context fixture is shared between tests."""
+    old = {k: ctx.get_option(k) for k in kv}
+    try:
+        for k, v in kv.items():
+            ctx.set_option(k, v)
+        yield
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v)
 
 
 def relerr(a, b):
@@ -234,11 +249,11 @@ def test_spmv_jagged_slice_layout_matches_csr_bitwise(ja, ctx, oracle, dims, reo
 
 
 @pytest.mark.parametrize("case", ["lattice", "far", "tiny"])
-def test_spmv_jagged_16bit_column_codes(ja, ctx, oracle, case, monkeypatch):
+def test_spmv_jagged_16bit_column_codes(ja, oracle, case):
     """Large matrices store the jagged-slice columns as 16-bit codes (window origin of the slice + code, or an index into the
     slice's list of far columns): the same bits as the CSR kernel, also with columns far outside every window, on the first
     slices (window origin negative), the last ragged slice, and a matrix smaller than one window."""
-    monkeypatch.setenv("JH_SPMV_COL", "16")   # (the default switches at 3M rows)
+    ctx = ja.HIPContext(0, spmv_col_bits=16)   # (the default switches at 3M rows; read when the layout is built)
     rng = np.random.default_rng(12)
     if case == "lattice":
         g = ja.tet_lattice_mesh(13, 11, 9)
@@ -376,17 +391,22 @@ def test_preconditioned_operator_fused_product(ja, ctx, oracle, kind):
     """jh_ilu0_apply_mul: x = M^-1 b and q = A x formed in one pass over the column-scaled pivot-only factors (the product
     inside the preconditioner apply of the right-preconditioned Krylov loop) == oracle spmv(ilu_apply(b)) at 1e-10, for scalar
     and 2x2-block matrices; the standalone apply on the same factors, the factor export and BiCGStab through the fused
-    operator agree with the unfused path (JH_NO_FUSED_PRODUCT) to rounding."""
-    import os
+    operator agree with the unfused path (option fused_product = 0 at solve time) to rounding."""
     import scipy.sparse as sp
     g, rng = tet_case(ja, (9, 8, 6), seed=12)
     lsys, law, disc, osys, nz_o, r_o = assemble_both(ja, ctx, oracle, g, rng, kind, "blocks")
     nc, bs = g["nc"], law.N
-    os.environ["JH_FUSED_PRODUCT"] = "1"   # opt-in (measured slower than apply + jagged SpMV, see jh_ilu.hip): read when the factors are laid out
+    ctx.set_option("fused_product", 1)   # opt-in (measured slower than apply + jagged SpMV, see jh_ilu.hip): read when the factors are laid out
     try:
         F = ja.ILUZeroPreconditioner(partition="blocks").update_preconditioner(lsys.jac)
+        _fused_product_checks(ja, ctx, oracle, kind, F, g, rng, lsys, law, disc, osys, nz_o)
     finally:
-        os.environ.pop("JH_FUSED_PRODUCT", None)
+        ctx.set_option("fused_product", 0)
+
+
+def _fused_product_checks(ja, ctx, oracle, kind, F, g, rng, lsys, law, disc, osys, nz_o):
+    import scipy.sparse as sp
+    nc, bs = g["nc"], law.N
     info = F.info()
     assert info["factor_kernel"] == "pivot-only" and info["fused_product"], info
     perm, bp = disc.ordering()
@@ -422,17 +442,13 @@ def test_preconditioned_operator_fused_product(ja, ctx, oracle, kind):
     # standalone apply on the column-scaled factors, factor export
     assert relerr(F.apply(lsys.jac.new_vector(), lsys.jac.new_vector(b)).download(), x_o) < 1e-10
     assert np.count_nonzero(F.factor_values()) > 0
-    # BiCGStab through the fused operator: same iterates as the two-operator path (environment switch read per solve)
+    # BiCGStab through the fused operator: same iterates as the two-operator path (the option is read per solve)
     sol = {}
     for off in (False, True):
-        if off:
-            os.environ["JH_NO_FUSED_PRODUCT"] = "1"
-        try:
+        with options(ctx, fused_product=0 if off else 1):
             ks = ja.GenericKrylov("bicgstab", preconditioner=F, relative_tolerance=1e-9, max_iterations=300)
             out = ja.linear_solve(lsys, ks, update_preconditioner=False)
             sol[off] = (out["iterations"], out["residuals"], lsys.dx.download())
-        finally:
-            os.environ.pop("JH_NO_FUSED_PRODUCT", None)
     assert abs(sol[False][0] - sol[True][0]) <= 1 and sol[False][0] > 3
     assert relerr(sol[False][2], sol[True][2]) < 1e-7
     k = min(len(sol[False][1]), len(sol[True][1]), 6)
@@ -478,18 +494,22 @@ def test_device_blocks_come_from_graph_bisection(ja, ctx):
 @pytest.mark.parametrize("wave", [None, "0", "1", "2", "3"])
 @pytest.mark.parametrize("bs", [1, 2, 3])
 @pytest.mark.parametrize("grid", ["bipartite", "bipartite7", "triangles"])
-def test_ilu0_factor_kernels_pivot_only_and_program(ja, ctx, oracle, grid, bs, wave, monkeypatch):
+def test_ilu0_factor_kernels_pivot_only_and_program(ja, ctx, oracle, grid, bs, wave):
     """The refactorisation picks its kernel from the pattern: on a triangle-free pattern (Cartesian / tet-lattice grids) no
     elimination step updates an off-diagonal entry and the sweep-shaped pivot-only kernel runs; a pattern with triangles (a
     Cartesian grid with one diagonal per cell pair) needs the general program-driven kernel.  Both give the oracle's ILU(0)
     (ilu0.jl:108-144) on the device-ordered matrix to 1e-11, scalar and 2x2 blocks, after a refactorisation with new values."""
     import scipy.sparse as sp
     # the pivot-only refactorisation has two kernels (one workgroup / one wavefront per block; the default picks by block size and
-    # row length): JH_ILU_FACTOR_WAVE = 0 / 1 forces one, 2 / 3 the wavefront kernel with / without its operand prefetch
-    if wave is not None:
-        if grid == "triangles":
-            pytest.skip("the switch only concerns the pivot-only kernels")
-        monkeypatch.setenv("JH_ILU_FACTOR_WAVE", wave)
+    # row length): option ilu_factor_kernel = 0 / 1 forces one, 2 / 3 the wavefront kernel with / without its operand prefetch
+    if wave is not None and grid == "triangles":
+        pytest.skip("the switch only concerns the pivot-only kernels")
+    with options(ctx, ilu_factor_kernel=-1 if wave is None else int(wave)):
+        _factor_kernel_case(ja, ctx, oracle, grid, bs, wave)
+
+
+def _factor_kernel_case(ja, ctx, oracle, grid, bs, wave):
+    import scipy.sparse as sp
     dims = (13, 11, 1)
     N = ja.cartesian_neighbors(dims)
     nc = int(np.prod(dims))

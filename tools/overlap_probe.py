@@ -3,7 +3,7 @@
 Rank 0's subdomain of the 8-way RCB partition (its owned cells + ghost ring) is solved with a 1-rank RCCL communicator
 whose halo plan sends to / receives from rank 0 itself: the ghosts receive the values of (arbitrary) owned boundary cells,
 so the numbers are not the physical solution, but every launch, the RCCL send/recv kernel, the second stream and the
-events are the ones of the multi-GPU path.  JH_HALO_OVERLAP=1 enables the overlapped exchange (default: serial)."""
+events are the ones of the multi-GPU path.  JH_OPTIONS=halo_overlap=1 enables the overlapped exchange (default: serial)."""
 import os, sys, time
 os.environ.pop("NCCL_DEBUG", None)  # the image exports NCCL_DEBUG=VERSION: keep stdout clean
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -45,6 +45,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 reps = [step() for _ in range(steps)]
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 its = [int(r.linear_iterations) for r in reps]
-print(f"owned {n_owned} ghosts {n_local - n_owned} split {disc.split()} overlap {'on' if os.environ.get('JH_HALO_OVERLAP') else 'off'} push {os.environ.get('PUSH', '0')}: "
+print(f"owned {n_owned} ghosts {n_local - n_owned} split {disc.split()} overlap {'on' if ctx.get_option('halo_overlap') else 'off'} push {os.environ.get('PUSH', '0')}: "
       f"{el / steps * 1e3:.3f} ms/step, {np.mean(its):.1f} its/step, {el / np.sum(its) * 1e6:.1f} us/iteration", flush=True)
 ctx.comm_finalize()

@@ -11,9 +11,9 @@ echo "## RCCL send/recv (fused pack, direct receive)"
 python tools/overlap_probe.py 2>&1 | grep owned
 echo "## push halo (PUSH=1)"
 PUSH=1 python tools/overlap_probe.py 2>&1 | grep owned
-echo "## RCCL send/recv, separate pack kernel (JH_NO_FUSED_PACK=1), ghosts in global-id order (GHOST_ORDER=global: unpack kernel)"
-JH_NO_FUSED_PACK=1 GHOST_ORDER=global python tools/overlap_probe.py 2>&1 | grep owned
-echo "## overlapped exchange on a second stream (JH_HALO_OVERLAP=1)"
-JH_HALO_OVERLAP=1 python tools/overlap_probe.py 2>&1 | grep owned
+echo "## RCCL send/recv, separate pack kernel (option fused_pack=0), ghosts in global-id order (GHOST_ORDER=global: unpack kernel)"
+JH_OPTIONS=fused_pack=0 GHOST_ORDER=global python tools/overlap_probe.py 2>&1 | grep owned
+echo "## overlapped exchange on a second stream (option halo_overlap=1)"
+JH_OPTIONS=halo_overlap=1 python tools/overlap_probe.py 2>&1 | grep owned
 } > gpurun_out/dist_proxy.txt 2>&1
 cat gpurun_out/dist_proxy.txt

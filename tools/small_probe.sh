@@ -2,7 +2,7 @@
 R=$GRAFT_REPO_ROOT; cd $R
 for c in 1250000 10000000; do
   python bench.py --cells $c --no-cpu --steps 12 --warmup 3 > gpurun_out/p_${c}.json 2> gpurun_out/p_${c}.err
-  JH_SYNC_LOOP=1 python bench.py --cells $c --no-cpu --steps 12 --warmup 3 > gpurun_out/p_${c}_sync.json 2> gpurun_out/p_${c}_sync.err
+  python bench.py --option sync_loop=1 --cells $c --no-cpu --steps 12 --warmup 3 > gpurun_out/p_${c}_sync.json 2> gpurun_out/p_${c}_sync.err
 done
 python - <<'PY'
 import json

@@ -25,7 +25,7 @@ def timeit(label, fn, reps=40):
     ms = ctx.timer_stop_ms() / reps
     print(f"{label:28s} {ms*1e3:8.1f} us   {(12.0*nnz + 20.0*nc)/ms/1e6:8.1f} GB/s (12 nnz + 20 n)", flush=True)
 timeit("csr tile kernel", lambda: ja.mul_(y, A, x))
-os.environ["JH_JDS_KEEP"] = "1"
+os.environ["JH_OPTIONS"] = "jds_keep=1"
 ja.mul_(y, A, x, jagged=True)
 timeit("jagged", lambda: ja.mul_(y, A, x, jagged=True))
 # streaming references on the same device: copy and dot of nnz-sized arrays

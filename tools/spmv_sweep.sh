@@ -1,6 +1,6 @@
 R=$GRAFT_REPO_ROOT; cd $R
 for w in 128 192 256 320 384 512; do
-  JH_SPMV_WGS=$w python bench.py --no-cpu --steps 8 --warmup 2 > gpurun_out/sw_$w.json 2>/dev/null
+  python bench.py --option spmv_waves_per_xcd=$((4*w)) --no-cpu --steps 8 --warmup 2 > gpurun_out/sw_$w.json 2>/dev/null
   python - $w <<'PY'
 import json,sys
 w=sys.argv[1]
