@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libjutul_hip.so")
+SO_PATH = os.environ.get("JUTUL_HIP_LIB") or os.path.join(_HERE, "libjutul_hip.so")  # (override: A/B of two builds in one GPU session)
 _lib = None
 
 I64P = C.POINTER(C.c_int64)

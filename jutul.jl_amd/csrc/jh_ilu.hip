@@ -395,6 +395,23 @@ __device__ __forceinline__ int jd_count(const int4 &d) {
   const unsigned w = J < 4 ? (unsigned)d.y : (unsigned)d.z;
   return (int)((w >> (8 * (J & 3))) & 0xffu);
 }
+// A chunk descriptor through the scalar cache: the kernels also store through global pointers, so the compiler cannot prove that a
+// descriptor is not clobbered and would fetch it with a vector load -- whose result the wavefront then has to wait for before it
+// can branch on the counts (one exposed memory latency per chunk step).  Constant address space: s_load_dwordx4.
+__device__ __forceinline__ int4 jds_desc(const int4 *desc, int i) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  typedef v4i __attribute__((address_space(4))) const *cptr;
+  const v4i d = *((cptr)(unsigned long long)desc + i);
+  return make_int4(d.x, d.y, d.z, d.w);
+}
+// Orders the LDS traffic of a one-wavefront workgroup: the LDS operations of a wavefront execute in order, so only the compiler
+// has to be kept from moving them.  (__syncthreads() here drains vmcnt as well: every level step would wait for the prefetched
+// entries of the NEXT chunk.)
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // ILU(0) refactorisation when no elimination step updates an off-diagonal entry -- the pattern inside every block is
 // triangle-free: Cartesian and corner-point grids, the tet lattice.  Then U keeps A's entries, L_ik = A_ik inv(u_kk), and only
 // the pivots u_ii = A_ii - sum_k L_ik A_ki follow the elimination order (ilu0.jl:108-144 with every process_partial_row! update
@@ -550,7 +567,7 @@ __global__ __launch_bounds__(64) void ilu_factor_wave_kernel(IluDev F, const dou
 #undef JH_FW
   };
   const int4 *desc = F.jf_desc;
-  int4 dc = desc[c0], dn = desc[c0 + 1], dnn;  // (the descriptor arrays are padded by two entries)
+  int4 dc = jds_desc(desc, c0), dn = jds_desc(desc, c0 + 1), dnn;  // (the descriptor arrays are padded by four entries)
   FWRow<BS, KU> cur, nxt;
   load(dc, c0, cur);
   const int u0 = ubase[b], nu = ubase[b + 1] - u0;
@@ -575,7 +592,7 @@ __global__ __launch_bounds__(64) void ilu_factor_wave_kernel(IluDev F, const dou
     }
   };
   for (int c = 0; c < nch; ++c) {
-    dnn = desc[c0 + c + 2];
+    dnn = jds_desc(desc, c0 + c + 2);
     if (PF && c + 1 < nch) load(dn, c0 + c + 1, nxt);
     const int lt = (int)(cur.word & 0xffffu), lev = (int)(cur.word >> 16);
     const bool has_row = lev != 0xffff;
@@ -612,7 +629,7 @@ __global__ __launch_bounds__(64) void ilu_factor_wave_kernel(IluDev F, const dou
           blk_store_al<BS>(F.kap + ((size_t)c0 * 64 + cur.bslot) * BB, aii);
         }
       }
-      __syncthreads();  // one wavefront: orders this level's LDS writes before the next level's reads
+      wave_lds_fence();  // one wavefront: orders this level's LDS writes before the next level's reads
     }
     dc = dn; dn = dnn;
     if (PF) cur = nxt;
@@ -1010,7 +1027,7 @@ __device__ __forceinline__ void chunk_sweep(const IluDev &F, double *xs, int b0,
     const int lv_hi = __shfl(lv_cur, nvalid - 1, 64);
     for (int lv = max(lv_lo, skip_level0); lv <= lv_hi; ++lv) {
       if (lv_cur == lv) pf_compute<BS, BWD, true>(F, cur, xs);
-      __syncthreads();
+      wave_lds_fence();  // (one wavefront per block: __syncthreads() would also wait for the next chunk's prefetched entries)
     }
     cur = nxt; lv_cur = lv_nxt;
     nxt = nn; lv_nxt = lv_nn;
@@ -1023,31 +1040,70 @@ __device__ __forceinline__ void chunk_sweep(const IluDev &F, double *xs, int b0,
 //   2:  p = r + beta*(p - omega*q) (beta = (rho'/rho)(alpha/omega)) input := p, p stored
 // Start of a one-wavefront-per-block apply with a fused BiCGStab update (GM 1 / 2): the pending second reduction stage (PendSum),
 // the previous iteration's record (workgroup 0) and the coefficients -- GM 1: ca = alpha; GM 2: ca = beta, cb = omega.
+// Two halves so that a kernel can issue other loads between the partials' loads and their use.
 // false: the launch is a no-op (speculative iteration after the solve has converged); the answer is uniform over the wavefront.
 template <int GM>
-__device__ __forceinline__ bool apply_prologue(const IluGather &G, double &ca, double &cb) {
+struct PendRegs {
+  static constexpr int CNT = GM == 2 ? 2 : 1;  // GM 1: <c, A y>; GM 2: (rho', ||r||^2)
+  double v[CNT][PEND_MAX / 64];
+  double rho, rho_next, cv, ts, tt, done;  // the device scalars of the update, requested together with the partials
+};
+template <int GM>
+__device__ __forceinline__ void apply_prologue_loads(const IluGather &G, PendRegs<GM> &R) {
+  if (GM == 0) return;
+  // (before workgroup 0 stores anything to the scalars: behind that store these loads would be a dependent memory latency of
+  // their own at the head of every wavefront)
+  R.rho = G.sc[G.rho_slot];
+  R.cv = G.sc[G.cv_slot];
+  R.rho_next = GM == 2 ? G.sc[G.rho_next_slot] : 0.0;
+  R.ts = GM == 2 ? G.sc[G.ts_slot] : 0.0;
+  R.tt = GM == 2 ? G.sc[G.ts_slot + 1] : 0.0;
+  R.done = G.done ? *G.done : 0.0;
+  if (!G.pend.part) return;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < PEND_MAX / 64; ++j) {
+    const int i = lane + 64 * j;
+#pragma unroll
+    for (int k = 0; k < PendRegs<GM>::CNT; ++k) R.v[k][j] = (i < G.pend.nparts) ? G.pend.part[(size_t)k * G.pend.stride + i] : 0.0;
+  }
+}
+template <int GM>
+__device__ __forceinline__ bool apply_prologue(const IluGather &G, PendRegs<GM> &R, double &ca, double &cb) {
   if (GM == 0) return true;
-  double p0 = 0.0, p1 = 0.0;
+  double p[2] = {0.0, 0.0};
   const bool pend = G.pend.part != nullptr;
-  if (pend) {
-    pend_sum_wave(G.pend, p0, p1);
+  if (pend) {  // the sums of pend_sum_wave, from loads issued earlier
+#pragma unroll
+    for (int k = 0; k < PendRegs<GM>::CNT; ++k) {
+      double a = R.v[k][0];
+#pragma unroll
+      for (int j = 1; j < PEND_MAX / 64; ++j) a += R.v[k][j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+      p[k] = a;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // for the kernels behind this one
-      G.sc_rw[G.pend.out_slot] = p0;
-      if (G.pend.count == 2) G.sc_rw[G.pend.out_slot + 1] = p1;
+      G.sc_rw[G.pend.out_slot] = p[0];
+      if (GM == 2) G.sc_rw[G.pend.out_slot + 1] = p[1];
     }
   }
-  if (GM == 2 && G.pub_rec && blockIdx.x == 0 && threadIdx.x == 0)
-    publish_record(G.sc_rw, G.pub_pair, G.pub_eps, G.pub_rec, G.pub_seq);  // raises the done flag on convergence
-  double dn = G.done ? *G.done : 0.0;
-  dn = __shfl(dn, 0, 64);  // (workgroup 0: lane 0 has just written the flag)
+  double dn = R.done;
+  if (GM == 2 && G.pub_rec && blockIdx.x == 0) {  // workgroup 0 publishes the previous iteration's record and knows its outcome
+    if (threadIdx.x == 0) {
+      publish_record(G.sc_rw, G.pub_pair, G.pub_eps, G.pub_rec, G.pub_seq);  // raises the done flag on convergence
+      dn = (dn != 0.0 || G.sc_rw[S_DONE] != 0.0) ? 1.0 : 0.0;
+    }
+    dn = __shfl(dn, 0, 64);
+  }
   if (dn != 0.0) return false;  // speculative launch after the Krylov solve has converged
   if (GM == 1) {
-    ca = G.sc[G.rho_slot] / (pend ? p0 : G.sc[G.cv_slot]);  // alpha
+    ca = R.rho / (pend ? p[0] : R.cv);  // alpha
   } else if (GM == 2) {
-    const double rho = G.sc[G.rho_slot], rho_next = pend ? p0 : G.sc[G.rho_next_slot];
-    const double alpha = rho / G.sc[G.cv_slot];
-    cb = G.sc[G.ts_slot + 1] == 0.0 ? 0.0 : G.sc[G.ts_slot] / G.sc[G.ts_slot + 1];  // omega (0/0 guard, see bicg_omega)
-    ca = (rho_next / rho) * (alpha / cb);        // beta
+    const double rho = R.rho, rho_next = pend ? p[0] : R.rho_next;
+    const double alpha = rho / R.cv;
+    cb = R.tt == 0.0 ? 0.0 : R.ts / R.tt;  // omega (0/0 guard, see bicg_omega)
+    ca = (rho_next / rho) * (alpha / cb);  // beta
   }
   return true;
 }
@@ -1056,7 +1112,9 @@ __global__ __launch_bounds__(64) void ilu_apply_chunked_kernel(IluDev F, const d
                                                               IluGather G) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
   double ca = 0.0, cb = 0.0;
-  if (!apply_prologue<GM>(G, ca, cb)) return;
+  PendRegs<GM> pr;
+  apply_prologue_loads<GM>(G, pr);
+  if (!apply_prologue<GM>(G, pr, ca, cb)) return;
   const int b = blockIdx.x;
   const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
   const int nr = b1 - b0;
@@ -1141,6 +1199,9 @@ __device__ __forceinline__ void jds_load(const IluDev &F, const int4 &D, int chu
     R.col[J < KU ? J : 0] = (int)cols[off + lane]; /* lanes past the count read the next diagonal's */     \
     _Pragma("unroll") for (int i = 0; i < BB; ++i) R.val[(J < KU ? J : 0) * BB + i] = vals[(size_t)(off + lane) * BB + i]; \
     off += jd_count<(J < 8 ? J : 0)>(D);                                                                   \
+  } else if (J < KU) { /* no such diagonal: a valid LDS index and a finite value for the unconditional reads of the sweep */ \
+    R.col[J < KU ? J : 0] = 0;                                                                             \
+    _Pragma("unroll") for (int i = 0; i < BB; ++i) R.val[(J < KU ? J : 0) * BB + i] = 0.0;                \
   }
   JH_JL(0) JH_JL(1) JH_JL(2) JH_JL(3) JH_JL(4) JH_JL(5) JH_JL(6) JH_JL(7)
 #undef JH_JL
@@ -1158,75 +1219,122 @@ __device__ __forceinline__ void jds_load(const IluDev &F, const int4 &D, int chu
 // SC (D-ILU storage, jh_ilu_s::uscaled): the values are A's own entries; forward g^_i = inv(D~_i) (b_i - sum A_ik g^_k), backward
 // y_i = g^_i - inv(D~_i) s_i with s_i = sum A_ik y_k.  MUL: the backward lane also stores A_ii y_i + s_i, the part of (A y)_i it
 // knows, to qq (= q + first row of the block) at the row's device position.
+// First chunk of a sweep in flight: its two descriptors and the lanes' entries.  Issued at the very start of the kernel for BOTH
+// sweeps -- the sweeps' first loads then overlap the gather phase (and each other) instead of being two exposed descriptor ->
+// entries latency chains per wavefront (~3 us each; at 1.25M rows per GPU a block's whole sweep is ~10 us).
+template <int BS, int KU>
+struct JPre {
+  int4 dc, dn;
+  JRow<BS, KU> cur;
+};
 template <int BS, int KU, bool BWD, bool SC, bool MUL>
-__device__ __forceinline__ void jds_sweep(const IluDev &F, double *xs, int c0, int nch, int lane, double *qq = nullptr) {
-  constexpr int BB = BS * BS;
+__device__ __forceinline__ void jds_prefetch(const IluDev &F, int c0, int lane, JPre<BS, KU> &P) {
   const int4 *desc = BWD ? F.jb_desc : F.jf_desc;
-  int4 dc = desc[c0], dn = desc[c0 + 1], dnn;  // (the descriptor arrays are padded by two entries)
-  JRow<BS, KU> cur, nxt;
-  jds_load<BS, KU, BWD, SC, MUL>(F, dc, c0, lane, cur);
-  for (int c = 0; c < nch; ++c) {
-    dnn = desc[c0 + c + 2];
-    if (c + 1 < nch) jds_load<BS, KU, BWD, SC, MUL>(F, dn, c0 + c + 1, lane, nxt);
-    const int lt = (int)(cur.word & 0xffffu), lev = (int)(cur.word >> 16);
-    const int lvlo = dc.w & 0xffff, lvhi = (int)((unsigned)dc.w >> 16);
-    double v[BS], x0[BS];
+  P.dc = jds_desc(desc, c0);
+  P.dn = jds_desc(desc, c0 + 1);  // (the descriptor arrays are padded by four entries)
+  jds_load<BS, KU, BWD, SC, MUL>(F, P.dc, c0, lane, P.cur);
+}
+// The levels of ONE chunk: the lane's row (cur) waits for its level, reads its operands from the block's vector in LDS, writes
+// its result there.
+template <int BS, int KU, bool BWD, bool SC, bool MUL>
+__device__ __forceinline__ void jds_chunk(double *xs, int lane, const int4 &dc, const JRow<BS, KU> &cur, double *qq) {
+  constexpr int BB = BS * BS;
+  const int lt = (int)(cur.word & 0xffffu), lev = (int)(cur.word >> 16);
+  const int lvlo = dc.w & 0xffff, lvhi = (int)((unsigned)dc.w >> 16);
+  double v[BS], x0[BS];
 #pragma unroll
-    for (int e = 0; e < BS; ++e) { x0[e] = xs[lt * BS + e]; v[e] = (SC && BWD) ? 0.0 : x0[e]; }  // this row's entry: only the row itself ever writes it
-    // forward, LU form: level-0 rows have no L entries, x = b; D-ILU form: they are scaled by their pivot like every row
-    for (int lv = (BWD || SC) ? lvlo : max(lvlo, 1); lv <= lvhi; ++lv) {
-      if (lev == lv) {
-#define JH_JC(J)                                                                                              \
-        if (J < KU && jd_count<(J < 8 ? J : 0)>(dc) > 0) {                                                   \
-          const int k = cur.col[J < KU ? J : 0];                                                             \
-          const bool a = lane < jd_count<(J < 8 ? J : 0)>(dc);                                               \
-          if (BS == 1) {                                                                                      \
-            const double t = v[0] - cur.val[J < KU ? J : 0] * xs[k];                                         \
-            v[0] = a ? t : v[0];                                                                              \
-          } else {                                                                                            \
-            _Pragma("unroll") for (int e = 0; e < BS; ++e) {                                                 \
-              double sum = 0.0;                                                                               \
-              _Pragma("unroll") for (int d = 0; d < BS; ++d) sum += cur.val[(J < KU ? J : 0) * BB + d * BS + e] * xs[k * BS + d]; \
-              v[e] = a ? v[e] - sum : v[e];                                                                   \
-            }                                                                                                 \
-          }                                                                                                   \
-        }
-        JH_JC(0) JH_JC(1) JH_JC(2) JH_JC(3) JH_JC(4) JH_JC(5) JH_JC(6) JH_JC(7)
-#undef JH_JC
-        if (BWD || SC) {
-          double o[BS];  // inv(D~_i) v
+  for (int e = 0; e < BS; ++e) { x0[e] = xs[lt * BS + e]; v[e] = (SC && BWD) ? 0.0 : x0[e]; }  // this row's entry: only the row itself ever writes it
+  // Entries the lane does not have (past a diagonal's count; diagonals the chunk does not have) become a zero coefficient times the
+  // lane's own entry of the vector, ONCE per chunk: the level loop -- one VALU-bound step per dependency level, all wavefronts of
+  // a SIMD in it together -- then is four multiply-subtracts, not four multiply-subtract-selects (v - 0 * x == v up to the sign
+  // of a zero)
+  int kc[KU];
+  double cv[KU * BB];
+#define JH_JM(J)                                                                                            \
+  if (J < KU) {                                                                                             \
+    const bool a = lane < jd_count<(J < 8 ? J : 0)>(dc);                                                   \
+    kc[J < KU ? J : 0] = a ? cur.col[J < KU ? J : 0] : lt; /* (not the stray index: LDS past the block's rows may hold NaN) */ \
+    _Pragma("unroll") for (int i = 0; i < BB; ++i) cv[(J < KU ? J : 0) * BB + i] = a ? cur.val[(J < KU ? J : 0) * BB + i] : 0.0; \
+  }
+  JH_JM(0) JH_JM(1) JH_JM(2) JH_JM(3) JH_JM(4) JH_JM(5) JH_JM(6) JH_JM(7)
+#undef JH_JM
+  // forward, LU form: level-0 rows have no L entries, x = b; D-ILU form: they are scaled by their pivot like every row
+  for (int lv = (BWD || SC) ? lvlo : max(lvlo, 1); lv <= lvhi; ++lv) {
+    if (lev == lv) {
+      // all operands of the row first -- the LDS reads in flight together, one wait -- then the updates in column order: per level
+      // one LDS round trip instead of one per entry behind a branch each
+      // (skipping the reads of diagonals no row of the level has -- a ballot and a branch each -- was measured slower: 16.4k instead
+      // of 11.0k cycles per forward sweep of a 256-row block)
+      double xk[KU][BS];
+#pragma unroll
+      for (int j = 0; j < KU; ++j) {
+#pragma unroll
+        for (int d = 0; d < BS; ++d) xk[j][d] = xs[kc[j] * BS + d];
+      }
+#pragma unroll
+      for (int j = 0; j < KU; ++j) {
+        if (BS == 1) {
+          v[0] = v[0] - cv[j] * xk[j][0];
+        } else {
 #pragma unroll
           for (int e = 0; e < BS; ++e) {
             double sum = 0.0;
 #pragma unroll
-            for (int d = 0; d < BS; ++d) sum += cur.dinv[d * BS + e] * v[d];
-            o[e] = sum;
+            for (int d = 0; d < BS; ++d) sum += cv[j * BB + d * BS + e] * xk[j][d];
+            v[e] = v[e] - sum;
           }
-          if (SC && BWD) {  // v = -s_i: y_i = g^_i + inv(D~_i) v
-#pragma unroll
-            for (int e = 0; e < BS; ++e) o[e] += x0[e];
-          }
-#pragma unroll
-          for (int e = 0; e < BS; ++e) xs[lt * BS + e] = o[e];
-          if (MUL) {  // A_ii y_i + s_i
-            const int dev = cur.dev & 0x7fff;
-#pragma unroll
-            for (int e = 0; e < BS; ++e) {
-              double sum = -v[e];
-#pragma unroll
-              for (int d = 0; d < BS; ++d) sum += cur.kap[d * BS + e] * o[d];
-              qq[dev * BS + e] = sum;
-            }
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < BS; ++e) xs[lt * BS + e] = v[e];
         }
       }
-      __syncthreads();  // one wavefront: orders this level's LDS writes before the next level's reads
+      if (BWD || SC) {
+        double o[BS];  // inv(D~_i) v
+#pragma unroll
+        for (int e = 0; e < BS; ++e) {
+          double sum = 0.0;
+#pragma unroll
+          for (int d = 0; d < BS; ++d) sum += cur.dinv[d * BS + e] * v[d];
+          o[e] = sum;
+        }
+        if (SC && BWD) {  // v = -s_i: y_i = g^_i + inv(D~_i) v
+#pragma unroll
+          for (int e = 0; e < BS; ++e) o[e] += x0[e];
+        }
+#pragma unroll
+        for (int e = 0; e < BS; ++e) xs[lt * BS + e] = o[e];
+        if (MUL) {  // A_ii y_i + s_i
+          const int dev = cur.dev & 0x7fff;
+#pragma unroll
+          for (int e = 0; e < BS; ++e) {
+            double sum = -v[e];
+#pragma unroll
+            for (int d = 0; d < BS; ++d) sum += cur.kap[d * BS + e] * o[d];
+            qq[dev * BS + e] = sum;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < BS; ++e) xs[lt * BS + e] = v[e];
+      }
     }
-    dc = dn; dn = dnn;
-    cur = nxt;
+    wave_lds_fence();  // this level's LDS writes before the next level's reads
+  }
+}
+// The chunk loop: the entries of chunk c+1 are requested before chunk c walks its levels.  Measured alternatives (round 4, in-kernel
+// clock stamps of tools/apply_timing.py and A/B runs of two builds on one box): the loop unrolled over two or three register sets in
+// rotating roles with a fixed number of loads per step -- so that the wait in front of a chunk is s_waitcnt vmcnt(n) with younger
+// chunks in flight instead of the full drain the copy "A = B" below implies -- was SLOWER at every size (10M rows 187 vs 184 us per
+// launch, Cartesian 10M 222-242 vs 208 us, 1.25M rows 30.5 vs 29.9 us), two chunks ahead slower still: what a level step waits for
+// is the LDS round trip of its own dependency chain, not the entry stream.
+template <int BS, int KU, bool BWD, bool SC, bool MUL>
+__device__ __forceinline__ void jds_sweep(const IluDev &F, double *xs, int c0, int nch, int lane, const JPre<BS, KU> &P, double *qq = nullptr) {
+  const int4 *desc = BWD ? F.jb_desc : F.jf_desc;
+  JRow<BS, KU> A = P.cur, B;
+  int4 dA = P.dc, dB = P.dn, dnext;
+  for (int c = 0; c < nch; ++c) {
+    dnext = jds_desc(desc, c0 + c + 2);  // (the descriptor arrays are padded by four entries)
+    if (c + 1 < nch) jds_load<BS, KU, BWD, SC, MUL>(F, dB, c0 + c + 1, lane, B);
+    jds_chunk<BS, KU, BWD, SC, MUL>(xs, lane, dA, A, qq);
+    dA = dB; dB = dnext;
+    A = B;
   }
 }
 // Third pass of the fused product (MUL): q_i += sum_{k<i} L_ik w_k over the forward chunks -- no dependencies, all lanes of a
@@ -1287,40 +1395,95 @@ struct IluMul {
   size_t pstride = 0;
   int dot_rows = 0x7fffffff;    // device rows >= dot_rows (ghost rows of a rank-local subdomain) do not contribute to the dot
 };
+// Development build (-DJH_APPLY_TIMING, tools/apply_timing.py): shader-clock stamps of the phases of every block's wavefront.
+#ifdef JH_APPLY_TIMING
+__device__ unsigned long long jh_apply_t[8 * 65536];
+#define JH_T(k) do { if (threadIdx.x == 0 && blockIdx.x < 65536) jh_apply_t[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define JH_T(k) do { } while (0)
+#endif
 template <int BS, int GM, int KU, bool SC, int MUL>
 __global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec, IluGather G, IluMul Q) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
-  double ca = 0.0, cb = 0.0;
-  if (!apply_prologue<GM>(G, ca, cb)) return;
-  if (GM == 0 && MUL && G.done && *G.done != 0.0) return;
   const int b = blockIdx.x, lane = threadIdx.x;
+  JH_T(0);
   const int b0 = F.blk_ptr[b], b1 = F.blk_ptr[b + 1];
   const int nr = b1 - b0;
   const int c0 = F.chunk_ptr[b], nch = F.chunk_ptr[b + 1] - c0;
-  // the block's rows are the device rows [b0, b1): read coalesced in device order, dropped at their ilu position
-  for (int t = lane; t < nr; t += 64) {
-    const int dev = b0 + t;
-    const int pos = (int)F.rowmap16[dev];
+  // everything that does not depend on a value computed here is requested first: the dot partials, the first chunk of both sweeps,
+  // the first batch of the vector rows
+  double ca = 0.0, cb = 0.0;
+  PendRegs<GM> pr;
+  apply_prologue_loads<GM>(G, pr);
+  // (the backward chunk costs a second set of entry registers for the whole forward sweep: only where that leaves the occupancy
+  // alone -- scalar rows of at most 4 entries per sweep; 2x2 blocks would go from 92 to 137 VGPRs)
+#ifndef JH_EARLY_BWD_KU
+#define JH_EARLY_BWD_KU 4
+#endif
+  constexpr bool EARLY_BWD = BS == 1 && KU <= JH_EARLY_BWD_KU;
+  JPre<BS, KU> pf, pb;
+  jds_prefetch<BS, KU, false, SC, false>(F, c0, lane, pf);
+  if (EARLY_BWD) jds_prefetch<BS, KU, true, SC, (MUL != 0)>(F, c0, lane, pb);
+  // The block's rows are the device rows [b0, b1): read coalesced in device order, dropped at their ilu position.  GB row groups of
+  // 64 per batch, all loads of a batch in flight together (a group at a time is two dependent memory latencies per 64 rows, in
+  // series: eight of them for a 256-row block before the first sweep can start).
+  constexpr int GB = BS == 1 ? 4 : 2;
+  struct GRow { int pos; double a[BS], b[BS], c[BS]; };
+  GRow gr[GB];
+  auto gather_load = [&](int t0) {
 #pragma unroll
-    for (int e = 0; e < BS; ++e) {
-      const size_t o = (size_t)dev * BS + e;
-      double v;
-      if (GM == 0) {
-        v = bvec[o];
-      } else if (GM == 1) {
-        v = (dev < G.n_owned_rows) ? G.r[o] - ca * G.q[o] : 0.0;
-        G.out[o] = v;
-      } else {
-        const double pa = G.out[o] - cb * G.q[o];
-        v = (dev < G.n_owned_rows) ? G.r[o] + ca * pa : 0.0;
-        G.out[o] = v;
+    for (int g = 0; g < GB; ++g) {
+      const int t = t0 + g * 64 + lane;
+      if (t < nr) {
+        const int dev = b0 + t;
+        gr[g].pos = (int)F.rowmap16[dev];
+#pragma unroll
+        for (int e = 0; e < BS; ++e) {
+          const size_t o = (size_t)dev * BS + e;
+          if (GM == 0) { gr[g].a[e] = bvec[o]; }
+          else { gr[g].a[e] = G.r[o]; gr[g].b[e] = G.q[o]; if (GM == 2) gr[g].c[e] = G.out[o]; }
+        }
       }
-      xs[pos * BS + e] = v;
     }
-  }
+  };
+  auto gather_finish = [&](int t0) {
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+      const int t = t0 + g * 64 + lane;
+      if (t < nr) {
+        const int dev = b0 + t;
+#pragma unroll
+        for (int e = 0; e < BS; ++e) {
+          const size_t o = (size_t)dev * BS + e;
+          double v;
+          if (GM == 0) {
+            v = gr[g].a[e];
+          } else if (GM == 1) {
+            v = (dev < G.n_owned_rows) ? gr[g].a[e] - ca * gr[g].b[e] : 0.0;
+            G.out[o] = v;
+          } else {
+            const double pa = gr[g].c[e] - cb * gr[g].b[e];
+            v = (dev < G.n_owned_rows) ? gr[g].a[e] + ca * pa : 0.0;
+            G.out[o] = v;
+          }
+          xs[gr[g].pos * BS + e] = v;
+        }
+      }
+    }
+  };
+  gather_load(0);
+  if (!apply_prologue<GM>(G, pr, ca, cb)) return;
+  if (GM == 0 && MUL && G.done && *G.done != 0.0) return;
+  JH_T(1);
+  gather_finish(0);
+  for (int t0 = 64 * GB; t0 < nr; t0 += 64 * GB) { gather_load(t0); gather_finish(t0); }
+  JH_T(2);
   __syncthreads();
-  jds_sweep<BS, KU, false, SC, false>(F, xs, c0, nch, lane);
-  jds_sweep<BS, KU, true, SC, (MUL != 0)>(F, xs, c0, nch, lane, MUL ? Q.q + (size_t)b0 * BS : nullptr);
+  jds_sweep<BS, KU, false, SC, false>(F, xs, c0, nch, lane, pf);
+  JH_T(3);
+  if (!EARLY_BWD) jds_prefetch<BS, KU, true, SC, (MUL != 0)>(F, c0, lane, pb);
+  jds_sweep<BS, KU, true, SC, (MUL != 0)>(F, xs, c0, nch, lane, pb, MUL ? Q.q + (size_t)b0 * BS : nullptr);
+  JH_T(4);
   __syncthreads();
   if (MUL) {
     // the partial products of the backward sweep were stored by lanes of this wavefront: a workgroup-scope fence orders them
@@ -1336,11 +1499,18 @@ __global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const doubl
       if (lane == 0) { Q.part[b] = d0; if (DOT == 2) Q.part[Q.pstride + b] = d1; }
     }
   }
-  for (int t = lane; t < nr; t += 64) {
-    const int dev = b0 + t;
-    const int pos = (int)F.rowmap16[dev];
+  for (int t0 = 0; t0 < nr; t0 += 64 * GB) {  // (batched like the gather: the row map of GB groups in flight together)
+    int pos[GB];
 #pragma unroll
-    for (int e = 0; e < BS; ++e) xvec[(size_t)dev * BS + e] = xs[pos * BS + e];
+    for (int g = 0; g < GB; ++g) { const int t = t0 + g * 64 + lane; pos[g] = t < nr ? (int)F.rowmap16[b0 + t] : 0; }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+      const int t = t0 + g * 64 + lane;
+      if (t < nr) {
+#pragma unroll
+        for (int e = 0; e < BS; ++e) xvec[(size_t)(b0 + t) * BS + e] = xs[pos[g] * BS + e];
+      }
+    }
   }
   if (F.send_ptr) {  // rows that neighbouring ranks hold as ghosts go straight into the halo send buffer (no pack kernel)
     for (int j = F.send_ptr[b] + lane; j < F.send_ptr[b + 1]; j += 64) {
@@ -1359,7 +1529,28 @@ __global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const doubl
       }
     }
   }
+  JH_T(5);
 }
+#ifdef JH_APPLY_TIMING
+// mean cycles of the phases over the blocks of the LAST launch: [0] prologue (pointers, partial sums, first loads), [1] gather,
+// [2] forward sweep, [3] backward sweep, [4] scatter; [5] first start -> last end of the launch; [6] mean wavefront lifetime
+extern "C" int32_t jh_debug_apply_times(int64_t nblocks, double *out7) {
+  std::vector<unsigned long long> h((size_t)8 * 65536);
+  if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(jh_apply_t), h.size() * sizeof(unsigned long long)) != hipSuccess) return -1;
+  const int64_t nb = std::min<int64_t>(nblocks, 65536);
+  for (int k = 0; k < 7; ++k) out7[k] = 0.0;
+  unsigned long long t0 = ~0ull, t1 = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    const unsigned long long *t = h.data() + b * 8;
+    for (int k = 0; k < 5; ++k) out7[k] += (double)(t[k + 1] - t[k]) / nb;
+    out7[6] += (double)(t[5] - t[0]) / nb;
+    t0 = std::min(t0, t[0]);
+    t1 = std::max(t1, t[5]);
+  }
+  out7[5] = (double)(t1 - t0);
+  return 0;
+}
+#endif
 
 // The part of the product the blocks cannot form: q_i += sum over the entries of row i OUTSIDE its block of A_ik y_k, one thread
 // per such row (13 % of the entries, a third of the rows on the bisection blocks of a tet grid), and those rows' share of the
@@ -1758,7 +1949,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         for (int64_t b = 0; b < nb; ++b) M->chunk_ptr[b + 1] = M->chunk_ptr[b] + (M->blk_ptr[b + 1] - M->blk_ptr[b] + 63) / 64;
         const int64_t nchunks = M->chunk_ptr[nb];
         M->j_nslots = nchunks * 64;
-        std::vector<int4> fdesc(nchunks + 2, make_int4(0, 0, 0, 0)), bdesc(nchunks + 2, make_int4(0, 0, 0, 0));  // + 2: read ahead
+        std::vector<int4> fdesc(nchunks + 4, make_int4(0, 0, 0, 0)), bdesc(nchunks + 4, make_int4(0, 0, 0, 0));  // + 4: read ahead
         std::vector<uint32_t> frow(M->j_nslots, 0xffff0000u), brow(M->j_nslots, 0xffff0000u);
         // the jagged order permutes the entries inside a block: block b keeps the ranges [l_ptr[b0], l_ptr[b1]) / [u_ptr[b0], u_ptr[b1]),
         // so the blocks can be laid out independently -- on all host cores

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -81,6 +82,22 @@ static inline void parallel_ranges(int64_t n, int64_t min_per_thread, F &&fn) {
   for (auto &x : th) x.join();
   for (auto &e : err) if (e) std::rethrow_exception(e);
 }
+
+// Pacing of the health checks inside a host spin on pinned memory: due() is true once every `period_ms` of waiting.  The check
+// itself is a hipStreamQuery, which is NOT free for the device: it puts a marker packet behind the last enqueued kernel, and the
+// kernel enqueued next waits for it (measured round 4: 6.3 instead of 1.4 us in front of the first kernel of every BiCGStab
+// iteration while the host polled the stream every 16 384 spins).
+struct SpinPacer {
+  uint64_t spins = 0;
+  std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+  bool due(int period_ms = 50) {
+    if ((++spins & 0xfff) != 0) return false;
+    const auto now = std::chrono::steady_clock::now();
+    if (now - last < std::chrono::milliseconds(period_ms)) return false;
+    last = now;
+    return true;
+  }
+};
 
 // v.resize(n) for the large set-up arrays.  (Touching the pages of the fresh allocation from all host cores before the
 // zero-fill was measured on the GPU box: no gain -- page faults are not what the set-up waits for -- so this is a plain resize.)
@@ -168,7 +185,7 @@ struct Comm;  // RCCL state (jh_comm.cpp)
   X(spmv_jagged, 1)           /* Krylov loop multiplies out of the jagged-slice copy when the matrix has one */               \
   X(spmv_col_bits, 0)         /* jagged column ids: 16 / 32, 0 = by size (16 from 3M rows) */                                  \
   X(spmv_waves_per_xcd, 0)    /* persistent wavefronts per XCD of the SpMV kernels, 0 = what is resident at once */            \
-  X(spmv_waves, 0)            /* wavefronts per workgroup of the jagged SpMV: 4 / 8 / 16, 0 = 4, or 8 with consumer_reduce */  \
+  X(spmv_waves, 0)            /* wavefronts per workgroup of the jagged SpMV: 4 / 8 / 16, 0 = 4, or 16 with consumer_reduce */ \
   X(spmv_window, 1)           /* CSR tile SpMV: LDS window of x */                                                             \
   X(spmv_pipe, 1)             /* CSR tile SpMV with a fused dot: software-pipelined variant */                                 \
   X(sync_loop, 0)             /* 1: the host waits for iteration k before enqueueing k+1 (no speculative iteration) */         \
@@ -470,8 +487,8 @@ namespace jh {
 // the same bits -- instead of a one-workgroup kernel between producer and consumer (4.8 us + a kernel boundary each, four per
 // BiCGStab iteration: 16 % of an iteration at 1.25M cells per GPU).  No atomics, no flags, no spinning: the kernel boundary that
 // is there anyway orders partials and consumer.  Workgroup 0 of the consumer also stores the sums to sc[out_slot (, +1)] for the
-// kernels behind it.  Producers that feed a PendSum run with at most PEND_MAX workgroups (16 loads per lane and sum).
-constexpr int PEND_MAX = 1024;
+// kernels behind it.  Producers that feed a PendSum run with at most PEND_MAX workgroups (8 loads per lane and sum).
+constexpr int PEND_MAX = 512;
 struct PendSum {
   const double *part = nullptr;  // nullptr: nothing pending, the scalars are in sc[]
   unsigned stride = 0;           // second sum at part + stride

@@ -256,9 +256,10 @@ void read_scalars(jh_context ctx, int slot, int count, double *out) {
   const double seq = (double)(++ctx->rd_seq);
   hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->scalars.p + slot, count, ctx->h_rd, seq);
   volatile double *r = ctx->h_rd;
-  for (uint64_t spin = 1;; ++spin) {
+  SpinPacer pace;
+  for (;;) {
     if (r[JH_NSCALARS - 1] == seq) break;
-    if ((spin & 0xffff) == 0) {  // the stream must still be busy, otherwise the kernel was lost (fault)
+    if (pace.due()) {  // the stream must still be busy, otherwise the kernel was lost (fault)
       hipError_t q = hipStreamQuery(ctx->stream);
       if (q == hipSuccess) {
         if (r[JH_NSCALARS - 1] == seq) break;

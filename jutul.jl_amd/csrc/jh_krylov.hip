@@ -259,9 +259,10 @@ namespace jh {
 // Wait (spinning on pinned memory, no stream synchronisation) until the record with sequence number seq has been published.
 static void wait_published(jh_context ctx, int rec, double seq, double *out) {
   volatile double *r = ctx->h_pub + rec * JH_PUB_LEN;
-  for (uint64_t spin = 1;; ++spin) {
+  SpinPacer pace;
+  for (;;) {
     if (r[15] == seq) break;
-    if ((spin & 0x3fff) == 0) {  // the stream must still be busy, otherwise the record was lost (kernel fault)
+    if (pace.due()) {  // the stream must still be busy, otherwise the record was lost (kernel fault)
       comm_check_errors(ctx);    // a peer that never arrived in a mailbox all-reduce / push halo (time-limited waits)
       hipError_t q = hipStreamQuery(ctx->stream);
       if (q == hipSuccess) {
@@ -338,7 +339,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   // the producers run with larger workgroups so that a full-chip launch leaves at most PEND_MAX partials.
   const bool pend_ok = ctx->opt.consumer_reduce && !fmul && jagged && right && ilu_can_fuse_gather(M) && !dist && comm_size(ctx) == 1;
   PendSum pend_spmv;  // partials of the last product with a fused dot
-  const int spmv_waves = ctx->opt.spmv_waves ? (int)ctx->opt.spmv_waves : (pend_ok ? 8 : 4);
+  const int spmv_waves = ctx->opt.spmv_waves ? (int)ctx->opt.spmv_waves : (pend_ok ? 16 : 4);
   auto spmv = [&](double *in, double *out, const SpmvDot *dot, bool packed = false) {
     if (dist) halo_exchange(disc, in, P.bs, packed, true);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
     K->mark(0, st);
