@@ -78,6 +78,18 @@ def parse_args(argv=None):
     # update_linearized_system_equation! -> convergence_criterion -> linear_solve! -> update_primary_variables! ->
     # update_after_step! [-> get_output_state]) through its call-for-call twin jutul.jl_amd/julia_mirror.py -- what simulate!
     # would get through the binding
+    ap.add_argument("--selftest-only", action="store_true",
+                    help="pre-flight of a multi-GPU run: initialise the communicator, mailboxes and push halo, run one ghost exchange of "
+                         "the global cell ids and one all-reduce per path, print which path each exchange takes and exit (non-zero if "
+                         "any exchange fell back from the requested path or returned wrong data)")
+    ap.add_argument("--timesteps", action="store_true",
+                    help="a step is one implicit TIME STEP through Simulator.solve_timestep (assemble -> converged? -> solve -> update -> "
+                         "..., ministep cuts on failure: simulator.jl:304-617) instead of one Newton iteration; value = Newton "
+                         "iterations (linear solves) per second.  The nonlinear line of configs[4]: --law compressible --timesteps")
+    ap.add_argument("--compressibility", type=float, default=0.0,
+                    help="--law compressible: fluid compressibility c in rho = rho0 exp(c (p - p_ref)) (0 = 1e-3); with dt = 5 a value of "
+                         "0.2 gives the accumulation term the weight it has in the Poisson headline and a genuinely nonlinear residual")
+    ap.add_argument("--newton-tol", type=float, default=1e-3, help="--timesteps: convergence tolerance on max|r_e| (models.jl:818-883)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="context option (jh_context_set_option, include/jutul_hip.h), repeatable: A/B runs")
     ap.add_argument("--path", default="fused", choices=["fused", "seams"])
@@ -89,6 +101,8 @@ def parse_args(argv=None):
         args.cells = 5_000_000 if args.law == "twophase" else 10_000_000
     if args.dt <= 0:
         args.dt = 0.5 if args.law == "twophase" else 5.0
+    if args.compressibility > 0 and args.law == "compressible":
+        LAW_PAR["compressible"] = dict(LAW_PAR["compressible"], compressibility=(args.compressibility, args.compressibility))
     return args
 
 
@@ -275,7 +289,7 @@ def main():
     prec = ja.ILUZeroPreconditioner(partition="blocks")
     ks = ja.GenericKrylov("bicgstab", preconditioner=prec, relative_tolerance=args.rtol, max_iterations=200 if N == 2 else 100,
                           precond_side=args.precond_side)
-    sim = ja.Simulator(law, ks)
+    sim = ja.Simulator(law, ks, tolerance=args.newton_tol)
     t0 = time.time()
     prec.update_preconditioner(sim.lsys.jac)  # symbolic phase (levels, maps); the first factorisation of zeros is harmless
     setup["ilu_symbolic_s"] = time.time() - t0
@@ -291,12 +305,24 @@ def main():
         if cinfo["mailbox"] != mailbox or disc.halo_info()["push"] != push:
             fatal(f"rank {rank}: communication paths differ from what was negotiated ({cinfo}, {disc.halo_info()})")
 
+    if args.selftest_only:
+        selftest(args, ja, np, torch, dist, ctx, disc, law, rank, world, N, n_owned,
+                 cells if (world > 1 or force_dist) else np.arange(nc_g), mailbox, push, host_halo, cinfo, real_stdout)
+        return
+
     def step_fused():
         rep = sim.perform_step(args.dt, 1)  # iteration 1 always solves (min_nonlinear_iterations = 1)
         law.update_state0()
         return rep
 
+    def step_timestep():
+        sim.reports = []
+        sim.solve_timestep(args.dt)   # state0 <- state on success (update_after_step!), ministep cuts on failure
+        return sim.reports
+
     seams = None
+    if args.timesteps and args.path == "seams":
+        fatal("--timesteps runs the fused path")
     if args.path == "seams":
         if world > 1 or force_dist:
             fatal("--path seams times the single-GPU binding sequence (the distributed hooks add jh_halo_exchange_state / jh_unit_diagonalize)")
@@ -344,7 +370,7 @@ def main():
                 seams["outputs"] += 1
             return SimpleNamespace(linear_iterations=its, error=err, assembly_ms=tm.get("assembly_ms", 0.0), precond_ms=tm.get("precond_ms", 0.0),
                                    linear_solve_ms=tm.get("linear_solve_ms", 0.0), update_ms=tm.get("update_ms", 0.0))
-    step = step_seams if seams else step_fused
+    step = step_seams if seams else (step_timestep if args.timesteps else step_fused)
 
     def barrier():
         torch.cuda.synchronize()
@@ -364,6 +390,27 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ks.profile(enable=False, reset=True)
     X_end = law.get_state().reshape(-1, N)  # (before the extra, untimed steps below)
+    nonlinear = None
+    n_units = args.steps   # what `value` counts per second: Newton iterations
+    if args.timesteps:
+        per_step = reps
+        allr = [r for st_ in per_step for r in st_]
+        solved = [r for r in allr if r.linear_iterations > 0]
+        checks = [r for r in allr if r.linear_iterations == 0]   # the assembly + convergence test that ends a ministep
+        n_units = len(solved)
+        nonlinear = {"timesteps": args.steps, "newton_iterations": len(solved), "assemblies": len(allr),
+                     "newton_iterations_per_timestep": round(len(solved) / max(1, args.steps), 3),
+                     "linear_iterations_per_newton_iteration": round(float(np.mean([r.linear_iterations for r in solved])), 2) if solved else None,
+                     "ministeps": len(sim.last_ministeps) if args.steps == 1 else None,
+                     "newton_tolerance": args.newton_tol,
+                     "convergence_check_ms": round(float(np.mean([r.assembly_ms for r in checks])), 4) if checks else None,
+                     "convergence_check_share_of_step": round(float(np.sum([r.assembly_ms for r in checks])) * 1e-3 / elapsed, 4) if checks else None,
+                     "ms_per_timestep": round(elapsed / args.steps * 1e3, 3),
+                     "note": "a time step = Simulator.solve_timestep: assemble -> converged? -> ILU(0) refactor + BiCGStab -> update -> ... until "
+                             "max|r_e| < tolerance (min_nonlinear_iterations = 1), state0 <- state; value counts the iterations that solved a "
+                             "linear system, the closing assembly + convergence test of every time step is inside the timed region"}
+        wreps = [r for st_ in wreps for r in st_ if r.linear_iterations > 0]
+        reps = solved
     seams_extra = None
     if seams:
         # per-phase device times from a few extra steps with event pairs around the calls (not inside the timed region: every
@@ -463,16 +510,17 @@ def main():
     if rank == 0:
         its_all = [int(r.linear_iterations) for r in wreps] + lin_its
         out = {
-            "metric": "newton_iterations_per_sec", "value": round(args.steps / elapsed, 4), "unit": "Newton iterations/s",
+            "metric": "newton_iterations_per_sec", "value": round(n_units / elapsed, 4), "unit": "Newton iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.law} TPFA conservation law ({N} primary variable{'s' if N > 1 else ''}/cell), {nc_g}-cell "
-                                   f"{mesh_desc}, nf={nf_g}, 1 Newton iteration/step: "
+                                   f"{mesh_desc}, nf={nf_g}, " + ("1 implicit time step/step (full Newton loop): " if args.timesteps else "1 Newton iteration/step: ") +
                                    f"assembly + block-Jacobi ILU(0) factor + BiCGStab(rtol={args.rtol})",
-                       "cells": nc_g, "faces": nf_g, "mesh": args.mesh, "law": args.law, "block_n": N, "dt": args.dt,
+                       "cells": nc_g, "faces": nf_g, "mesh": args.mesh, "law": args.law, "law_parameters": {k: list(v) if isinstance(v, tuple) else v for k, v in LAW_PAR[args.law].items()},
+                       "block_n": N, "dt": args.dt,
                        "block_rows": args.block_rows or "library default", "ilu_max_block_rows": info["max_block_rows"],
                        "parallelism": f"dd{world}" if world > 1 else "single", "precond_side": ks.config.precond_side,
-                       "path": args.path, "seams": seams_extra, "options": {k: v for k, v in options.items() if k != "comm_timeout_ms"},
+                       "path": args.path, "seams": seams_extra, "nonlinear": nonlinear, "options": {k: v for k, v in options.items() if k != "comm_timeout_ms"},
                        "launcher": os.environ.get("JH_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),
                        "ranks_seen": ranks_seen, "devices_used": devices_used, "rccl_ranks": cinfo["rccl_ranks"],
                        "scalar_allreduce": ("mailbox" if mailbox else "rccl") if world > 1 else None,
@@ -505,6 +553,80 @@ def main():
         ctx.comm_finalize()
     if world > 1:
         dist.destroy_process_group()
+
+
+def selftest(args, ja, np, torch, dist, ctx, disc, law, rank, world, N, n_owned, cells, mailbox, push, host_halo, cinfo, real_stdout):
+    """--selftest-only: every exchange of the distributed step once, with data whose answer every rank knows.
+      state halo    parray_synchronize_primary_variables (ext/JutulPartitionedArraysExt/interface.jl:189-220): the global cell ids go
+                    through jh_halo_exchange_state; every ghost row must hold its owner's id
+      all-reduce    the dots / norms of the Krylov loop (ext/.../krylov.jl:67-74): sum and max of rank-dependent values through the
+                    negotiated path (mailboxes) AND through ncclAllReduce
+      Krylov halo   consistent! before every mul! (ext/.../linalg.jl:46): the push halo verified one exchange of the global ids when
+                    it was set up (dd.setup_push_halo); reported here
+    Rank 0 prints one JSON line {"selftest": ...}; exit code 1 if an exchange returned wrong data or took another path than the
+    one requested (requested: RCCL state halo unless JH_BENCH_HALO=host, mailboxes unless JH_BENCH_NO_MAILBOX=1, push halo unless
+    JH_BENCH_NO_PUSH=1)."""
+    problems = []
+    nloc = disc.nc
+    gid = (cells[:nloc] + 1).astype(np.float64)
+    X = np.stack([gid + 0.25 * e for e in range(N)], axis=1)
+    Xown = X.copy()
+    Xown[n_owned:] = -1.0                       # ghosts unknown before the exchange
+    law.set_state(Xown.reshape(-1))
+    if world > 1 or nloc > n_owned:
+        law.synchronize_ghosts()
+    got = law.get_state().reshape(nloc, N)
+    halo_ok = bool(np.array_equal(got, X))
+    if not halo_ok:
+        problems.append(f"rank {rank}: state halo returned wrong ghost values ({int((got != X).any(axis=1).sum())} rows)")
+    ar = {}
+    want_sum = np.array([world * (world + 1) / 2.0, float(world)])
+    want_max = np.array([float(world), 1.0])
+    mine = np.array([rank + 1.0, 1.0])
+    paths = [("negotiated", None)] + ([("rccl", False)] if (mailbox and not host_halo) else [])
+    if cinfo["nranks"] < 1 or (world == 1 and nloc == n_owned and not cinfo["rccl_ranks"]):
+        paths = []   # no communicator on a plain single-rank run
+    for name, enable in paths:
+        if enable is not None:
+            ctx.comm_ipc_enable(enable)
+        try:
+            s_ = ctx.allreduce(mine.copy(), "sum")
+            m_ = ctx.allreduce(mine.copy(), "max")
+            ok = bool(np.array_equal(s_, want_sum) and np.array_equal(m_, want_max))
+        except Exception as e:  # noqa: BLE001
+            ok = False
+            problems.append(f"rank {rank}: all-reduce ({name}) failed: {e}")
+        ar[name] = ok
+        if not ok:
+            problems.append(f"rank {rank}: all-reduce ({name}) returned wrong values")
+        if enable is not None:
+            ctx.comm_ipc_enable(mailbox)
+    want = {"state_halo": "host-callback" if host_halo else "rccl",
+            "scalar_allreduce": "rccl" if (os.environ.get("JH_BENCH_NO_MAILBOX") == "1" or world == 1) else "mailbox",
+            "krylov_halo": "push" if (world > 1 and os.environ.get("JH_BENCH_NO_PUSH") != "1") else ("host-callback" if host_halo else "rccl")}
+    took = {"state_halo": "host-callback" if host_halo else "rccl",
+            "scalar_allreduce": "mailbox" if mailbox else "rccl",
+            "krylov_halo": "push" if push else ("host-callback" if host_halo else "rccl")}
+    for k in want:
+        if world > 1 and took[k] != want[k]:
+            problems.append(f"rank {rank}: {k} fell back from {want[k]} to {took[k]}")
+    allp = [None] * world
+    if world > 1:
+        dist.all_gather_object(allp, problems)
+    else:
+        allp = [problems]
+    flat = [p for ps in allp for p in ps]
+    if rank == 0:
+        out = {"selftest": {"ranks": world, "rccl_ranks": cinfo["rccl_ranks"], "paths": took, "requested": want, "state_halo_ok": halo_ok,
+                            "allreduce_ok": ar, "ghost_rows": int(nloc - n_owned), "comm_timeouts": ctx.comm_info()["timeouts"],
+                            "problems": flat},
+               "ok": not flat}
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if world > 1:
+        dist.barrier()
+    if flat:
+        sys.exit(1)
 
 
 def make_mesh(ja, args, cells=None, scramble=True):
@@ -653,9 +775,20 @@ def cpu_baseline(args, nc_gpu):
     lim = update_limits(np, args.law)
     src = source_values(np, args.law, [1.0, -1.0])
 
-    def leg(scramble, seconds, kernels):
-        m, _ = make_mesh(ja, args, args.cpu_cells, scramble=scramble)
+    def leg(order, seconds, kernels):
+        m, _ = make_mesh(ja, args, args.cpu_cells, scramble=order != "natural")
         nc = m["nc"]
+        if order == "rcm":   # cells renumbered by reverse Cuthill-McKee of the cell graph (faces keep their ids)
+            import scipy.sparse as sp
+            from scipy.sparse.csgraph import reverse_cuthill_mckee
+            Nf = m["N"] - 1
+            G = sp.csr_matrix((np.ones(Nf.shape[1], dtype=np.int8), (Nf[0], Nf[1])), shape=(nc, nc))
+            perm = reverse_cuthill_mckee(G + G.T, symmetric_mode=True)      # new position -> old cell
+            newid = np.empty(nc, dtype=np.int64)
+            newid[perm] = np.arange(nc)
+            m["N"] = (newid[Nf] + 1).astype(m["N"].dtype)
+            m["volumes"] = m["volumes"][perm]
+            m["cell_centroids"] = m["cell_centroids"][:, perm]
         T = o.touch_copy(m["T"] / m["T"].mean())
         vol = o.touch_copy(m["volumes"])
         U = o.touch_copy(initial_state(np, args.law, nc))
@@ -720,22 +853,47 @@ def cpu_baseline(args, nc_gpu):
                 "cells": nc, "note": "best of 3-5 repetitions on the sample grid, all host cores"}
         return out
 
-    a = leg(True, args.cpu_seconds * 0.6, True)
-    b = leg(False, args.cpu_seconds * 0.4, False)
-    julia = shutil.which("julia")
-    return {"value": round(a["rate"] * a["nc"] / nc_gpu, 5), "unit": "Newton iterations/s", "cores": threads, "kind": "port",
+    # three legs on the same grid: the generator's natural numbering (what a mesh generator hands Jutul: the headline `value`),
+    # the scrambled numbering the GPU run is given, and that scrambled grid renumbered by reverse Cuthill-McKee (the locality help
+    # the GPU gives itself with its block ordering, given to the CPU as well)
+    b = leg("natural", args.cpu_seconds * 0.4, True)
+    a = leg("scrambled", args.cpu_seconds * 0.3, False)
+    c = leg("rcm", args.cpu_seconds * 0.3, False)
+    scale = lambda x: round(x["rate"] * x["nc"] / nc_gpu, 5)
+    return {"value": scale(b), "unit": "Newton iterations/s", "cores": threads, "kind": "port",
             "cores_note": f"{threads} OpenMP threads = min(logical CPUs {os.cpu_count()}, affinity, cgroup CPU quota)",
-            "linear_iterations_per_step": round(float(np.mean(a["its"])), 2), "linear_iterations_first_steps": (a["wits"] + a["its"])[:8],
-            "value_natural_numbering": round(b["rate"] * b["nc"] / nc_gpu, 5),
-            "kernels": a["kernels"],
-            "jutul_itself": f"julia found at {julia}, but no build-owned Jutul run is wired: not executed" if julia else
-                            "absent: `command -v julia` finds nothing on this box (BASELINE.md baseline B not possible)",
-            "sample": f"steps {args.warmup + 1}..{args.warmup + len(a['its'])} of the same sequence the GPU leg runs ({args.warmup} warm-up steps, "
-                      f"then {len(a['its'])} timed: assembly + block-Jacobi ILU(0) refactor with {threads} blocks + BiCGStab rtol={args.rtol}, "
-                      f"{float(np.mean(a['its'])):.1f} its/step + state update) on a {a['nc']}-cell grid of the same family (same scrambled "
-                      f"numbering as the GPU input) in {a['el']:.1f}s = {a['rate']:.3f} it/s, scaled by cells {a['nc']}/{nc_gpu} to the GPU grid; "
-                      f"value_natural_numbering: the same on the generator's own cell numbering ({b['rate']:.3f} it/s on the sample); "
+            "numbering": "natural (the mesh generator's own cell numbering)",
+            "linear_iterations_per_step": round(float(np.mean(b["its"])), 2), "linear_iterations_first_steps": (b["wits"] + b["its"])[:8],
+            "value_scrambled_numbering": scale(a), "value_rcm_of_scrambled_numbering": scale(c),
+            "kernels": b["kernels"],
+            "jutul_itself": jutul_itself(args),
+            "sample": f"steps {args.warmup + 1}..{args.warmup + len(b['its'])} of the same sequence the GPU leg runs ({args.warmup} warm-up steps, "
+                      f"then {len(b['its'])} timed: assembly + block-Jacobi ILU(0) refactor with {threads} blocks + BiCGStab rtol={args.rtol}, "
+                      f"{float(np.mean(b['its'])):.1f} its/step + state update) on a {b['nc']}-cell grid of the same family in its natural "
+                      f"numbering in {b['el']:.1f}s = {b['rate']:.3f} it/s, scaled by cells {b['nc']}/{nc_gpu} to the GPU grid; "
+                      f"value_scrambled_numbering: the same on the scrambled numbering the GPU leg is given ({a['rate']:.3f} it/s on the sample); "
+                      f"value_rcm_of_scrambled_numbering: that grid renumbered by reverse Cuthill-McKee ({c['rate']:.3f} it/s); "
                       f"OpenMP restatement of Jutul's ParallelCSRContext path (not Jutul itself)"}
+
+
+def jutul_itself(args):
+    """BASELINE.md baseline B: Jutul.jl's own simulate! (ParallelCSRContext + GenericKrylov(:bicgstab, ILUZeroPreconditioner())) through
+    tools/jutul_baseline.jl when `julia` with an installed Jutul is on the box; a string saying why not otherwise."""
+    import shutil
+    import subprocess
+    julia = shutil.which("julia")
+    if not julia:
+        return "absent: `command -v julia` finds nothing on this box (tools/jutul_baseline.jl is the run that would be timed)"
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "jutul_baseline.jl")
+    try:
+        r = subprocess.run([julia, "-t", str(usable_cores()), script, str(args.cpu_cells), "10", str(args.dt), str(args.rtol)],
+                           capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return f"julia found at {julia}, tools/jutul_baseline.jl failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
+    except Exception as e:  # noqa: BLE001 -- a baseline that cannot run must not take the GPU line with it
+        return f"julia found at {julia}, tools/jutul_baseline.jl did not finish: {e}"
 
 
 if __name__ == "__main__":

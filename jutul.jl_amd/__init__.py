@@ -756,6 +756,7 @@ class Simulator:
         self.linear_solver = linear_solver or GenericKrylov("bicgstab", preconditioner=ILUZeroPreconditioner())
         self.tol = tolerance
         self.max_it, self.min_it, self.max_cuts = max_nonlinear_iterations, min_nonlinear_iterations, max_timestep_cuts
+        self.reports = None
 
     def _needs_general_path(self):
         """jh_newton_step is the fast path for the reference's defaults (BiCGStab, no scaling, base tolerances).  Every other
@@ -818,6 +819,8 @@ class Simulator:
     def solve_ministep(self, dt):
         for it in range(1, self.max_it + 2):
             rep = self.perform_step(dt, it, solve=it <= self.max_it)
+            if self.reports is not None:   # (bench.py: per-iteration reports of a whole time step)
+                self.reports.append(rep)
             err = max(rep.error[: self.law.N])
             if not np.isfinite(err) or err > 1e20:  # simulator.jl:771-800
                 return False, it, rep

@@ -569,7 +569,9 @@ extern "C" int32_t jh_law_get_variable(jh_law L, int32_t which, int32_t e, doubl
 extern "C" int32_t jh_host_register(void *ptr, int64_t bytes) {
   return guard([&] {
     if (!ptr || bytes <= 0) JH_THROW("bad host range");
-    JH_HIP(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return; }  // page-locked already: what was asked for
+    JH_HIP(e);
   });
 }
 extern "C" int32_t jh_host_unregister(void *ptr) {

@@ -96,9 +96,12 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
+// maximum that keeps a NaN (Julia's max / maximum propagate NaN: increment_norm, variable_change_report, models.jl:955-1038;
+// fmax drops it)
+__device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  for (int off = 32; off > 0; off >>= 1) v = nanmax(v, __shfl_down(v, off, 64));
   return v;
 }
 template <bool MAX>
@@ -111,7 +114,7 @@ __device__ __forceinline__ double block_reduce(double v, double *sm) {
   double r = 0.0;
   if (threadIdx.x == 0) {
     r = sm[0];
-    for (int i = 1; i < nw; ++i) r = MAX ? fmax(r, sm[i]) : r + sm[i];
+    for (int i = 1; i < nw; ++i) r = MAX ? nanmax(r, sm[i]) : r + sm[i];
   }
   __syncthreads();
   return r;  // valid on thread 0

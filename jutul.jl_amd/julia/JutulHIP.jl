@@ -57,13 +57,25 @@ mutable struct HIPContext <: GPUJutulContext
     matrix_layout
     block_rows::Int
     n_owned::Int            # > 0: rank-local model whose cells are [owned..., ghosts...] (ext/.../utils.jl:178-184)
-    function HIPContext(device = 0; matrix_layout = BlockMajorLayout(), block_rows = 0, n_owned = 0)
+    # options: the named integer options of the context (jh_context_set_option, include/jutul_hip.h) as keyword arguments, e.g.
+    # HIPContext(0; consumer_reduce = 0, comm_timeout_ms = 60_000) -- the role of ParallelCSRContext's keyword arguments
+    # (contexts/csr.jl:3-23)
+    function HIPContext(device = 0; matrix_layout = BlockMajorLayout(), block_rows = 0, n_owned = 0, options...)
         h = Ref{Handle}(C_NULL)
         @jh :jh_context_create (Int32, Ref{Handle}) Int32(device) h
         ctx = new(h[], device, matrix_layout, block_rows, n_owned)
         finalizer(c -> ccall((:jh_context_destroy, libjutul_hip), Int32, (Handle,), c.handle), ctx)
+        for (k, v) in options
+            set_option!(ctx, k, v)
+        end
         return ctx
     end
+end
+set_option!(c::HIPContext, key, value) = @jh :jh_context_set_option (Handle, Cstring, Int64) c.handle String(key) Int64(value)
+function get_option(c::HIPContext, key)
+    v = Ref{Int64}(0)
+    @jh :jh_context_get_option (Handle, Cstring, Ref{Int64}) c.handle String(key) v
+    return v[]
 end
 matrix_layout(c::HIPContext) = c.matrix_layout
 float_type(::HIPContext) = Float64          # context.jl:76
@@ -156,7 +168,16 @@ mutable struct HIPConservationLawStorage
     device_state0_valid::Bool      # device X0 == what the host last wrote into storage.state0
     host_state_stale::Bool         # the device has updated X since storage.state was last refreshed
     host_state0_stale::Bool        # the device has updated X0 (update_after_step!) since storage.state0 was last refreshed
-    registered::Bool               # storage.state0[k] arrays are page-locked (jh_host_register)
+    registered::Dict{Symbol, Ptr{Cvoid}}  # storage.state0[k] arrays that are page-locked (jh_host_register), by address
+end
+# the page-locked ranges are handed back when the storage goes away (a later simulator may get the same addresses: registering a
+# range twice is an error of the runtime) -- also called by hand when a simulator is torn down
+function unregister_host_arrays!(s::HIPConservationLawStorage)
+    for p in values(s.registered)
+        ccall((:jh_host_unregister, libjutul_hip), Int32, (Ptr{Cvoid},), p)   # (no error out of a finalizer)
+    end
+    empty!(s.registered)
+    return s
 end
 
 function setup_equation_storage(model::HIPModel,
@@ -192,8 +213,10 @@ function setup_equation_storage(model::HIPModel,
     @jh :jh_vec_create (Handle, Ref{Handle}) disc[] r
     @jh :jh_vec_create (Handle, Ref{Handle}) disc[] dx
     n_owned = ctx.n_owned > 0 ? ctx.n_owned : nc
-    return HIPConservationLawStorage(disc[], law[], jac[], r[], dx[], nc, ne, n_owned, NaN, zeros(ne, nc), SourceAccumulator(ne, nc), Int64[], Float64[],
-                                     zeros(ne), false, false, false, false, false)
+    s = HIPConservationLawStorage(disc[], law[], jac[], r[], dx[], nc, ne, n_owned, NaN, zeros(ne, nc), SourceAccumulator(ne, nc), Int64[], Float64[],
+                                  zeros(ne), false, false, false, false, Dict{Symbol, Ptr{Cvoid}}())
+    finalizer(unregister_host_arrays!, s)
+    return s
 end
 
 # ---- linearized system (seam: setup_linearized_system!, models.jl:654-668; LinearizedSystem, linsolve/default.jl:34-42) -----
@@ -325,12 +348,16 @@ function get_output_state(storage, model::HIPModel)
     if s.host_state0_stale
         for (i, k) in enumerate(keys(Jutul.get_primary_variables(model)))
             v0 = storage.state0[k]::Array{Float64}
-            if !s.registered
-                @jh :jh_host_register (Ptr{Cvoid}, Int64) v0 Int64(sizeof(v0))
+            p0 = Ptr{Cvoid}(pointer(v0))
+            if get(s.registered, k, C_NULL) != p0      # first use, or Jutul has replaced the array since
+                haskey(s.registered, k) && ccall((:jh_host_unregister, libjutul_hip), Int32, (Ptr{Cvoid},), s.registered[k])
+                @jh :jh_host_register (Ptr{Cvoid}, Int64) v0 Int64(sizeof(v0))     # (a range that is already page-locked is accepted)
+                s.registered[k] = p0
             end
-            @jh :jh_law_get_variable (Handle, Int32, Int32, Ptr{Float64}) s.law Int32(1) Int32(i - 1) v0
+            GC.@preserve v0 begin
+                @jh :jh_law_get_variable (Handle, Int32, Int32, Ptr{Float64}) s.law Int32(1) Int32(i - 1) v0
+            end
         end
-        s.registered = true
         s.host_state0_stale = false
     end
     return invoke(get_output_state, Tuple{Any, Jutul.JutulModel}, storage, model)
@@ -450,16 +477,42 @@ end
 # ---- end of a step (seams: update_after_step!, models.jl:983-1011; reset_state_to_previous_state!, :1068-1073) ----------
 function update_after_step!(storage, model::HIPModel, dt, forces; kwarg...)
     s = storage.LinearizedSystem.eq_s
-    rep4 = zeros(4 * s.N)          # variable_change_report (models.jl:1023-1038) before state0 <- state
-    @jh :jh_law_change_report (Handle, Int64, Ptr{Float64}) s.law Int64(s.n_owned) rep4
+    defs = storage.variable_definitions
+    pvar, svar = defs.primary_variables, defs.secondary_variables
+    nloc = s.nc                    # the reference reports over ALL local cells (length(X), models.jl:1023-1038): ghosts included
+    rep4 = zeros(4 * s.N)          # variable_change_report of the primary variables on the device, before state0 <- state
+    @jh :jh_law_change_report (Handle, Int64, Ptr{Float64}) s.law Int64(nloc) rep4
+    report = Jutul.OrderedDict{Symbol, Any}()
+    for (i, k) in enumerate(keys(pvar))
+        o = 4 * (i - 1)
+        report[k] = (dx = (sum = rep4[o + 1], max = rep4[o + 2]), x = (sum = rep4[o + 3], max = rep4[o + 4]), n = nloc)
+    end
+    # Secondary variables and extra fields live on the host (Jutul evaluates them): a model that has any gets the host's primary
+    # variables refreshed, its secondary variables re-evaluated from them, their change reports and their state0 <- state sync
+    # exactly as in the generic method (models.jl:983-1011); a model without them (the bench laws) pays nothing here
+    host_fields = !isempty(keys(svar)) || !isempty(defs.extra_variable_fields)
+    if host_fields
+        sync_host_state!(storage, model)
+        Jutul.update_secondary_variables!(storage, model)
+        for k in keys(svar)
+            report[k] = Jutul.variable_change_report(storage.state[k], storage.state0[k], svar[k])
+        end
+    end
+    # the hooks of the generic method
+    update_after_step!(storage, model.domain, model, dt, forces; kwarg...)
+    update_after_step!(storage, model.system, model, dt, forces; kwarg...)
+    update_after_step!(storage, model.formulation, model, dt, forces; kwarg...)
+    # state0 <- state: primary variables on the device (the host copy follows at the next get_output_state), the rest on the host
     @jh :jh_law_update_state0 (Handle,) s.law
     s.host_state0_stale = true
-    report = Jutul.OrderedDict{Symbol, Any}()
-    for (i, k) in enumerate(keys(Jutul.get_primary_variables(model)))
-        o = 4 * (i - 1)
-        report[k] = (dx = (sum = rep4[o + 1], max = rep4[o + 2]), x = (sum = rep4[o + 3], max = rep4[o + 4]), n = s.n_owned)
+    if host_fields
+        for key in keys(svar)
+            Jutul.update_values!(storage.state0[key], storage.state[key])
+        end
+        for key in defs.extra_variable_fields
+            Jutul.update_values!(storage.state0[key], storage.state[key])
+        end
     end
-    # the host copies follow at the next sync (get_output_state): state0 == state on both sides after a converged step
     return report
 end
 function reset_state_to_previous_state!(storage, model::HIPModel)

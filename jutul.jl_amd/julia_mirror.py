@@ -225,10 +225,10 @@ class JuliaMirror:
     def update_after_step(self, s):
         rep4 = np.zeros(4 * s.N)
         with self._fn("update_after_step!"):
-            check(self.L.jh_law_change_report(s.law, s.n_owned, pf(rep4)))
+            check(self.L.jh_law_change_report(s.law, s.nc, pf(rep4)))   # all local cells, like length(X) in the reference
             check(self.L.jh_law_update_state0(s.law))
             s.host_state0_stale = True
-        return [dict(dx=dict(sum=rep4[4 * e], max=rep4[4 * e + 1]), x=dict(sum=rep4[4 * e + 2], max=rep4[4 * e + 3]), n=s.n_owned)
+        return [dict(dx=dict(sum=rep4[4 * e], max=rep4[4 * e + 1]), x=dict(sum=rep4[4 * e + 2], max=rep4[4 * e + 3]), n=s.nc)
                 for e in range(s.N)]
 
     def reset_state_to_previous_state(self, s, host_state=None, host_state0=None):

@@ -1039,12 +1039,13 @@ static double dotp(I64 n, const double *a, const double *b) {
 }
 
 /* side: 0 none, 1 left (M = prec), 2 right (N = prec; Jutul single-process default, linsolve/utils.jl:25).
- * History: ||r_k|| for k = 0..iters (length iters+1).  Returns: 0 solved, 1 itmax, 2 breakdown.
+ * History: ||r_k|| for k = 0..iters (length iters+1).  Returns: 0 solved, 1 itmax, 2 breakdown, -1 workspace allocation failed.
  * x0 = 0, c = r0 (shadow), stop on ||r|| <= atol + rtol*||r0||. */
 /* Workspace of the Krylov solvers: ten vectors kept between solves (Krylov.jl's BicgstabSolver workspace is allocated once,
  * linsolve/krylov.jl:27-58), pages first touched by the threads that work on them. */
-static double *ws_buf = NULL;
-static I64 ws_len = 0;
+/* (per calling thread: ctypes releases the GIL during a call, two Python threads may solve at the same time) */
+static __thread double *ws_buf = NULL;
+static __thread I64 ws_len = 0;
 static double *ws_get(I64 m) {
   if (ws_len != m) {
     free(ws_buf);

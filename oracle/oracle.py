@@ -416,6 +416,8 @@ def bicgstab(n, bs, rowptr, colidx, nz, b, prec=None, side="right", rtol=1e-3, a
                            prec.h if prec is not None else None, C.c_int(SIDE[side] if prec is not None else 0),
                            _pf(_f(b)), _pf(x), C.c_double(rtol), C.c_double(atol), C.c_int64(itmax), C.byref(iters),
                            _pf(hist), C.c_int64(hist.size))
+    if st < 0:
+        raise MemoryError("oracle Krylov solver: workspace allocation failed")
     return x, dict(status=st, solved=(st == 0), iterations=iters.value, residuals=hist[: iters.value + 1].copy())
 
 
@@ -427,6 +429,8 @@ def gmres(n, bs, rowptr, colidx, nz, b, prec=None, side="right", rtol=1e-3, atol
                         prec.h if prec is not None else None, C.c_int(SIDE[side] if prec is not None else 0),
                         _pf(_f(b)), _pf(x), C.c_double(rtol), C.c_double(atol), C.c_int64(itmax), C.byref(iters),
                         _pf(hist), C.c_int64(hist.size))
+    if st < 0:
+        raise MemoryError("oracle Krylov solver: workspace allocation failed")
     return x, dict(status=st, solved=(st == 0), iterations=iters.value, residuals=hist[: iters.value + 1].copy())
 
 

@@ -141,3 +141,25 @@ def test_bench_seam_path_matches_fused_path():
     assert c["linear_iterations_first_steps"] == fused["config"]["linear_iterations_first_steps"]
     two = run(base + ["--path", "seams", "--law", "twophase", "--report-every", "2"])
     assert two["config"]["seams"]["output_states_downloaded"] == 2 and two["config"]["block_n"] == 2
+
+
+def test_bench_selftest_only_two_processes():
+    """`bench.py --gpus N --selftest-only`: the pre-flight of a multi-GPU run -- communicator, mailboxes, push halo, one ghost
+    exchange of the global cell ids, one all-reduce per path -- prints which path every exchange takes and exits non-zero on a
+    fallback or wrong data.  Two processes on the box's one GPU (host-callback state halo requested, like the test above)."""
+    env = dict(os.environ, JH_BENCH_HALO="host", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", "bench.py", "--gpus", "2", "--cells", "200000", "--selftest-only"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    st = d["selftest"]
+    assert d["ok"] and st["ranks"] == 2 and st["state_halo_ok"] and st["allreduce_ok"]["negotiated"] and st["ghost_rows"] > 0
+    assert st["paths"] == {"state_halo": "host-callback", "scalar_allreduce": "mailbox", "krylov_halo": "push"} and not st["problems"]
+    # the same with the push halo switched off on request: host-callback Krylov halo is then the requested path, not a fallback
+    p = subprocess.run(cmd[:9] + ["29548"] + cmd[10:], cwd=ROOT, env=dict(env, JH_BENCH_NO_PUSH="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
+    assert d["ok"] and d["selftest"]["paths"]["krylov_halo"] == "host-callback"

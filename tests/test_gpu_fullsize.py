@@ -180,6 +180,138 @@ def test_1M_cells_eight_ranks_match_single_rank(ja):
     assert np.abs(X - X_ref).max() <= 1e-7 * np.abs(X_ref).max()
 
 
+def _newton_update_over_ranks_matches_single_rank(ja, cells, kind, nranks, dt):
+    """One Newton update (perform_step!: ghost exchange of the primary variables, assembly, ghost rows -> -I, block-Jacobi ILU(0),
+    distributed BiCGStab at rtol 1e-10, update, simulator.jl:392-455 through ext/JutulPartitionedArraysExt) of the case decomposed
+    over `nranks` in-process ranks == the single-rank update to 1e-7 of the state's scale, owned cells and ghost copies."""
+    import threading
+    from bench import dims_for_cells
+    from jutul_amd import dd
+    g = ja.tet_lattice_mesh(*dims_for_cells(cells))
+    nc = g["nc"]
+    assert nc > 0.99 * cells
+    T = g["T"] / g["T"].mean()
+    rng = np.random.default_rng(3)
+    bs = 2 if kind == "twophase" else 1
+    if bs == 1:
+        X0 = 1.0 + 0.1 * rng.random(nc)
+        src = ([1, nc], np.array([[1.0], [-1.0]]))
+        par = {}
+    else:
+        X0 = np.stack([1.0 + 0.05 * rng.random(nc), rng.uniform(0.3, 0.7, nc)]).T.reshape(-1)
+        src = ([1, nc], np.array([[1.0, 0.2], [-1.0, -0.2]]))
+        par = dict(rho0=(1.0, 0.8), compressibility=(1e-3, 2e-3), viscosity=(1.0, 2.0), p_ref=1.0)
+
+    def make_sim(law):
+        ks = ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"), relative_tolerance=1e-10,
+                              max_iterations=600, precond_side="right")
+        return ja.Simulator(law, ks, tolerance=1e-8)
+
+    ctx0 = ja.HIPContext(0)
+    disc0 = ja.TwoPointPotentialFlowHardCoded(ctx0, g["N"], nc, block_n=bs, reorder="blocks")
+    law0 = ja.ConservationLaw(disc0, kind, **par)
+    law0.set_face_trans(T); law0.set_volumes(g["volumes"]); law0.set_state(X0); law0.set_state0(X0)
+    law0.set_sources(src[0], src[1].reshape(-1))
+    rep0 = make_sim(law0).perform_step(dt, 1)
+    assert rep0.linear_status == 0 and rep0.linear_iterations > 3
+    X_ref = law0.get_state().reshape(nc, bs)
+    del law0, disc0
+    part = dd.partition_rcb(g["cell_centroids"], nranks)
+    group = ja.LocalCommGroup(nranks)
+    out, err = [None] * nranks, []
+
+    def rank_fn(r):
+        try:
+            ctx = ja.HIPContext(0)
+            ctx.comm_init_local(group, r)
+            disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, r, T, g["volumes"], X0, kind=kind, block_n=bs, sources=src,
+                                                   block_rows=0, law_params=par, ghost_order="owner")
+            assert disc.split()[0] > 0
+            rep = make_sim(law).perform_step(dt, 1)
+            law.synchronize_ghosts()   # consistent!(state): the ghost copies of the updated primary variables
+            out[r] = (rep.linear_status, sub["cells"].copy(), sub["n_owned"], law.get_state().reshape(-1, bs))
+            ctx.comm_finalize()
+        except Exception as e:  # a failing rank would leave the others waiting in a collective
+            err.append(e)
+            raise
+
+    th = [threading.Thread(target=rank_fn, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join(900) for t in th]
+    assert not err, err
+    X = np.zeros((nc, bs))
+    scale = np.abs(X_ref).max(axis=0)
+    for status, cells_r, n_owned, Xl in out:
+        assert status == 0
+        X[cells_r[:n_owned] - 1] = Xl[:n_owned]
+        assert np.all(np.abs(Xl[n_owned:] - X_ref[cells_r[n_owned:] - 1]) <= 1e-7 * scale)
+    assert np.all(np.abs(X - X_ref) <= 1e-7 * scale)
+    assert np.abs(X_ref - X0.reshape(nc, bs)).max() > 1e-4       # the update is not a no-op
+
+
+def test_5M_cells_two_phase_eight_ranks_match_single_rank(ja):
+    """BASELINE configs[3] at full size: the 5M-cell two-phase case (2x2 block-CSR assembly, block-ILU(0)) decomposed over 8 ranks."""
+    _newton_update_over_ranks_matches_single_rank(ja, 5_000_000, "twophase", 8, 0.5)
+
+
+def test_10M_cells_eight_ranks_match_single_rank(ja):
+    """BASELINE configs[4] at full size: the 10M-cell grid decomposed over 8 ranks (1.25M owned cells each)."""
+    _newton_update_over_ranks_matches_single_rank(ja, 10_000_000, "poisson", 8, 5.0)
+
+
+def test_1M_cells_nonlinear_timesteps_match_the_oracle_newton_sequence(ja, oracle):
+    """bench.py's nonlinear line (--law compressible --compressibility 0.5 --timesteps) at 1M cells: three implicit time steps
+    through Simulator.solve_timestep (assemble -> converged? -> ILU(0) refactor + BiCGStab -> update -> ..., simulator.jl:304-617)
+    against the oracle's Newton loop on the same grid with the same control flow (min_nonlinear_iterations = 1, tolerance on
+    max|r|): the SAME number of Newton iterations in every time step and the same states to 1e-7.  Linear solves at rtol 1e-8 on
+    both sides, so that the iteration counts are decided by the nonlinear convergence and not by the last digit of an inexact
+    solve (the device eliminates in its own block order: its BiCGStab iterates differ from the oracle's, Krylov.jl is unpinned)."""
+    from bench import dims_for_cells
+    from jutul_amd import dd
+    ctx = ja.HIPContext(0)
+    g = ja.tet_lattice_mesh(*dims_for_cells(1_000_000))
+    nc = g["nc"]
+    T = g["T"] / g["T"].mean()
+    vol = g["volumes"]
+    par = dict(rho0=(1.0, 1.0), compressibility=(0.5, 0.5), viscosity=(1.0, 1.0), p_ref=1.0)
+    X0 = 1.0 + 0.1 * np.random.default_rng(3).random(nc)
+    src_c, src_v = [1, nc], [1.0, -1.0]
+    dt, tol, nsteps = 5.0, 1e-7, 3
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, reorder="blocks")
+    law = ja.ConservationLaw(disc, "compressible", **par)
+    law.set_face_trans(T); law.set_volumes(vol); law.set_state(X0); law.set_state0(X0); law.set_sources(src_c, src_v)
+    ks = ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"), relative_tolerance=1e-8,
+                          max_iterations=300)
+    sim = ja.Simulator(law, ks, tolerance=tol)
+    gpu_its, gpu_states = [], []
+    for _ in range(nsteps):
+        gpu_its.append(sim.solve_timestep(dt))
+        assert len(sim.last_ministeps) == 1 and sim.last_ministeps[0]["success"]      # no time-step cut on this problem
+        gpu_states.append(law.get_state())
+    # the oracle: same loop, its own BiCGStab with a block-Jacobi ILU(0) over 8 coordinate blocks
+    osys = oracle.TPFASystem(g["N"], nc)
+    olaw = oracle.Law("compressible", dt, rho0=par["rho0"], comp=par["compressibility"], mu=par["viscosity"], p_ref=par["p_ref"])
+    part = dd.partition_rcb(g["cell_centroids"], 8)
+    X = X0.copy()
+    Fo = None
+    for step in range(nsteps):
+        Xp = X.copy()
+        for it in range(1, 17):
+            nz, r = osys.assemble(olaw, X, Xp, vol, T, src_cells=src_c, src_values=src_v)
+            if it > 1 and np.abs(r).max() < tol:
+                break
+            if Fo is None:
+                Fo = oracle.ILU0(nc, 1, osys.rowptr, osys.colidx, nz, partition=part)
+            else:
+                Fo.refactor(nz)
+            x, st = oracle.bicgstab(nc, 1, osys.rowptr, osys.colidx, nz, r, prec=Fo, side="right", rtol=1e-8, atol=1e-30, itmax=300)
+            assert st["solved"]
+            X = X - x
+        assert it == gpu_its[step], (step, it, gpu_its)
+        assert np.abs(gpu_states[step] - X).max() <= 1e-7 * np.abs(X).max()
+    assert max(gpu_its) >= 3        # genuinely nonlinear: more than one Newton update per time step
+
+
 def test_3M_cells_oracle_parity_where_the_defaults_switch(ja, oracle):
     """Oracle parity at a size where the library's defaults change code path: >= 3M rows -> 16-bit column codes in the jagged
     SpMV (no environment override), >= 2M cells -> 512-row bisection blocks, ~100 tiles per XCD chunk.  Assembly, jh_spmv,

@@ -325,22 +325,23 @@ def test_ilu0_factor_and_apply_parity(ja, ctx, oracle, bs, mode):
         part = oracle.partition_linear(6, nc)
     elif mode == "partition_scattered":
         part = rng.integers(1, 5, nc)
+    from tests import _ilu_checks as ck
     A = ja.StaticSparsityMatrixCSR(context=ctx, n=nc, bs=bs, rowptr=rowptr, colidx=colidx, nzval=nz)
     F = ja.ilu0_csr(A, part)
-    Fo = oracle.ILU0(nc, bs, rowptr, colidx, nz, partition=part)
-    lu_o = Fo.export(nz.size)
-    lu = F.factor_values()
-    # entries outside every block are not part of the factor: compare only those the oracle wrote
-    mask = lu_o != 0
-    assert relerr(lu[mask], lu_o[mask]) < 1e-11
+    info = F.info()
+    # factor values entry by entry against the size of each entry's own terms, the solve as a componentwise backward error with
+    # the oracle's factors (tests/_ilu_checks.py) -- nothing scaled by the largest entry of an array
+    Fo, lu_o, Lm, Um = ck.oracle_factors(oracle, nc, bs, rowptr, colidx, nz, part)
+    ck.check_factor_values(F.factor_values(), lu_o, Lm, Um, nc, bs, rowptr, colidx)
     b = rng.standard_normal(nc * bs)
-    x = ja.ldiv_(A.new_vector(), F, A.new_vector(b))
-    assert relerr(x.download(), Fo.apply(b)) < 1e-10
-    # ilu0_csr!: refactor after the values change
+    x = ja.ldiv_(A.new_vector(), F, A.new_vector(b)).download()
+    ck.check_triangular_solve(x, b, Lm, Um, levels=info["max_levels"])
+    assert relerr(x, Fo.apply(b)) < 1e-10
+    # ilu0_csr!: refactor after the values change (a power of two: the factors scale exactly, the solve by its inverse)
     A.nzval = 2.0 * nz
     F.update_preconditioner(A)
-    assert relerr(ja.ldiv_(A.new_vector(), F, A.new_vector(b)).download(), 0.5 * Fo.apply(b)) < 1e-10
-    info = F.info()
+    x2 = ja.ldiv_(A.new_vector(), F, A.new_vector(b)).download()
+    ck.check_triangular_solve(2.0 * x2, b, Lm, Um, levels=info["max_levels"])
     assert info["nblocks"] == (1 if part is None else int(part.max()))
 
 
@@ -541,15 +542,18 @@ def _factor_kernel_case(ja, ctx, oracle, grid, bs, wave):
         F.update_preconditioner(A)
         info = F.info()
         assert info["jagged"] and info["factor_kernel"] == ("program" if grid == "triangles" else "pivot-only"), info
-        # oracle on the device-ordered scalar expansion is not needed: compare the action M^-1 b, which pins L, U and the pivots
-        Ab = sp.bsr_matrix((nzb, colidx - 1, rowptr - 1), shape=(nc * bs, nc * bs)).tocsr()
+        # the oracle in the device's elimination order: factor VALUES entry by entry (L multipliers, inverted pivots, U) and the
+        # triangular solve as a componentwise backward error with the oracle's factors (tests/_ilu_checks.py)
+        from tests import _ilu_checks as ck
+        nz_flat = nzb.transpose(0, 2, 1).reshape(-1)
+        rp_p, ci_p, nz_p, part_p, slot = ck.device_order_problem(nc, bs, rowptr, colidx, nz_flat, perm, bp)
+        Fo, lu_o, Lm, Um = ck.oracle_factors(oracle, nc, bs, rp_p, ci_p, nz_p, part_p)
+        ck.check_factor_values(F.factor_values().reshape(-1, bs * bs)[slot].reshape(-1), lu_o, Lm, Um, nc, bs, rp_p, ci_p)
         p0 = perm - 1
         pe = (p0[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
-        Ap = sp.bsr_matrix(Ab[pe][:, pe], blocksize=(bs, bs))
-        Ap.sort_indices()
-        Fo = oracle.ILU0(nc, bs, Ap.indptr + 1, Ap.indices + 1, np.ascontiguousarray(Ap.data.transpose(0, 2, 1)).reshape(-1), partition=part[p0])
         b = rng.standard_normal(nc * bs)
         x = F.apply(A.new_vector(), A.new_vector(b)).download()
+        ck.check_triangular_solve(x[pe], b[pe], Lm, Um, levels=info["max_levels"])
         assert relerr(x[pe], Fo.apply(b[pe])) < 1e-10, (grid, bs, trial)
 
 
@@ -1508,6 +1512,12 @@ def test_device_side_reports_and_per_variable_download(ja, ctx):
     dxh[5, 1] = np.nan                                                                    # check_increment: a non-finite entry shows in the sum
     dx.upload(dxh)
     assert not np.isfinite(law.increment_norm(dx)[1][0]) and np.isfinite(law.increment_norm(dx)[0][0])
+    assert np.isnan(law.increment_norm(dx)[1][1])      # ... and in the maximum (Julia's max propagates NaN, models.jl:955-965)
+    for lane in (0, 63, 64, nc - 1):                    # wherever it sits in its wavefront / workgroup
+        dxh[:, 1] = rng.standard_normal(nc)
+        dxh[lane, 1] = np.nan
+        dx.upload(dxh)
+        assert np.isnan(law.increment_norm(dx)[1][1]) and np.isfinite(law.increment_norm(dx)[0][1])
     L = _lib.load()
     out = np.empty(nc)
     check(L.jh_host_register(out.ctypes.data_as(C.c_void_p), out.nbytes))                # page-locked target, as JutulHIP.jl does for state0[k]

@@ -4,8 +4,10 @@ per cell: the best case of every layout heuristic):
     the dual graph -> the ILU(0) elimination updates off-diagonal entries (program-driven factor kernel), varying cell sizes;
   * the polyhedral median dual of such a mesh: ~15 faces per cell, rows of up to ~50 entries -> beyond the jagged layouts
     (CSR tile SpMV, row-major ILU kernels).
-Everything against the oracle through the C ABI: tables bit-exact, assembly / SpMV 1e-12 per row scale, block-Jacobi ILU(0)
-apply 1e-10, BiCGStab solution 1e-7."""
+Everything against the oracle through the C ABI, for the scalar compressible law and the 2x2-block two-phase law: tables
+bit-exact, assembly / SpMV 1e-12 per row scale, block-Jacobi ILU(0) FACTOR VALUES entry by entry against the size of each
+entry's own terms and the triangular solve as a componentwise backward error (tests/_ilu_checks.py), the Newton update through the
+true residual with the oracle's Jacobian."""
 import numpy as np
 import pytest
 
@@ -20,13 +22,16 @@ def ja():
 
 def run_family(ja, oracle, g, kind, expect):
     import scipy.sparse as sp
+    from tests import _ilu_checks as ck
     ctx = ja.HIPContext(0)
     nc, nf, N = g["nc"], g["nf"], g["N"]
+    bs = 2 if kind == "twophase" else 1
+    bb = bs * bs
     rng = np.random.default_rng(4)
     T = g["T"] / g["T"].mean()
     vol = g["volumes"] / g["volumes"].mean()
     gdz = ja.compute_face_gdz(N, g["cell_centroids"][2]) * 1e-3
-    disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, reorder="blocks")
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, block_n=bs, reorder="blocks")
     # ---- a-1..a-4: bit exact ---------------------------------------------------------------------------------------------------
     h = oracle.half_face_map(N, nc)
     c = disc.conn
@@ -39,55 +44,63 @@ def run_family(ja, oracle, g, kind, expect):
     # ---- a-5..a-9: assembly ----------------------------------------------------------------------------------------------------
     par = dict(rho0=(1.0, 0.8), compressibility=(1e-2, 2e-2), viscosity=(1.0, 2.0), p_ref=1.0)
     law = ja.ConservationLaw(disc, kind, **par)
-    X, X0 = rng.uniform(1.0, 2.0, nc), rng.uniform(1.0, 2.0, nc)
+    if bs == 1:
+        X, X0 = rng.uniform(1.0, 2.0, nc), rng.uniform(1.0, 2.0, nc)
+    else:   # (pressure, saturation) per cell
+        X = np.stack([rng.uniform(1.0, 2.0, nc), rng.uniform(0.2, 0.8, nc)]).T.reshape(-1)
+        X0 = np.stack([rng.uniform(1.0, 2.0, nc), rng.uniform(0.2, 0.8, nc)]).T.reshape(-1)
     law.set_face_trans(T)
     law.set_volumes(vol)
     law.set_face_gdz(gdz)
     law.set_state(X)
     law.set_state0(X0)
-    src_c, src_v = [5, nc - 3], [0.3, -0.3]
+    src_c = [5, nc - 3]
+    src_v = np.array([0.3, -0.3]) if bs == 1 else np.array([0.3, 0.1, -0.3, -0.1])
     law.set_sources(src_c, src_v)
     lsys = ja.LinearizedSystem(disc)
     dt = 0.5
     law.update_equation_and_linearized_system(dt, lsys.jac, lsys.r)
-    osys = oracle.TPFASystem(N, nc)
+    osys = oracle.TPFASystem(N, nc, bs)
     olaw = oracle.Law(kind, dt, rho0=par["rho0"], comp=par["compressibility"], mu=par["viscosity"], p_ref=par["p_ref"])
     nz_o, r_o = osys.assemble(olaw, X, X0, vol, T, gdz, src_c, src_v)
-    A = sp.csr_matrix((nz_o, oci - 1, orp - 1), shape=(nc, nc))
-    row_scale = np.asarray(abs(A).sum(axis=1)).ravel() * 2.5 + np.abs(r_o)      # |J| (|x| <= 2) + |r|: the size of a row's terms
-    assert np.all(np.abs(lsys.r.download() - r_o) <= 1e-12 * row_scale)
+    blocks = nz_o.reshape(-1, bs, bs).transpose(0, 2, 1)             # column-major blocks -> [row, col]
+    A = sp.bsr_matrix((blocks, oci - 1, orp - 1), shape=(nc * bs, nc * bs)).tocsr()
+    # |J| (|x| <= 2) + |r|: the size of a row's terms, per CELL (the largest of its equations)
+    row_scale = (np.asarray(abs(A).sum(axis=1)).ravel() * 2.5 + np.abs(r_o)).reshape(nc, bs).max(axis=1)
+    assert np.all(np.abs(lsys.r.download() - r_o) <= 1e-12 * np.repeat(row_scale, bs))
     nz = lsys.jac.nzval
-    assert np.all(np.abs(nz - nz_o) <= 1e-12 * np.repeat(row_scale, np.diff(orp)))
+    assert np.all(np.abs(nz - nz_o) <= 1e-12 * np.repeat(row_scale, np.diff(orp) * bb))
     # ---- a-10: SpMV ------------------------------------------------------------------------------------------------------------
     info = lsys.jac.spmv_info()
     assert info["jagged"] == expect["jagged_spmv"] and info["longest_row"] == expect["longest_row"], info
-    x = rng.standard_normal(nc)
+    x = rng.standard_normal(nc * bs)
     lsys.jac.nzval = nz_o
-    y_o = oracle.spmv(nc, 1, orp, oci, nz_o, x)
-    bound = 1e-13 * (abs(A) @ np.abs(x)) * max(8, expect["longest_row"])
+    y_o = oracle.spmv(nc, bs, orp, oci, nz_o, x)
+    bound = 1e-13 * (abs(A) @ np.abs(x)) * max(8, expect["longest_row"]) * bs
     xv = ja.DeviceVector(disc, x)
     y = ja.mul_(ja.DeviceVector(disc), lsys.jac, xv).download()
     assert np.all(np.abs(y - y_o) <= bound)
     if info["jagged"]:
         assert np.array_equal(ja.mul_(ja.DeviceVector(disc), lsys.jac, xv, jagged=True).download(), y)
-    # ---- a-11..a-13: block-Jacobi ILU(0) on the device blocks vs the oracle in the device's elimination order ----------------
+    # ---- a-11..a-13: block-Jacobi ILU(0) on the device blocks vs the oracle in the device's elimination order: the FACTOR VALUES
+    # entry by entry against the size of each entry's own terms, the triangular solve as a componentwise backward error with the
+    # oracle's factors (cell volumes over 8 decades: nothing here is scaled by the largest entry of an array) -----------------
     F = ja.ILUZeroPreconditioner(partition="blocks").update_preconditioner(lsys.jac)
     fi = F.info()
     assert fi["factor_kernel"] == expect["factor_kernel"] and fi["jagged"] == expect["jagged_ilu"], fi
     perm, bp = disc.ordering()
     p0 = perm - 1
-    part = np.zeros(nc, dtype=np.int64)
-    part[p0] = np.repeat(np.arange(1, len(bp)), np.diff(bp))
-    Ap = A[p0][:, p0].tocsr()
-    Ap.sort_indices()
-    Fo = oracle.ILU0(nc, 1, Ap.indptr + 1, Ap.indices + 1, Ap.data, partition=part[p0])
-    b = rng.standard_normal(nc)
-    xh = F.apply(lsys.jac.new_vector(), lsys.jac.new_vector(b)).download()[p0]
-    x_o = Fo.apply(b[p0])
-    assert np.abs(xh - x_o).max() <= 1e-10 * np.abs(x_o).max()
+    rp_p, ci_p, nz_p, part_p, slot = ck.device_order_problem(nc, bs, orp, oci, nz_o, perm, bp)
+    Fo, lu_o, Lm, Um = ck.oracle_factors(oracle, nc, bs, rp_p, ci_p, nz_p, part_p)
+    lu_dev = F.factor_values().reshape(-1, bb)[slot].reshape(-1)
+    w_f = ck.check_factor_values(lu_dev, lu_o, Lm, Um, nc, bs, rp_p, ci_p, c=64.0 * max(1, fi["max_levels"] // 16))
+    b = rng.standard_normal(nc * bs)
+    pe = (p0[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+    xh = F.apply(lsys.jac.new_vector(), lsys.jac.new_vector(b)).download()[pe]
+    w_s = ck.check_triangular_solve(xh, b[pe], Lm, Um, levels=fi["max_levels"])
     # ---- a-14: BiCGStab + primary update through the Newton step -----------------------------------------------------------------
     ks = ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"), relative_tolerance=1e-10,
-                          max_iterations=400)
+                          max_iterations=600)
     law.set_state(X)
     sim = ja.Simulator(law, ks)
     rep = sim.perform_step(dt, 1)
@@ -96,27 +109,30 @@ def run_family(ja, oracle, g, kind, expect):
     # contrast of these grids is ~1e8, so a bound on the error itself would be a statement about the grid)
     dxv = law.get_state() - X
     assert np.linalg.norm(A @ dxv + r_o) <= 5e-10 * np.linalg.norm(r_o)
-    return dict(its=int(rep.linear_iterations), blocks=fi["nblocks"], levels=fi["max_levels"],
-                kept=(fi["l_entries"] + fi["u_entries"]) / (A.nnz - nc))
+    return dict(its=int(rep.linear_iterations), blocks=fi["nblocks"], levels=fi["max_levels"], factor_eps=w_f, solve_eps=w_s,
+                kept=(fi["l_entries"] + fi["u_entries"]) / (oci.size - nc))
 
 
-def test_delaunay_tet_mesh_parity(ja, oracle):
+@pytest.mark.parametrize("kind", ["compressible", "twophase"])
+def test_delaunay_tet_mesh_parity(ja, oracle, kind):
     g = ja.delaunay_tet_mesh(32000, grading=2.0)                     # ~210k tets, cell volumes over 8 decades
     assert g["nc"] > 200_000
-    out = run_family(ja, oracle, g, "compressible",
-                     dict(longest_row=5, jagged_spmv=True, jagged_ilu=True, factor_kernel="program"))
+    out = run_family(ja, oracle, g, kind,
+                     dict(longest_row=5, jagged_spmv=kind != "twophase", jagged_ilu=True, factor_kernel="program"))
     assert out["kept"] > 0.6
 
 
-def test_polyhedral_dual_mesh_parity(ja, oracle):
+@pytest.mark.parametrize("kind", ["compressible", "twophase"])
+def test_polyhedral_dual_mesh_parity(ja, oracle, kind):
     g = ja.polyhedral_dual_mesh(30000, grading=1.5)                  # 30k cells, ~15 faces each
     deg = np.bincount(g["N"].reshape(-1), minlength=g["nc"] + 1)[1:]
     assert deg.max() > 16 and deg.mean() > 12
-    run_family(ja, oracle, g, "compressible",
+    run_family(ja, oracle, g, kind,
                dict(longest_row=int(deg.max()) + 1, jagged_spmv=False, jagged_ilu=False, factor_kernel="program"))
 
 
-def test_cartesian_mesh_parity(ja, oracle):
+@pytest.mark.parametrize("kind", ["compressible", "twophase"])
+def test_cartesian_mesh_parity(ja, oracle, kind):
     g = ja.cartesian_mesh(60, 60, 60)                                # 216k hexahedra, the reference's CartesianMesh: 6 faces per cell
-    run_family(ja, oracle, g, "compressible",
-               dict(longest_row=7, jagged_spmv=True, jagged_ilu=True, factor_kernel="pivot-only"))
+    run_family(ja, oracle, g, kind,
+               dict(longest_row=7, jagged_spmv=kind != "twophase", jagged_ilu=True, factor_kernel="pivot-only"))
