@@ -22,9 +22,17 @@ namespace {
 // exits; the buffers themselves live as long as the process (no runtime calls from thread-exit or process-exit destructors).
 struct Bounce {
   void *buf = nullptr;
-  static constexpr size_t CAP = (size_t)16 << 20;
+  hipEvent_t ev[2] = {nullptr, nullptr};  // "the DMA out of / into half i has finished"
+  static constexpr size_t CAP = (size_t)16 << 20, HALF = CAP / 2;
+  int ev_dev = -1;
   void ensure() {
     if (!buf) JH_HIP(hipHostMalloc(&buf, CAP, hipHostMallocPortable));  // usable with the streams of any device
+    int dev = 0;
+    JH_HIP(hipGetDevice(&dev));
+    if (dev != ev_dev) {  // events belong to a device: a thread that moves to another one gets new ones
+      for (auto &e : ev) { if (e) (void)hipEventDestroy(e); JH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+      ev_dev = dev;
+    }
   }
 };
 struct BouncePool {
@@ -72,12 +80,18 @@ void copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s) 
   }
   Bounce &B = bounce();
   B.ensure();
-  for (size_t off = 0; off < bytes; off += Bounce::CAP) {
-    const size_t len = std::min(Bounce::CAP, bytes - off);
-    std::memcpy(B.buf, (const char *)src_host + off, len);
-    JH_HIP(hipMemcpyAsync((char *)dst_dev + off, B.buf, len, hipMemcpyHostToDevice, s));
-    JH_HIP(hipStreamSynchronize(s));  // (the host copy dominates: 16 MB take ~2 ms to copy and 0.3 ms to transfer)
+  // two halves in alternation: the host fills one while the DMA engine drains the other (the host copy dominates -- 8 MB take
+  // ~1 ms to copy and 0.15 ms to transfer -- so this hides the transfers, not the copies)
+  int k = 0;
+  for (size_t off = 0; off < bytes; off += Bounce::HALF, k ^= 1) {
+    const size_t len = std::min(Bounce::HALF, bytes - off);
+    char *half = (char *)B.buf + (size_t)k * Bounce::HALF;
+    if (off >= 2 * Bounce::HALF) JH_HIP(hipEventSynchronize(B.ev[k]));  // the transfer that last read this half
+    std::memcpy(half, (const char *)src_host + off, len);
+    JH_HIP(hipMemcpyAsync((char *)dst_dev + off, half, len, hipMemcpyHostToDevice, s));
+    JH_HIP(hipEventRecord(B.ev[k], s));
   }
+  JH_HIP(hipStreamSynchronize(s));  // the caller may free or reuse its array when this returns
 }
 void copy_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s) {
   if (!bytes) return;
@@ -88,11 +102,19 @@ void copy_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s) 
   }
   Bounce &B = bounce();
   B.ensure();
-  for (size_t off = 0; off < bytes; off += Bounce::CAP) {
-    const size_t len = std::min(Bounce::CAP, bytes - off);
-    JH_HIP(hipMemcpyAsync(B.buf, (const char *)src_dev + off, len, hipMemcpyDeviceToHost, s));
-    JH_HIP(hipStreamSynchronize(s));
-    std::memcpy((char *)dst_host + off, B.buf, len);
+  // the transfer of chunk i+1 runs while the host copies chunk i out of the other half
+  const size_t nchunks = (bytes + Bounce::HALF - 1) / Bounce::HALF;
+  auto issue = [&](size_t i) {
+    const size_t off = i * Bounce::HALF, len = std::min(Bounce::HALF, bytes - off);
+    JH_HIP(hipMemcpyAsync((char *)B.buf + (i & 1) * Bounce::HALF, (const char *)src_dev + off, len, hipMemcpyDeviceToHost, s));
+    JH_HIP(hipEventRecord(B.ev[i & 1], s));
+  };
+  issue(0);
+  for (size_t i = 0; i < nchunks; ++i) {
+    JH_HIP(hipEventSynchronize(B.ev[i & 1]));
+    if (i + 1 < nchunks) issue(i + 1);  // (the other half: its previous contents were copied out in the last round)
+    const size_t off = i * Bounce::HALF, len = std::min(Bounce::HALF, bytes - off);
+    std::memcpy((char *)dst_host + off, (const char *)B.buf + (i & 1) * Bounce::HALF, len);
   }
 }
 }  // namespace jh

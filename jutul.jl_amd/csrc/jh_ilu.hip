@@ -65,6 +65,7 @@ struct jh_ilu_s {
   // ---- chunk-jagged layout (the performance path of the LDS mode, see ilu_apply_jds_kernel) ----------------------------------
   bool jag = false;      // l_val / u_val / dinv are stored in chunk-jagged order
   int jag_ku = 4;        // diagonals held in registers per sweep (4 or 8)
+  bool jag_vr = false;   // rows of more than 8 entries are chains of lanes (virtual rows)
   int64_t jl_nent = 0, ju_nent = 0, j_nslots = 0;  // jagged entry counts (+ padding), 64 * chunks
   std::vector<int32_t> chunk_ptr;                  // per block: first chunk; block b has ceil(rows/64) chunks per sweep
   std::vector<int32_t> jl_map, ju_map, jd_map;     // A slot of every jagged L / U entry and of every bwd lane's pivot (-1: no row)
@@ -670,7 +671,8 @@ __global__ void ilu_factor_prog_kernel(IluDev F, const double *__restrict__ aval
         const int j = j0 + u * T;
         if (j < count) {
 #pragma unroll
-          for (int e = 0; e < BB; ++e) vals[(size_t)(vbase + j) * BB + e] = m[u] >= 0 ? aval[(size_t)m[u] * BB + e] : 0.0;
+          for (int e = 0; e < BB; ++e)  // (-2: the unit pivot of a lane that does not finish its row, see the layout's virtual rows)
+            vals[(size_t)(vbase + j) * BB + e] = m[u] >= 0 ? aval[(size_t)m[u] * BB + e] : ((m[u] == -2 && e % (BS + 1) == 0) ? 1.0 : 0.0);
         }
       }
     }
@@ -1236,14 +1238,17 @@ __device__ __forceinline__ void jds_prefetch(const IluDev &F, int c0, int lane, 
 }
 // The levels of ONE chunk: the lane's row (cur) waits for its level, reads its operands from the block's vector in LDS, writes
 // its result there.
-template <int BS, int KU, bool BWD, bool SC, bool MUL>
+// VR: rows of more than 8 entries are chains of lanes (virtual rows, see the layout): a lane then reads its row's entry of the vector
+// when its own level comes up -- an earlier lane of the chain may have written a partial result there -- instead of at the start
+// of the chunk.
+template <int BS, int KU, bool BWD, bool SC, bool MUL, bool VR = false>
 __device__ __forceinline__ void jds_chunk(double *xs, int lane, const int4 &dc, const JRow<BS, KU> &cur, double *qq) {
   constexpr int BB = BS * BS;
   const int lt = (int)(cur.word & 0xffffu), lev = (int)(cur.word >> 16);
   const int lvlo = dc.w & 0xffff, lvhi = (int)((unsigned)dc.w >> 16);
   double v[BS], x0[BS];
 #pragma unroll
-  for (int e = 0; e < BS; ++e) { x0[e] = xs[lt * BS + e]; v[e] = (SC && BWD) ? 0.0 : x0[e]; }  // this row's entry: only the row itself ever writes it
+  for (int e = 0; e < BS; ++e) { x0[e] = VR ? 0.0 : xs[lt * BS + e]; v[e] = (SC && BWD) ? 0.0 : x0[e]; }  // this row's entry: only the row itself ever writes it
   // Entries the lane does not have (past a diagonal's count; diagonals the chunk does not have) become a zero coefficient times the
   // lane's own entry of the vector, ONCE per chunk: the level loop -- one VALU-bound step per dependency level, all wavefronts of
   // a SIMD in it together -- then is four multiply-subtracts, not four multiply-subtract-selects (v - 0 * x == v up to the sign
@@ -1266,6 +1271,10 @@ __device__ __forceinline__ void jds_chunk(double *xs, int lane, const int4 &dc, 
       // (skipping the reads of diagonals no row of the level has -- a ballot and a branch each -- was measured slower: 16.4k instead
       // of 11.0k cycles per forward sweep of a 256-row block)
       double xk[KU][BS];
+      if (VR) {
+#pragma unroll
+        for (int e = 0; e < BS; ++e) { x0[e] = xs[lt * BS + e]; v[e] = x0[e]; }
+      }
 #pragma unroll
       for (int j = 0; j < KU; ++j) {
 #pragma unroll
@@ -1324,7 +1333,7 @@ __device__ __forceinline__ void jds_chunk(double *xs, int lane, const int4 &dc, 
 // chunks in flight instead of the full drain the copy "A = B" below implies -- was SLOWER at every size (10M rows 187 vs 184 us per
 // launch, Cartesian 10M 222-242 vs 208 us, 1.25M rows 30.5 vs 29.9 us), two chunks ahead slower still: what a level step waits for
 // is the LDS round trip of its own dependency chain, not the entry stream.
-template <int BS, int KU, bool BWD, bool SC, bool MUL>
+template <int BS, int KU, bool BWD, bool SC, bool MUL, bool VR = false>
 __device__ __forceinline__ void jds_sweep(const IluDev &F, double *xs, int c0, int nch, int lane, const JPre<BS, KU> &P, double *qq = nullptr) {
   const int4 *desc = BWD ? F.jb_desc : F.jf_desc;
   JRow<BS, KU> A = P.cur, B;
@@ -1332,7 +1341,7 @@ __device__ __forceinline__ void jds_sweep(const IluDev &F, double *xs, int c0, i
   for (int c = 0; c < nch; ++c) {
     dnext = jds_desc(desc, c0 + c + 2);  // (the descriptor arrays are padded by four entries)
     if (c + 1 < nch) jds_load<BS, KU, BWD, SC, MUL>(F, dB, c0 + c + 1, lane, B);
-    jds_chunk<BS, KU, BWD, SC, MUL>(xs, lane, dA, A, qq);
+    jds_chunk<BS, KU, BWD, SC, MUL, VR>(xs, lane, dA, A, qq);
     dA = dB; dB = dnext;
     A = B;
   }
@@ -1402,7 +1411,7 @@ __device__ unsigned long long jh_apply_t[8 * 65536];
 #else
 #define JH_T(k) do { } while (0)
 #endif
-template <int BS, int GM, int KU, bool SC, int MUL>
+template <int BS, int GM, int KU, bool SC, int MUL, bool VR = false>
 __global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec, IluGather G, IluMul Q) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -1479,10 +1488,10 @@ __global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const doubl
   for (int t0 = 64 * GB; t0 < nr; t0 += 64 * GB) { gather_load(t0); gather_finish(t0); }
   JH_T(2);
   __syncthreads();
-  jds_sweep<BS, KU, false, SC, false>(F, xs, c0, nch, lane, pf);
+  jds_sweep<BS, KU, false, SC, false, VR>(F, xs, c0, nch, lane, pf);
   JH_T(3);
   if (!EARLY_BWD) jds_prefetch<BS, KU, true, SC, (MUL != 0)>(F, c0, lane, pb);
-  jds_sweep<BS, KU, true, SC, (MUL != 0)>(F, xs, c0, nch, lane, pb, MUL ? Q.q + (size_t)b0 * BS : nullptr);
+  jds_sweep<BS, KU, true, SC, (MUL != 0), VR>(F, xs, c0, nch, lane, pb, MUL ? Q.q + (size_t)b0 * BS : nullptr);
   JH_T(4);
   __syncthreads();
   if (MUL) {
@@ -1937,16 +1946,65 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     // one wavefront per small block keeps many blocks resident per CU (the level loop is latency-bound)
     M->threads = maxrows <= 1024 ? 64 : (maxrows <= 2048 ? 128 : 256);
     { const int t = (int)M->ctx->opt.ilu_threads; if (t == 64 || t == 128 || t == 256 || t == 512) M->threads = t; }
-    // ---- chunk-jagged layout (ilu_apply_jds_kernel): per sweep and 64-row chunk, lanes sorted by entry count, entries stored
-    // diagonal by diagonal.  Needs block-local 16-bit ids and at most 8 strict-L / strict-U entries per row.
+    // ---- chunk-jagged layout (ilu_apply_jds_kernel): per sweep and 64-lane chunk, lanes sorted by entry count, entries stored
+    // diagonal by diagonal.  Needs block-local 16-bit ids; a lane carries at most 8 entries.
+    // VIRTUAL ROWS (round 4): a row with more than 8 strict-L (strict-U) entries -- polyhedral / PEBI cells -- becomes a chain of
+    // lanes of at most 8 entries each, in column order.  Every lane of the chain reads the row's entry of the block vector when its
+    // own level comes up, subtracts its entries and writes the partial result back; the chain's last lane is the row's result
+    // (backward: times the inverted pivot; the other lanes carry a unit pivot).  A lane's level = 1 + the latest of its operands'
+    // final levels and of its predecessor in the chain, so the arithmetic is the row's left-to-right sum (mat.jl / ilu0.jl:156-187
+    // order): the same bits as the row-major sweep.  Rows of at most 8 entries are chains of one lane with their old level.
+    struct VRow { int32_t p, first, level; uint8_t n, final; };
+    int maxcnt = 0;
+    for (int64_t t = 0; t < n; ++t) maxcnt = std::max({maxcnt, M->l_ptr[t + 1] - M->l_ptr[t], M->u_ptr[t + 1] - M->u_ptr[t]});
+    const bool VR = maxcnt > 8;
+    // lanes of block b in sweep order, sorted by level (stable); done: scratch of the block's row count
+    auto build_vrows = [&](int64_t b, int sweep, std::vector<VRow> &out, std::vector<int32_t> &done) {
+      const int32_t b0 = M->blk_ptr[b], b1 = M->blk_ptr[b + 1];
+      const std::vector<int32_t> &ptr = sweep ? M->u_ptr : M->l_ptr, &ocol = sweep ? M->u_col : M->l_col;
+      out.clear();
+      if (!VR) {
+        for (int32_t p = b0; p < b1; ++p)
+          out.push_back(VRow{p, ptr[p], sweep ? (int32_t)M->u_lev[p] : (int32_t)M->l_lev[p], (uint8_t)(ptr[p + 1] - ptr[p]), 1});
+        return;
+      }
+      done.assign((size_t)(b1 - b0), 0);
+      for (int32_t p = b0; p < b1; ++p) {  // sweep order: the operands of a row come before it
+        const int32_t lt = sweep ? M->u_row[p] : p - b0, cnt = ptr[p + 1] - ptr[p];
+        if (cnt == 0) { out.push_back(VRow{p, ptr[p], 0, 0, 1}); done[lt] = 0; continue; }
+        int32_t lprev = -1;
+        for (int32_t f = 0; f < cnt; f += 8) {
+          const int32_t m = std::min(8, cnt - f);
+          int32_t lv = lprev + 1;
+          for (int32_t e = 0; e < m; ++e) lv = std::max(lv, done[ocol[ptr[p] + f + e]] + 1);
+          out.push_back(VRow{p, ptr[p] + f, lv, (uint8_t)m, (uint8_t)(f + m == cnt)});
+          lprev = lv;
+        }
+        done[lt] = lprev;
+      }
+      std::stable_sort(out.begin(), out.end(), [](const VRow &a, const VRow &c) { return a.level < c.level; });
+    };
     if (lds && M->threads == 64 && maxrows < 65536 && maxlev < 0xffff && M->ctx->opt.ilu_jagged) {
-      int maxcnt = 0;
-      for (int64_t t = 0; t < n; ++t) maxcnt = std::max({maxcnt, M->l_ptr[t + 1] - M->l_ptr[t], M->u_ptr[t + 1] - M->u_ptr[t]});
-      if (maxcnt <= 8) {
+      bool jag_ok = true;
+      {
         M->jag = true;
+        M->jag_vr = VR;
         M->jag_ku = maxcnt <= 4 ? 4 : 8;
         M->chunk_ptr.assign(nb + 1, 0);
-        for (int64_t b = 0; b < nb; ++b) M->chunk_ptr[b + 1] = M->chunk_ptr[b] + (M->blk_ptr[b + 1] - M->blk_ptr[b] + 63) / 64;
+        if (!VR) {
+          for (int64_t b = 0; b < nb; ++b) M->chunk_ptr[b + 1] = (M->blk_ptr[b + 1] - M->blk_ptr[b] + 63) / 64;
+        } else {  // the longer of the two sweeps' lane lists decides (the shorter one is padded with empty lanes)
+          parallel_ranges(nb, 16, [&](int64_t bb0, int64_t bb1) {
+            std::vector<VRow> v;
+            std::vector<int32_t> done;
+            for (int64_t b = bb0; b < bb1; ++b) {
+              size_t m = 0;
+              for (int sweep = 0; sweep < 2; ++sweep) { build_vrows(b, sweep, v, done); m = std::max(m, v.size()); }
+              M->chunk_ptr[b + 1] = (int32_t)((m + 63) / 64);
+            }
+          });
+        }
+        for (int64_t b = 0; b < nb; ++b) M->chunk_ptr[b + 1] += M->chunk_ptr[b];
         const int64_t nchunks = M->chunk_ptr[nb];
         M->j_nslots = nchunks * 64;
         std::vector<int4> fdesc(nchunks + 4, make_int4(0, 0, 0, 0)), bdesc(nchunks + 4, make_int4(0, 0, 0, 0));  // + 4: read ahead
@@ -1968,16 +2026,19 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         parallel_ranges(nb, 16, [&](int64_t bb0, int64_t bb1) {
           int lanes[64];
           std::vector<uint16_t> code;
+          std::vector<VRow> vrows[2];
+          std::vector<int32_t> done;
           for (int64_t b = bb0; b < bb1; ++b) {
             const int32_t b0 = M->blk_ptr[b], b1 = M->blk_ptr[b + 1], nrb = b1 - b0;
             int32_t wpos[2] = {M->blk_lbase[b], M->blk_ubase[b]};  // running jagged position of the forward / backward sweep
+            for (int sweep = 0; sweep < 2; ++sweep) build_vrows(b, sweep, vrows[sweep], done);
             for (int32_t c = 0; c < M->chunk_ptr[b + 1] - M->chunk_ptr[b]; ++c) {
               const int64_t ch = M->chunk_ptr[b] + c;
-              const int32_t p0 = b0 + 64 * c, nrc = std::min(64, b1 - p0);
               for (int sweep = 0; sweep < 2; ++sweep) {
-                const std::vector<int32_t> &ptr = sweep ? M->u_ptr : M->l_ptr;
+                const std::vector<VRow> &vr = vrows[sweep];
+                const int32_t v0 = 64 * c, nrc = std::max(0, std::min<int32_t>(64, (int32_t)vr.size() - v0));
                 std::iota(lanes, lanes + nrc, 0);
-                std::stable_sort(lanes, lanes + nrc, [&](int a, int c2) { return ptr[p0 + a + 1] - ptr[p0 + a] > ptr[p0 + c2 + 1] - ptr[p0 + c2]; });
+                std::stable_sort(lanes, lanes + nrc, [&](int a, int c2) { return vr[v0 + a].n > vr[v0 + c2].n; });
                 std::vector<uint16_t> &jc = sweep ? juc : jlc;
                 std::vector<int32_t> &jm = sweep ? M->ju_map : M->jl_map;
                 std::vector<int32_t> &jold = sweep ? M->ju_of_old : M->jl_of_old;
@@ -1989,9 +2050,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
                 for (int j = 0; j < 8; ++j) {
                   int cn = 0;
                   for (int l = 0; l < nrc; ++l) {
-                    const int32_t p = p0 + lanes[l];
-                    if (ptr[p + 1] - ptr[p] <= j) break;  // sorted by count
-                    const int32_t old = ptr[p] + j;
+                    const VRow &v = vr[v0 + lanes[l]];
+                    if ((int)v.n <= j) break;  // sorted by count
+                    const int32_t old = v.first + j;
                     jold[old] = w;
                     jc[w] = (uint16_t)ocol[old];
                     jm[w] = omap[old];
@@ -2003,12 +2064,18 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
                 D.y = (int)cw[0]; D.z = (int)cw[1];
                 int lo = 0xffff, hi = 0;
                 for (int l = 0; l < nrc; ++l) {
-                  const int32_t p = p0 + lanes[l];  // ilu row (forward) or U-order position (backward)
-                  const int lv = sweep ? (int)M->u_lev[p] : (int)M->l_lev[p];
+                  const VRow &v = vr[v0 + lanes[l]];
+                  const int32_t p = v.p;  // ilu row (forward) or U-order position (backward)
+                  const int lv = v.level;
+                  if (lv >= 0xffff) { blk_ok[b] = 0; continue; }
                   const int lt = sweep ? M->u_row[p] : p - b0;
                   (sweep ? brow : frow)[ch * 64 + l] = (uint32_t)lt | ((uint32_t)lv << 16);
                   lo = std::min(lo, lv); hi = std::max(hi, lv);
-                  if (sweep) { M->jd_map[ch * 64 + l] = M->d_map[p]; M->jd_of_old[p] = (int32_t)(ch * 64 + l); }
+                  if (sweep) {
+                    // the pivot slot of a row = the backward lane that finishes it; the other lanes of a chain carry a unit pivot (-2)
+                    if (v.final) { M->jd_map[ch * 64 + l] = M->d_map[p]; M->jd_of_old[p] = (int32_t)(ch * 64 + l); }
+                    else M->jd_map[ch * 64 + l] = -2;
+                  }
                 }
                 D.w = (int)((unsigned)lo | ((unsigned)hi << 16));
                 (sweep ? bdesc : fdesc)[ch] = D;
@@ -2023,7 +2090,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
             prog.assign(2 * (size_t)nrb + 1, 0);  // row offsets (nrb + 1), pivot indices (nrb)
             code.clear();
             auto didx = [&](int32_t t) { return (uint16_t)(nl + nu + (M->jd_of_old[M->upos_of[t]] - dslot0)); };  // t: ilu row
-            for (int32_t c = 0; c < M->chunk_ptr[b + 1] - M->chunk_ptr[b]; ++c)  // pivot slot / backward lane of every forward lane
+            for (int32_t c = 0; c < M->chunk_ptr[b + 1] - M->chunk_ptr[b] && !VR; ++c)  // pivot slot / backward lane of every forward lane (pivot-only kernels)
               for (int l = 0; l < 64; ++l) {
                 const size_t fs = (size_t)(M->chunk_ptr[b] + c) * 64 + l;
                 if ((frow[fs] >> 16) == 0xffffu) continue;
@@ -2081,7 +2148,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
           }
           M->blk_prog[nb] = (int32_t)total;
           {
-            bool all_diag = ok;
+            bool all_diag = ok && !VR;  // (the pivot-only kernels take one lane per row)
             int mxc = 0;
             for (int64_t b = 0; b < nb; ++b) { all_diag = all_diag && blk_diag[b]; mxc = std::max(mxc, M->chunk_ptr[b + 1] - M->chunk_ptr[b]); }
             M->max_chunks = mxc;
@@ -2194,7 +2261,11 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         JH_HIP(hipMemsetAsync(M->jl_val.p, 0, M->jl_val.n * sizeof(double), sj));
         JH_HIP(hipMemsetAsync(M->ju_val.p, 0, M->ju_val.n * sizeof(double), sj));
         JH_HIP(hipMemsetAsync(M->jdinv.p, 0, M->jdinv.n * sizeof(double), sj));
-      } else if (M->ctx->opt.ilu_prog) {
+        // chains of lanes need the unit pivots the program kernel writes: without a program (a block beyond its 16-bit indices or
+        // the LDS) long rows keep the row-major sweeps
+        if (VR && !M->prog) { M->jag = false; M->jag_vr = false; jag_ok = false; }
+      }
+      if (!jag_ok && M->ctx->opt.ilu_prog) {
         // Rows with more than 8 strict-L / strict-U entries (polyhedral / PEBI cells): no jagged layout, the triangular sweeps keep
         // the row-major kernels -- but the refactorisation still runs program-driven (ilu_factor_prog_kernel over the row-major
         // arrays: value index = old entry position, pivot slot = U-order position).  The per-row factor kernels it replaces
@@ -2382,9 +2453,11 @@ static void ilu_apply_jagged(jh_ilu M, IluDev F, const double *b, double *x, con
   hipStream_t s = M->ctx->stream;
   if (mul && !M->uscaled) JH_THROW("fused product needs column-scaled factors");
 #define JH_J(BSV, GMV, KUV, SCV, MULV) hipLaunchKernelGGL((ilu_apply_jds_kernel<BSV, GMV, KUV, SCV, MULV>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x, G, Q)
+#define JH_JV(BSV, GMV) hipLaunchKernelGGL((ilu_apply_jds_kernel<BSV, GMV, 8, false, 0, true>), dim3((unsigned)nb), dim3(64), M->lds_bytes, s, F, b, x, G, Q)
 #define JH_JM(BSV, GMV, KUV)                                                                          \
   do {                                                                                                 \
-    if (!M->uscaled) JH_J(BSV, GMV, KUV, false, 0);                                                    \
+    if (M->jag_vr) JH_JV(BSV, GMV);                                                                    \
+    else if (!M->uscaled) JH_J(BSV, GMV, KUV, false, 0);                                               \
     else if (mul == 0) JH_J(BSV, GMV, KUV, true, 0);                                                   \
     else if (mul == 1) JH_J(BSV, GMV, KUV, true, 1);                                                   \
     else if (mul == 2) JH_J(BSV, GMV, KUV, true, 2);                                                   \
@@ -2399,6 +2472,7 @@ static void ilu_apply_jagged(jh_ilu M, IluDev F, const double *b, double *x, con
   }
 #undef JH_JK
 #undef JH_JM
+#undef JH_JV
 #undef JH_J
 }
 void ilu_factor(jh_ilu M) {
@@ -2457,11 +2531,16 @@ void ilu_factor(jh_ilu M) {
       return;
     }
     const int pthreads = (int)ctx->opt.ilu_factor_threads;
+    // long rows (chains of lanes in the layout): a wavefront per row, its lanes on the update pairs of one multiplier
+    const bool wprj = M->jag_vr && ctx->opt.ilu_factor_wave_per_row != 0;
 #define JH_PROG(BSV)                                                                                                             \
     do {                                                                                                                          \
       if (M->prog_lds_bytes > 64 * 1024)                                                                                          \
-        JH_HIP(hipFuncSetAttribute((const void *)ilu_factor_prog_kernel<BSV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes)); \
-      hipLaunchKernelGGL((ilu_factor_prog_kernel<BSV, false>), dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
+        JH_HIP(hipFuncSetAttribute(wprj ? (const void *)ilu_factor_prog_kernel<BSV, true> : (const void *)ilu_factor_prog_kernel<BSV, false>, \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes));                         \
+      if (wprj) hipLaunchKernelGGL((ilu_factor_prog_kernel<BSV, true>), dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
+                         M->d_blk_ubase.p, M->d_blk_prog.p, M->d_jl_map.p, M->d_ju_map.p, M->d_jd_map.p, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p); \
+      else hipLaunchKernelGGL((ilu_factor_prog_kernel<BSV, false>), dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
                          M->d_blk_ubase.p, M->d_blk_prog.p, M->d_jl_map.p, M->d_ju_map.p, M->d_jd_map.p, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p); \
     } while (0)
     switch (M->bs) { case 1: JH_PROG(1); break; case 2: JH_PROG(2); break; case 3: JH_PROG(3); break; }

@@ -128,7 +128,7 @@ def test_polyhedral_dual_mesh_parity(ja, oracle, kind):
     deg = np.bincount(g["N"].reshape(-1), minlength=g["nc"] + 1)[1:]
     assert deg.max() > 16 and deg.mean() > 12
     run_family(ja, oracle, g, kind,
-               dict(longest_row=int(deg.max()) + 1, jagged_spmv=False, jagged_ilu=False, factor_kernel="program"))
+               dict(longest_row=int(deg.max()) + 1, jagged_spmv=False, jagged_ilu=True, factor_kernel="program"))   # ILU: chains of lanes
 
 
 @pytest.mark.parametrize("kind", ["compressible", "twophase"])
