@@ -371,21 +371,41 @@ function convergence_criterion(model::HIPModel, storage, eq::ConservationLaw, s:
 end
 
 # ---- preconditioner (seams: update_preconditioner!, precond/ilu.jl:37; apply!, :62) -----------------------------------
-mutable struct HIPILUZero <: Jutul.JutulPreconditioner
+abstract type HIPPreconditioner <: Jutul.JutulPreconditioner end
+mutable struct HIPILUZero <: HIPPreconditioner       # ILUZeroPreconditioner (precond/ilu.jl:4-14): block-Jacobi ILU(0) over the device blocks
     handle::Handle
     dim
     HIPILUZero() = new(C_NULL, nothing)
 end
-function update_preconditioner!(p::HIPILUZero, s::HIPConservationLawStorage, b, context::HIPContext, executor)
+mutable struct HIPJacobi <: HIPPreconditioner        # JacobiPreconditioner(w) (precond/jacobi.jl:5-18)
+    handle::Handle
+    dim
+    w::Float64
+    HIPJacobi(; w = 1.0) = new(C_NULL, nothing, w)
+end
+mutable struct HIPSPAI0 <: HIPPreconditioner         # SPAI0Preconditioner (precond/spai.jl:40-60)
+    handle::Handle
+    dim
+    HIPSPAI0() = new(C_NULL, nothing)
+end
+function hip_preconditioner_create!(p::HIPILUZero, s::HIPConservationLawStorage)
+    h = Ref{Handle}(C_NULL)
+    @jh :jh_ilu0_create (Handle, Ptr{Int64}, Int64, Ref{Handle}) s.jac C_NULL -1 h   # device blocks
+    return h[]
+end
+function hip_preconditioner_create!(p::Union{HIPJacobi, HIPSPAI0}, s::HIPConservationLawStorage)
+    h = Ref{Handle}(C_NULL)
+    @jh :jh_diag_precond_create (Handle, Int32, Float64, Ref{Handle}) s.jac Int32(p isa HIPJacobi ? 1 : 2) Float64(p isa HIPJacobi ? p.w : 1.0) h
+    return h[]
+end
+function update_preconditioner!(p::HIPPreconditioner, s::HIPConservationLawStorage, b, context::HIPContext, executor)
     if p.handle == C_NULL
-        h = Ref{Handle}(C_NULL)
-        @jh :jh_ilu0_create (Handle, Ptr{Int64}, Int64, Ref{Handle}) s.jac C_NULL -1 h   # device blocks
-        p.handle = h[]
+        p.handle = hip_preconditioner_create!(p, s)
         p.dim = (s.nc * s.N, s.nc * s.N)
     end
-    @jh :jh_ilu0_factor (Handle,) p.handle
+    @jh :jh_ilu0_factor (Handle,) p.handle        # update_preconditioner! of every kind (jutul_hip.h: jh_diag_precond_create)
 end
-operator_nrows(p::HIPILUZero) = p.dim[1]
+operator_nrows(p::HIPPreconditioner) = p.dim[1]
 
 # ---- linear solve (seam: linear_solve!, linsolve/krylov.jl:71-85) -------------------------------------------------------
 mutable struct HIPKrylov
@@ -403,7 +423,7 @@ function linear_solve!(sys::HIPLinearizedSystem, krylov::GenericKrylov, context:
     if krylov.scaling != :none      # krylov_scale_system! (krylov.jl:194; default.jl:325-385)
         @jh :jh_scale_system (Handle, Handle, Int32, Float64) s.jac s.r Int32(krylov.scaling == :diagonal ? 1 : 2) Float64(isnothing(dt) ? 1.0 : dt)
     end
-    prec = krylov.preconditioner::HIPILUZero
+    prec = krylov.preconditioner::HIPPreconditioner   # HIPILUZero / HIPJacobi / HIPSPAI0
     t_prec = @elapsed update_preconditioner!(prec, s, nothing, context, executor)
     ws = krylov.storage
     if !(ws isa HIPKrylov)

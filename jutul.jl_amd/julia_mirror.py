@@ -176,9 +176,13 @@ class JuliaMirror:
     def update_preconditioner(self, prec, s):
         with self._fn("update_preconditioner!"):
             if not prec.get("handle"):
-                h = H()
-                check(self.L.jh_ilu0_create(s.jac, None, -1, C.byref(h)))
-                prec["handle"] = h
+                with self._fn("hip_preconditioner_create!"):   # HIPILUZero (kind None) / HIPJacobi (1, w) / HIPSPAI0 (2)
+                    h = H()
+                    if prec.get("kind"):
+                        check(self.L.jh_diag_precond_create(s.jac, int(prec["kind"]), float(prec.get("w", 1.0)), C.byref(h)))
+                    else:
+                        check(self.L.jh_ilu0_create(s.jac, None, -1, C.byref(h)))
+                    prec["handle"] = h
             check(self.L.jh_ilu0_factor(prec["handle"]))
 
     # ---- linear_solve! (linsolve/krylov.jl:71-182) ------------------------------------------------------------------------------
