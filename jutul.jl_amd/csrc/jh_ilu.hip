@@ -1480,10 +1480,11 @@ __global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const doubl
       }
     }
   };
-  gather_load(0);
+  if (GM != 2) gather_load(0);  // (GM 2: after the partial sums, whose registers it then reuses: 6 instead of 5 wavefronts per SIMD)
   if (!apply_prologue<GM>(G, pr, ca, cb)) return;
   if (GM == 0 && MUL && G.done && *G.done != 0.0) return;
   JH_T(1);
+  if (GM == 2) gather_load(0);
   gather_finish(0);
   for (int t0 = 64 * GB; t0 < nr; t0 += 64 * GB) { gather_load(t0); gather_finish(t0); }
   JH_T(2);
