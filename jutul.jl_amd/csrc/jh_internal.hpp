@@ -185,7 +185,7 @@ struct Comm;  // RCCL state (jh_comm.cpp)
   X(spmv_jagged, 1)           /* Krylov loop multiplies out of the jagged-slice copy when the matrix has one */               \
   X(spmv_col_bits, 0)         /* jagged column ids: 16 / 32, 0 = by size (16 from 3M rows) */                                  \
   X(spmv_waves_per_xcd, 0)    /* persistent wavefronts per XCD of the SpMV kernels, 0 = what is resident at once */            \
-  X(spmv_waves, 0)            /* wavefronts per workgroup of the jagged SpMV: 4 / 8 / 16, 0 = 4, or 16 with consumer_reduce */ \
+  X(spmv_waves, 0)            /* wavefronts per workgroup of the jagged SpMV in the Krylov loop: 4 / 8 / 16, 0 = 16 */           \
   X(spmv_window, 1)           /* CSR tile SpMV: LDS window of x */                                                             \
   X(spmv_pipe, 1)             /* CSR tile SpMV with a fused dot: software-pipelined variant */                                 \
   X(sync_loop, 0)             /* 1: the host waits for iteration k before enqueueing k+1 (no speculative iteration) */         \

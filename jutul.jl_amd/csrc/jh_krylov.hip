@@ -339,7 +339,10 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   // the producers run with larger workgroups so that a full-chip launch leaves at most PEND_MAX partials.
   const bool pend_ok = ctx->opt.consumer_reduce && !fmul && jagged && right && ilu_can_fuse_gather(M) && !dist && comm_size(ctx) == 1;
   PendSum pend_spmv;  // partials of the last product with a fused dot
-  const int spmv_waves = ctx->opt.spmv_waves ? (int)ctx->opt.spmv_waves : (pend_ok ? 16 : 4);
+  // 16 wavefronts per workgroup: <= 512 partials for the consumers above, and the faster product at every size measured (10M rows
+  // 0.160 vs 0.174-0.182 ms with 4, one workgroup per CU; 1.25M rows 26.1 vs 27.4 us) -- also where the dots still go through the
+  // reduction launch (several ranks)
+  const int spmv_waves = ctx->opt.spmv_waves ? (int)ctx->opt.spmv_waves : 16;
   auto spmv = [&](double *in, double *out, const SpmvDot *dot, bool packed = false) {
     if (dist) halo_exchange(disc, in, P.bs, packed, true);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
     K->mark(0, st);

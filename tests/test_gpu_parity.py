@@ -1528,3 +1528,27 @@ def test_device_side_reports_and_per_variable_download(ja, ctx):
                 assert np.array_equal(out, ref[:, e])
     finally:
         check(L.jh_host_unregister(out.ctypes.data_as(C.c_void_p)))
+
+
+def test_context_options_api(ja):
+    """jh_context_set_option / jh_context_get_option: named integer options per context (the keyword arguments of the reference's
+    contexts and solver set-up, contexts/csr.jl:3-23); unknown keys are errors; JH_OPTIONS seeds new contexts."""
+    import os
+    c = ja.HIPContext(0, consumer_reduce=0, spmv_col_bits=16)
+    assert c.get_option("consumer_reduce") == 0 and c.get_option("spmv_col_bits") == 16 and c.get_option("fuse_gather") == 1
+    c.set_option("consumer_reduce", 1)
+    assert c.get_option("consumer_reduce") == 1
+    with pytest.raises(ja.JutulHIPError, match="unknown option"):
+        c.set_option("no_such_option", 1)
+    with pytest.raises(ja.JutulHIPError, match="unknown option"):
+        c.get_option("no_such_option")
+    assert ja.HIPContext(0).get_option("consumer_reduce") == 1          # per context, not per process
+    os.environ["JH_OPTIONS"] = "sync_loop=1,comm_timeout_ms=2500"
+    try:
+        d = ja.HIPContext(0)
+        assert d.get_option("sync_loop") == 1 and d.get_option("comm_timeout_ms") == 2500
+        os.environ["JH_OPTIONS"] = "bogus=1"
+        with pytest.raises(ja.JutulHIPError, match="unknown option"):
+            ja.HIPContext(0)
+    finally:
+        os.environ.pop("JH_OPTIONS", None)
