@@ -56,7 +56,9 @@ int32_t jh_synchronize(jh_context ctx); /* synchronize(ctx), context.jl:72 */
  *   halo_overlap (0), fused_pack (1), comm_timeout_ms (600000; 0 = wait like a collective)
  *   fused_product (0), fuse_gather (1)
  *   ilu_jagged (1), ilu_threads (0), ilu_factor_kernel (-1 = by pattern | 0 workgroup | 1 wavefront per block),
- *   ilu_factor_threads (512), ilu_factor_wave_per_row (1), ilu_diag_factor (1), ilu_prog (1), ilu_factor_global (0)
+ *   ilu_factor_threads (0 = 512; rows-form programs 256), ilu_diag_factor (1), ilu_prog (1), ilu_factor_global (0),
+ *   ilu_factor_wave_per_row (long rows; read when the preconditioner is created: 1 = rows-form programs (scalar matrices) | 2 = instruction-form
+ *                            programs, wavefront per row | 0 = thread per row)
  *   asm_pipe (1), asm_pipe2_wgs (0), block_order (0 bisection | 1 onion)
  *   read_sync (0), setup_timing (0), jds_keep (0) */
 int32_t jh_context_set_option(jh_context ctx, const char *key, int64_t value);
@@ -255,7 +257,8 @@ int32_t jh_ilu0_info(jh_ilu M, int64_t *nblocks, int64_t *max_block_rows, int64_
  * [2] execution blocks, [3] kernel selection: bit 0 = LDS (block-Jacobi) kernels (0: level-per-launch kernels), bit 1 = chunk-jagged
  * layout, bit 2 = program-driven refactorisation available, bit 3 = pivot-only refactorisation in use (no elimination step
  * updates an off-diagonal entry: triangle-free block patterns), bit 4 = the product A*x is fused into the apply of the Krylov loop
- * (jh_ilu0_apply_mul) */
+ * (jh_ilu0_apply_mul), bit 5 = the programs are in the rows form (long rows of scalar matrices: a wavefront per row, the row in
+ * registers) */
 int32_t jh_ilu0_stats(jh_ilu M, int64_t *stats4);
 
 /* DiagonalPreconditioner family (precond/diagonal.jl): kind 1 = JacobiPreconditioner(w) D_i = w*inv(A_ii)

@@ -561,7 +561,7 @@ class ILUZeroPreconditioner(_Handle):
         check(_L().jh_ilu0_stats(self.h, pi(st)))
         return dict(nblocks=a.value, max_block_rows=b.value, max_levels=c.value, l_entries=int(st[0]),
                     u_entries=int(st[1]), exec_blocks=int(st[2]), lds_mode=bool(st[3] & 1), jagged=bool(st[3] & 2),
-                    factor_kernel="pivot-only" if st[3] & 8 else ("program" if st[3] & 4 else "generic"),
+                    factor_kernel="pivot-only" if st[3] & 8 else (("program, rows form" if st[3] & 32 else "program") if st[3] & 4 else "generic"),
                     fused_product=bool(st[3] & 16))
 
 

@@ -106,6 +106,7 @@ struct jh_ilu_s {
   DevBuf<int32_t> d_blk_lbase, d_blk_ubase, d_blk_prog, d_blk_dbase;
   DevBuf<uint16_t> d_prog;
   size_t prog_lds_bytes = 0;
+  bool prog_rows = false;  // the program is in the rows form (ilu_factor_rows_kernel)
   int prog_max_vals = 0, prog_max_words = 0;
 };
 
@@ -639,6 +640,41 @@ __global__ __launch_bounds__(64) void ilu_factor_wave_kernel(IluDev F, const dou
   ucopy(u0, u0 + nu);
 }
 
+// Development build (-DJH_APPLY_TIMING, tools/apply_timing.py): shader-clock stamps of the phases of every block's wavefront.
+#ifdef JH_APPLY_TIMING
+__device__ unsigned long long jh_apply_t[8 * 65536];
+#define JH_T(k) do { if (threadIdx.x == 0 && blockIdx.x < 65536) jh_apply_t[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define JH_T(k) do { } while (0)
+#endif
+#ifdef JH_APPLY_TIMING
+#define JH_TV(k, v) do { if (threadIdx.x == 0 && blockIdx.x < 65536) jh_apply_t[blockIdx.x * 8 + (k)] = (v); } while (0)
+#else
+#define JH_TV(k, v) do { } while (0)
+#endif
+// gather of a block's factor entries through a map into LDS, four entries per thread at a time: the map loads, then the dependent
+// value loads, are in flight together (one entry per thread and iteration leaves the block waiting on two memory latencies per
+// 128 entries; deeper than four does not help: measured)
+template <int BS>
+__device__ __forceinline__ void prog_gather(double *vals, const double *__restrict__ aval, const int32_t *__restrict__ map, int first,
+                                            int count, int vbase, int tid, int T) {
+  constexpr int BB = BS * BS;
+  for (int j0 = tid; j0 < count; j0 += 4 * T) {
+    int m[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int j = j0 + u * T; m[u] = j < count ? map[first + j] : -1; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * T;
+      if (j < count) {
+#pragma unroll
+        for (int e = 0; e < BB; ++e)  // (-2: the unit pivot of a lane that does not finish its row, see the layout's virtual rows)
+          vals[(size_t)(vbase + j) * BB + e] = m[u] >= 0 ? aval[(size_t)m[u] * BB + e] : ((m[u] == -2 && e % (BS + 1) == 0) ? 1.0 : 0.0);
+      }
+    }
+  }
+}
+
 // WPR (wave per row; long rows, i.e. the row-major programs of polyhedral cells): a block of ~160 rows of ~15 entries has ~90
 // dependency levels of one or two rows each, so a thread per row leaves the elimination serial (3.1 ms at 2M cells: 0.3 ms per
 // block of LDS round trips); the update pairs of ONE multiplier are independent, so a wavefront takes a row and its lanes the
@@ -659,24 +695,7 @@ __global__ void ilu_factor_prog_kernel(IluDev F, const double *__restrict__ aval
   const int u0 = ubase[b], nu = ubase[b + 1] - u0;
   const int d0 = dbase[b], nd = dbase[b + 1] - d0;  // pivot slots: backward chunk lanes (jagged layout) or U-order positions (row-major)
   const int p0 = pbase[b], np = pbase[b + 1] - p0;
-  // gather through the maps, four entries per thread at a time: the map loads, then the dependent value loads, are in flight
-  // together (one entry per thread and iteration leaves the block waiting on two memory latencies per 128 entries)
-  auto gather = [&](const int32_t *map, int first, int count, int vbase) {
-    for (int j0 = tid; j0 < count; j0 += 4 * T) {
-      int m[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const int j = j0 + u * T; m[u] = j < count ? map[first + j] : -1; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = j0 + u * T;
-        if (j < count) {
-#pragma unroll
-          for (int e = 0; e < BB; ++e)  // (-2: the unit pivot of a lane that does not finish its row, see the layout's virtual rows)
-            vals[(size_t)(vbase + j) * BB + e] = m[u] >= 0 ? aval[(size_t)m[u] * BB + e] : ((m[u] == -2 && e % (BS + 1) == 0) ? 1.0 : 0.0);
-        }
-      }
-    }
-  };
+  auto gather = [&](const int32_t *map, int first, int count, int vbase) { prog_gather<BS>(vals, aval, map, first, count, vbase, tid, T); };
   gather(jl_map, l0, nl, 0);
   gather(ju_map, u0, nu, nl);
   gather(jd_map, d0, nd, nl + nu);
@@ -747,6 +766,231 @@ __global__ void ilu_factor_prog_kernel(IluDev F, const double *__restrict__ aval
   for (int j = tid; j < nl * BB; j += T) F.l_val[(size_t)l0 * BB + j] = vals[j];
   for (int j = tid; j < nu * BB; j += T) F.u_val[(size_t)u0 * BB + j] = vals[(size_t)nl * BB + j];
   for (int j = tid; j < nd * BB; j += T) F.dinv[(size_t)d0 * BB + j] = vals[(size_t)(nl + nu) * BB + j];
+}
+
+// ---- wave per row, the row in registers (long rows: the virtual-row layout of polyhedral cells) ----------------------------------
+// The wave-per-row variant above walks a row's program one multiplier at a time: header -> multiplier and pivot -> pair codes ->
+// target and source values -> store -> fence, five dependent LDS round trips and ~80 instructions per multiplier on the only
+// wavefront that is busy in a level of one or two rows (measured with the shader clock: 4200 cycles per row, 1.70 ms at 2M
+// polyhedral cells, 0.04 of the HBM roofline).  The "rows form" of the program (prog_rows_form) turns the row around: lane e
+// keeps entry e of the row in a register (two registers for rows of 65..128 entries) for the whole elimination, and the program
+// is a dense table [multiplier][entry] of source indices (0xffff: no update), read PROG_CH multipliers at a time -- the sources
+// (U entries of rows of earlier levels) and pivot inverses are final by then, so a chunk's operands come in two LDS latencies
+// and the steps themselves touch no memory: the multiplier is a lane broadcast (v_readlane) from the register of the lane that
+// owns it, the update one multiply-subtract on the lanes whose table entry is set.  Same operations on every entry in the same
+// order as the other program kernels, hence the same bits.
+template <int BS> struct ProgRows { static constexpr int CH = BS == 1 ? 8 : (BS == 2 ? 4 : 2); };  // multipliers per chunk (registers)
+constexpr int PROG_ROWS_ENT = 128;  // entries of a row that take part in its elimination: two registers per lane
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// one row: NE registers per lane; gp: the block's program (global memory)
+template <int BS, int NE>
+__device__ __forceinline__ void prog_row_eliminate(double *vals, const uint16_t *__restrict__ gp, int o, int nent, int nsteps, int dpos, int lane) {
+  constexpr int BB = BS * BS, CH = ProgRows<BS>::CH;
+  const int hb = o + nent, tb = (hb + 2 * nsteps + 3) & ~3;
+  uint16_t idx[NE];
+  Blk<BS> v[NE];
+#pragma unroll
+  for (int r = 0; r < NE; ++r) idx[r] = lane + 64 * r < nent ? gp[o + lane + 64 * r] : (uint16_t)0xffffu;
+#pragma unroll
+  for (int r = 0; r < NE; ++r) {
+#pragma unroll
+    for (int i = 0; i < BB; ++i) v[r].a[i] = 0.0;
+    if (idx[r] != 0xffffu) v[r] = blk_load<BS>(vals + (size_t)idx[r] * BB);
+  }
+  for (int c0 = 0; c0 < nsteps; c0 += CH) {
+    // the chunk's static operands: lane q < CH holds the position and the pivot inverse of multiplier c0 + q, every lane the
+    // source indices of its entries
+    int hm = 0;
+    Blk<BS> dk;
+#pragma unroll
+    for (int i = 0; i < BB; ++i) dk.a[i] = 0.0;
+    uint32_t code[NE][CH / 2];
+#pragma unroll
+    for (int r = 0; r < NE; ++r) {
+      const uint32_t *tp = reinterpret_cast<const uint32_t *>(gp + tb + ((size_t)(c0 / CH) * nent + lane + 64 * r) * CH);
+#pragma unroll
+      for (int q = 0; q < CH / 2; ++q) code[r][q] = lane + 64 * r < nent ? tp[q] : 0xffffffffu;
+    }
+    if (lane < CH && c0 + lane < nsteps) {
+      hm = gp[hb + 2 * (c0 + lane)];
+      dk = blk_load<BS>(vals + (size_t)gp[hb + 2 * (c0 + lane) + 1] * BB);
+    }
+    // (rows of two registers per lane take the chunk in two halves: the same number of source registers)
+    constexpr int HC = NE > 1 ? CH / 2 : CH;
+#pragma unroll
+    for (int h0 = 0; h0 < CH; h0 += HC) {
+      Blk<BS> src[NE][HC];
+#pragma unroll
+      for (int r = 0; r < NE; ++r)
+#pragma unroll
+        for (int q = 0; q < HC; ++q) {
+          const uint32_t sidx = (code[r][(h0 + q) >> 1] >> (16 * ((h0 + q) & 1))) & 0xffffu;
+#pragma unroll
+          for (int i = 0; i < BB; ++i) src[r][q].a[i] = 0.0;
+          if (sidx != 0xffffu) src[r][q] = blk_load<BS>(vals + (size_t)sidx * BB);
+        }
+#pragma unroll
+      for (int q = h0; q < h0 + HC; ++q) {
+        if (c0 + q < nsteps) {  // wave-uniform
+          const int m = __builtin_amdgcn_readlane(hm, q);  // entry position of the multiplier
+          Blk<BS> lv, dks;
+#pragma unroll
+          for (int i = 0; i < BB; ++i) {
+            dks.a[i] = readlane_f64(dk.a[i], q);
+            lv.a[i] = readlane_f64(NE > 1 && m >= 64 ? v[NE - 1].a[i] : v[0].a[i], m & 63);
+          }
+          const Blk<BS> lik = blk_mul<BS>(lv, dks);  // nz_l * inv(A_kk)
+#pragma unroll
+          for (int r = 0; r < NE; ++r)
+            if (lane + 64 * r == m) v[r] = lik;
+          if (blk_nonzero<BS>(lik)) {
+#pragma unroll
+            for (int r = 0; r < NE; ++r)
+              if (((code[r][q >> 1] >> (16 * (q & 1))) & 0xffffu) != 0xffffu) blk_sub<BS>(v[r], blk_mul<BS>(lik, src[r][q - h0]));
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NE; ++r) {
+    if (lane + 64 * r == dpos) v[r] = blk_inv<BS>(v[r]);
+    if (idx[r] != 0xffffu) blk_store<BS>(vals + (size_t)idx[r] * BB, v[r]);
+  }
+}
+
+template <int BS>
+__global__ void __launch_bounds__(512) ilu_factor_rows_kernel(IluDev F, const double *__restrict__ aval, const int32_t *__restrict__ lbase,
+                                       const int32_t *__restrict__ ubase, const int32_t *__restrict__ pbase,
+                                       const int32_t *__restrict__ jl_map, const int32_t *__restrict__ ju_map,
+                                       const int32_t *__restrict__ jd_map, const uint16_t *__restrict__ prog, int max_vals,
+                                       const int32_t *__restrict__ dbase) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BB = BS * BS;
+  double *vals = reinterpret_cast<double *>(smem);
+  uint16_t *hw = reinterpret_cast<uint16_t *>(vals + (size_t)max_vals * BB);
+  const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+  const int nr = F.blk_ptr[b + 1] - F.blk_ptr[b];
+  const int l0 = lbase[b], nl = lbase[b + 1] - l0;
+  const int u0 = ubase[b], nu = ubase[b + 1] - u0;
+  const int d0 = dbase[b], nd = dbase[b + 1] - d0;
+  // the block's program: [levels] [level row pointers (levels + 1)] [per row: offset, entries, multipliers, position of the pivot]
+  // -- the head, kept in LDS -- then the rows, read from global memory where they are needed (an L2-resident stream: with the
+  // rows in LDS two blocks fit a CU, with the head only seven).  A row: [entry indices] [multiplier position, pivot index of its
+  // row] x multipliers, then (from a multiple of four words) the source table, chunk by chunk: [entry][multiplier of the chunk]
+  const uint16_t *__restrict__ gp = prog + pbase[b];
+  const int nlev = (int)gp[0], hlen = 2 + nlev + 4 * nr;
+  JH_T(0);
+  prog_gather<BS>(vals, aval, jl_map, l0, nl, 0, tid, T);
+  prog_gather<BS>(vals, aval, ju_map, u0, nu, nl, tid, T);
+  prog_gather<BS>(vals, aval, jd_map, d0, nd, nl + nu, tid, T);
+  JH_T(1);
+  for (int j = tid; j < hlen; j += T) hw[j] = gp[j];
+  __syncthreads();
+  JH_T(2);
+#ifdef JH_APPLY_TIMING
+  unsigned long long t_rows = 0, n_rows = 0;
+#endif
+  const uint16_t *levp = hw + 1, *rows = hw + 2 + nlev;
+  const int lane = tid & 63, wv = tid >> 6, nwv = T >> 6;
+  // level 0: no multipliers, a thread per row inverts the pivot (its only entry)
+  for (int t = (int)levp[0] + tid; t < (int)levp[1]; t += T) {
+    const int di = (int)gp[rows[4 * t]];
+    blk_store<BS>(vals + (size_t)di * BB, blk_inv<BS>(blk_load<BS>(vals + (size_t)di * BB)));
+  }
+  __syncthreads();
+  for (int lev = 1; lev < nlev; ++lev) {
+    const int s = (int)levp[lev], e = (int)levp[lev + 1];
+    for (int t = s + wv; t < e; t += nwv) {  // wave-uniform
+#ifdef JH_APPLY_TIMING
+      const unsigned long long tr0 = __builtin_readcyclecounter();
+#endif
+      // (wave-uniform words: in scalar registers, so that the multiplier steps branch instead of masking)
+      const int o = __builtin_amdgcn_readfirstlane((int)rows[4 * t]), nent = __builtin_amdgcn_readfirstlane((int)rows[4 * t + 1]);
+      const int nsteps = __builtin_amdgcn_readfirstlane((int)rows[4 * t + 2]), dpos = __builtin_amdgcn_readfirstlane((int)rows[4 * t + 3]);
+      if (nent <= 64) prog_row_eliminate<BS, 1>(vals, gp, o, nent, nsteps, dpos, lane);
+      else prog_row_eliminate<BS, 2>(vals, gp, o, nent, nsteps, dpos, lane);
+#ifdef JH_APPLY_TIMING
+      t_rows += __builtin_readcyclecounter() - tr0; ++n_rows;
+#endif
+    }
+    __syncthreads();
+  }
+  JH_T(3);
+#ifdef JH_APPLY_TIMING
+  JH_TV(6, t_rows); JH_TV(7, n_rows);
+#endif
+  for (int j = tid; j < nl * BB; j += T) F.l_val[(size_t)l0 * BB + j] = vals[j];
+  for (int j = tid; j < nu * BB; j += T) F.u_val[(size_t)u0 * BB + j] = vals[(size_t)nl * BB + j];
+  for (int j = tid; j < nd * BB; j += T) F.dinv[(size_t)d0 * BB + j] = vals[(size_t)(nl + nu) * BB + j];
+  JH_T(4); JH_T(5);
+}
+
+// The rows form of one block's program (see ilu_factor_rows_kernel) from its instruction form; false when it does not fit the
+// 16-bit words (the caller keeps the instruction form for the whole matrix then).
+static bool prog_rows_form(const std::vector<uint16_t> &prog, int nrb, int nvals, const int32_t *levp, int nlev, int32_t row0, int CH,
+                           std::vector<uint16_t> &out) {
+  out.clear();
+  if (nvals >= 0xffff || prog.empty() || nlev < 1) return false;
+  const uint16_t *rptr = prog.data(), *rdiag = rptr + nrb + 1, *code = rptr + 2 * nrb + 1;
+  std::vector<uint16_t> &W = out;
+  W.assign(2 + (size_t)nlev + 4 * (size_t)nrb, 0);
+  W[0] = (uint16_t)nlev;
+  for (int l = 0; l <= nlev; ++l) W[1 + l] = (uint16_t)(levp[l] - row0);
+  std::vector<uint16_t> ent;
+  struct Step { uint16_t lidx, kd; int first, n; };
+  std::vector<Step> steps;
+  for (int lt = 0; lt < nrb; ++lt) {
+    while (W.size() & 3) W.push_back(0);
+    if (W.size() >= 0xffff) return false;
+    ent.assign(1, rdiag[lt]);
+    steps.clear();
+    for (int pc = rptr[lt], pe = rptr[lt + 1]; pc < pe;) {
+      const int nupd = code[pc + 2];
+      steps.push_back({code[pc], code[pc + 1], pc + 3, nupd});
+      ent.push_back(code[pc]);
+      for (int u = 0; u < nupd; ++u) ent.push_back(code[pc + 3 + 2 * u]);
+      pc += 3 + 2 * nupd;
+    }
+    std::sort(ent.begin(), ent.end());
+    ent.erase(std::unique(ent.begin(), ent.end()), ent.end());
+    const int nent = (int)ent.size(), nsteps = (int)steps.size();
+    if (nent > PROG_ROWS_ENT || nsteps >= 0xffff) return false;
+    auto pos = [&](uint16_t x) { return (uint16_t)(std::lower_bound(ent.begin(), ent.end(), x) - ent.begin()); };
+    uint16_t *hr = W.data() + 2 + nlev + 4 * (size_t)lt;
+    hr[0] = (uint16_t)W.size(); hr[1] = (uint16_t)nent; hr[2] = (uint16_t)nsteps; hr[3] = pos(rdiag[lt]);
+    W.insert(W.end(), ent.begin(), ent.end());
+    for (const Step &st : steps) { W.push_back(pos(st.lidx)); W.push_back(st.kd); }
+    while (W.size() & 3) W.push_back(0);
+    const size_t tb = W.size();
+    const int nch = (nsteps + CH - 1) / CH;
+    W.resize(tb + (size_t)nch * nent * CH, (uint16_t)0xffffu);
+    for (int sidx = 0; sidx < nsteps; ++sidx) {
+      const Step &st = steps[sidx];
+      for (int u = 0; u < st.n; ++u)
+        W[tb + ((size_t)(sidx / CH) * nent + pos(code[st.first + 2 * u])) * CH + sidx % CH] = code[st.first + 2 * u + 1];
+    }
+  }
+  while (W.size() & 3) W.push_back(0);
+  return W.size() < 0xffff;
+}
+
+// launches the program-driven refactorisation: wave or thread per row
+template <int BS>
+static void launch_factor_prog(jh_ilu_s *M, const IluDev &F, const double *aval, const int32_t *lmap, const int32_t *umap,
+                               const int32_t *dmap, bool wpr, int threads, int64_t nb, hipStream_t s) {
+  auto go = [&](auto kern) {
+    if (M->prog_lds_bytes > 64 * 1024)
+      JH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(threads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, M->d_blk_ubase.p,
+                       M->d_blk_prog.p, lmap, umap, dmap, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p);
+  };
+  if (wpr) go(ilu_factor_prog_kernel<BS, true>);
+  else go(ilu_factor_prog_kernel<BS, false>);
 }
 
 // LDS mode: one workgroup per block, levels separated by __syncthreads()
@@ -1404,13 +1648,6 @@ struct IluMul {
   size_t pstride = 0;
   int dot_rows = 0x7fffffff;    // device rows >= dot_rows (ghost rows of a rank-local subdomain) do not contribute to the dot
 };
-// Development build (-DJH_APPLY_TIMING, tools/apply_timing.py): shader-clock stamps of the phases of every block's wavefront.
-#ifdef JH_APPLY_TIMING
-__device__ unsigned long long jh_apply_t[8 * 65536];
-#define JH_T(k) do { if (threadIdx.x == 0 && blockIdx.x < 65536) jh_apply_t[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define JH_T(k) do { } while (0)
-#endif
 template <int BS, int GM, int KU, bool SC, int MUL, bool VR = false>
 __global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const double *__restrict__ bvec, double *__restrict__ xvec, IluGather G, IluMul Q) {
   extern __shared__ __attribute__((aligned(16))) double xs[];
@@ -1542,6 +1779,23 @@ __global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const doubl
   JH_T(5);
 }
 #ifdef JH_APPLY_TIMING
+// rows-form factor kernel, means over the blocks of the last launch: [0] gather, [1] program copy, [2] level loop, [3] stores,
+// [4] cycles wave 0 spent inside rows, [5] rows wave 0 took, [6] launch span
+extern "C" int32_t jh_debug_factor_times(int64_t nblocks, double *out7) {
+  std::vector<unsigned long long> h((size_t)8 * 65536);
+  if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(jh_apply_t), h.size() * sizeof(unsigned long long)) != hipSuccess) return -1;
+  const int64_t nb = std::min<int64_t>(nblocks, 65536);
+  for (int k = 0; k < 7; ++k) out7[k] = 0.0;
+  unsigned long long t0 = ~0ull, t1 = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    const unsigned long long *t = h.data() + b * 8;
+    for (int k = 0; k < 4; ++k) out7[k] += (double)(t[k + 1] - t[k]) / nb;
+    out7[4] += (double)t[6] / nb; out7[5] += (double)t[7] / nb;
+    t0 = std::min(t0, t[0]); t1 = std::max(t1, t[5]);
+  }
+  out7[6] = (double)(t1 - t0);
+  return 0;
+}
 // mean cycles of the phases over the blocks of the LAST launch: [0] prologue (pointers, partial sums, first loads), [1] gather,
 // [2] forward sweep, [3] backward sweep, [4] scatter; [5] first start -> last end of the launch; [6] mean wavefront lifetime
 extern "C" int32_t jh_debug_apply_times(int64_t nblocks, double *out7) {
@@ -2020,6 +2274,12 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         M->blk_lbase.assign(nb + 1, 0); M->blk_ubase.assign(nb + 1, 0); M->blk_prog.assign(nb + 1, 0);
         for (int64_t b = 0; b <= nb; ++b) { M->blk_lbase[b] = M->l_ptr[M->blk_ptr[b]]; M->blk_ubase[b] = M->u_ptr[M->blk_ptr[b]]; }
         std::vector<std::vector<uint16_t>> progs(nb);  // factorisation program of every block (ilu_factor_prog_kernel)
+        // long rows: the rows form of the programs (ilu_factor_rows_kernel; ilu_factor_wave_per_row = 2 keeps the instruction form).
+        // Scalar matrices only: the entries of a block of 2x2 cells take 80 KB of LDS, two blocks per CU either way, and the
+        // instruction form is the faster one there (1.50 against 1.67 ms at 1M polyhedral two-phase cells).
+        const bool want_rows = VR && P.bs == 1 && M->ctx->opt.ilu_factor_wave_per_row == 1;
+        std::vector<std::vector<uint16_t>> progs_rows(want_rows ? nb : 0);
+        std::vector<char> rows_ok(nb, 0);
         std::vector<int> blk_vals(nb, 0);
         std::vector<char> blk_ok(nb, 1), blk_diag(nb, 1);  // blk_diag: every update of the block targets a pivot
         std::vector<int32_t> jt_map(nlent, -1), jf_diag(M->j_nslots, -1);
@@ -2134,16 +2394,25 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
             }
             prog[nrb] = (uint16_t)code.size();
             prog.insert(prog.end(), code.begin(), code.end());
+            if (want_rows && blk_ok[b])
+              rows_ok[b] = prog_rows_form(prog, nrb, nl + nu + nd, M->flev_ptr.data() + M->flev_off[b],
+                                          M->flev_off[b + 1] - M->flev_off[b] - 1, b0, P.bs == 1 ? 8 : (P.bs == 2 ? 4 : 2), progs_rows[b]);
           }
         });
         {
           bool ok = true;
           int max_vals = 0, max_words = 0;
           size_t total = 0;
+          bool rows = want_rows;
+          for (int64_t b = 0; b < nb && rows; ++b) rows = rows_ok[b] != 0;
+          if (rows) progs.swap(progs_rows);
+          M->prog_rows = rows;
           for (int64_t b = 0; b < nb; ++b) {
             ok = ok && blk_ok[b];
             max_vals = std::max(max_vals, blk_vals[b]);
-            max_words = std::max<int>(max_words, (int)progs[b].size());
+            // LDS words: the whole program, or (rows form: the rows are read from global memory) its head
+            max_words = std::max<int>(max_words, rows ? 2 + (M->flev_off[b + 1] - M->flev_off[b] - 1) + 4 * (M->blk_ptr[b + 1] - M->blk_ptr[b])
+                                                      : (int)progs[b].size());
             M->blk_prog[b] = (int32_t)total;
             total += progs[b].size();
           }
@@ -2415,7 +2684,7 @@ extern "C" int32_t jh_ilu0_stats(jh_ilu M, int64_t *stats4) {
     stats4[1] = (int64_t)M->u_col.size();
     stats4[2] = (int64_t)M->blk_ptr.size() - 1;
     stats4[3] = (M->lds_mode ? 1 : 0) | (M->jag ? 2 : 0) | (((M->jag && M->prog) || M->prog_rowmajor) ? 4 : 0) | (M->jag && M->prog && M->diag_only ? 8 : 0) |
-                ((M->jag && M->uscaled && M->ctx->opt.fused_product) ? 16 : 0);
+                ((M->jag && M->uscaled && M->ctx->opt.fused_product) ? 16 : 0) | (M->jag && M->prog && M->prog_rows ? 32 : 0);
   });
 }
 
@@ -2531,21 +2800,25 @@ void ilu_factor(jh_ilu M) {
       M->factored = true;
       return;
     }
-    const int pthreads = (int)ctx->opt.ilu_factor_threads;
+    const int pthreads = ctx->opt.ilu_factor_threads ? (int)ctx->opt.ilu_factor_threads : 512;
     // long rows (chains of lanes in the layout): a wavefront per row, its lanes on the update pairs of one multiplier
     const bool wprj = M->jag_vr && ctx->opt.ilu_factor_wave_per_row != 0;
-#define JH_PROG(BSV)                                                                                                             \
-    do {                                                                                                                          \
-      if (M->prog_lds_bytes > 64 * 1024)                                                                                          \
-        JH_HIP(hipFuncSetAttribute(wprj ? (const void *)ilu_factor_prog_kernel<BSV, true> : (const void *)ilu_factor_prog_kernel<BSV, false>, \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes));                         \
-      if (wprj) hipLaunchKernelGGL((ilu_factor_prog_kernel<BSV, true>), dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
-                         M->d_blk_ubase.p, M->d_blk_prog.p, M->d_jl_map.p, M->d_ju_map.p, M->d_jd_map.p, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p); \
-      else hipLaunchKernelGGL((ilu_factor_prog_kernel<BSV, false>), dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
-                         M->d_blk_ubase.p, M->d_blk_prog.p, M->d_jl_map.p, M->d_ju_map.p, M->d_jd_map.p, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p); \
-    } while (0)
-    switch (M->bs) { case 1: JH_PROG(1); break; case 2: JH_PROG(2); break; case 3: JH_PROG(3); break; }
-#undef JH_PROG
+    if (M->prog_rows) {
+      // (four wavefronts: seven blocks of ~20 KB of LDS share a CU; eight would leave room for four blocks)
+      const int rthreads = ctx->opt.ilu_factor_threads ? std::min((int)ctx->opt.ilu_factor_threads, 512) : 256;
+      auto go = [&](auto kern) {
+        if (M->prog_lds_bytes > 64 * 1024)
+          JH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(rthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, M->d_blk_ubase.p,
+                           M->d_blk_prog.p, M->d_jl_map.p, M->d_ju_map.p, M->d_jd_map.p, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p);
+      };
+      go(ilu_factor_rows_kernel<1>);  // (scalar matrices only: see want_rows)
+    } else
+    switch (M->bs) {
+      case 1: launch_factor_prog<1>(M, F, aval, M->d_jl_map.p, M->d_ju_map.p, M->d_jd_map.p, wprj, pthreads, nb, s); break;
+      case 2: launch_factor_prog<2>(M, F, aval, M->d_jl_map.p, M->d_ju_map.p, M->d_jd_map.p, wprj, pthreads, nb, s); break;
+      case 3: launch_factor_prog<3>(M, F, aval, M->d_jl_map.p, M->d_ju_map.p, M->d_jd_map.p, wprj, pthreads, nb, s); break;
+    }
     JH_HIP(hipGetLastError());
     M->factored = true;
     return;
@@ -2553,20 +2826,13 @@ void ilu_factor(jh_ilu M) {
   if (M->prog_rowmajor && M->lds_mode) {  // long rows: the program-driven refactorisation over the row-major arrays
     IluDev F = dev_view(M);
     const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
-    const int pthreads = (int)ctx->opt.ilu_factor_threads;
+    const int pthreads = ctx->opt.ilu_factor_threads ? (int)ctx->opt.ilu_factor_threads : 512;
     const bool wpr = ctx->opt.ilu_factor_wave_per_row != 0;  // wave per row (long rows); 0: thread per row
-#define JH_PROGR(BSV)                                                                                                            \
-    do {                                                                                                                          \
-      if (M->prog_lds_bytes > 64 * 1024)                                                                                          \
-        JH_HIP(hipFuncSetAttribute(wpr ? (const void *)ilu_factor_prog_kernel<BSV, true> : (const void *)ilu_factor_prog_kernel<BSV, false>,        \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->prog_lds_bytes));                                         \
-      if (wpr) hipLaunchKernelGGL((ilu_factor_prog_kernel<BSV, true>), dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
-                         M->d_blk_ubase.p, M->d_blk_prog.p, M->d_l_map.p, M->d_u_map.p, M->d_d_map.p, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p); \
-      else hipLaunchKernelGGL((ilu_factor_prog_kernel<BSV, false>), dim3((unsigned)nb), dim3(pthreads), M->prog_lds_bytes, s, F, aval, M->d_blk_lbase.p, \
-                         M->d_blk_ubase.p, M->d_blk_prog.p, M->d_l_map.p, M->d_u_map.p, M->d_d_map.p, M->d_prog.p, M->prog_max_vals, M->d_blk_dbase.p); \
-    } while (0)
-    switch (M->bs) { case 1: JH_PROGR(1); break; case 2: JH_PROGR(2); break; case 3: JH_PROGR(3); break; }
-#undef JH_PROGR
+    switch (M->bs) {
+      case 1: launch_factor_prog<1>(M, F, aval, M->d_l_map.p, M->d_u_map.p, M->d_d_map.p, wpr, pthreads, nb, s); break;
+      case 2: launch_factor_prog<2>(M, F, aval, M->d_l_map.p, M->d_u_map.p, M->d_d_map.p, wpr, pthreads, nb, s); break;
+      case 3: launch_factor_prog<3>(M, F, aval, M->d_l_map.p, M->d_u_map.p, M->d_d_map.p, wpr, pthreads, nb, s); break;
+    }
     JH_HIP(hipGetLastError());
     M->factored = true;
     return;
@@ -2576,7 +2842,7 @@ void ilu_factor(jh_ilu M) {
     const int64_t nb = (int64_t)M->blk_ptr.size() - 1;
     const int mr = (int)M->max_block_rows;
     // the bulk load/store phases want many lanes (memory-level parallelism); the level loop only needs a few
-    const int fthreads = (int)ctx->opt.ilu_factor_threads;
+    const int fthreads = ctx->opt.ilu_factor_threads ? (int)ctx->opt.ilu_factor_threads : 512;
     if (M->factor_lds_bytes > 64 * 1024) {
       const int fb = (int)M->factor_lds_bytes;
       switch (M->bs) {

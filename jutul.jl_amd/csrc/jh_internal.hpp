@@ -196,7 +196,7 @@ struct Comm;  // RCCL state (jh_comm.cpp)
   X(ilu_jagged, 1)            /* chunk-jagged factor layout (set before jh_ilu0_create) */                                     \
   X(ilu_threads, 0)           /* threads per block of the row-major sweeps: 64 / 128 / 256 / 512, 0 = default */               \
   X(ilu_factor_kernel, -1)    /* pivot-only refactorisation: 0 workgroup per block, 1 wavefront per block, -1 = by pattern */  \
-  X(ilu_factor_threads, 512)  /* program-driven refactorisation: threads per block */                                          \
+  X(ilu_factor_threads, 0)  /* program-driven refactorisation: threads per block (0: 512, rows form 256) */                      \
   X(ilu_factor_wave_per_row, 1)                                                                                                \
   X(ilu_diag_factor, 1)       /* pivot-only kernels for triangle-free block patterns (set before jh_ilu0_create) */            \
   X(ilu_prog, 1)              /* factorisation programs (set before jh_ilu0_create) */                                         \

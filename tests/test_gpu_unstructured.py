@@ -128,7 +128,8 @@ def test_polyhedral_dual_mesh_parity(ja, oracle, kind):
     deg = np.bincount(g["N"].reshape(-1), minlength=g["nc"] + 1)[1:]
     assert deg.max() > 16 and deg.mean() > 12
     run_family(ja, oracle, g, kind,
-               dict(longest_row=int(deg.max()) + 1, jagged_spmv=False, jagged_ilu=True, factor_kernel="program"))   # ILU: chains of lanes
+               dict(longest_row=int(deg.max()) + 1, jagged_spmv=False, jagged_ilu=True,   # ILU: chains of lanes
+                    factor_kernel="program, rows form" if kind == "compressible" else "program"))
 
 
 @pytest.mark.parametrize("kind", ["compressible", "twophase"])
@@ -136,3 +137,29 @@ def test_cartesian_mesh_parity(ja, oracle, kind):
     g = ja.cartesian_mesh(60, 60, 60)                                # 216k hexahedra, the reference's CartesianMesh: 6 faces per cell
     run_family(ja, oracle, g, kind,
                dict(longest_row=7, jagged_spmv=kind != "twophase", jagged_ilu=True, factor_kernel="pivot-only"))
+
+
+@pytest.mark.parametrize("kind", ["compressible", "twophase"])
+def test_long_row_factor_program_forms_agree_bitwise(ja, kind):
+    """ilu_factor_wave_per_row: thread per row (0), wavefront per row over the rows-form programs (1, default; scalar matrices)
+    and over the instruction-form programs (2) do the same operations on every entry in the same order -> identical factor bits"""
+    g = ja.polyhedral_dual_mesh(12000, grading=1.5)
+    bs = 2 if kind == "twophase" else 1
+    rng = np.random.default_rng(9)
+    got = {}
+    for mode in (0, 1, 2):
+        ctx = ja.HIPContext(0, ilu_factor_wave_per_row=mode)
+        disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], g["nc"], block_n=bs, reorder="blocks")
+        lsys = ja.LinearizedSystem(disc)
+        rowptr, colidx = disc.pattern()
+        if "nz" not in got:   # a diagonally dominant random matrix on the pattern
+            rows = np.repeat(np.arange(g["nc"]), np.diff(rowptr))
+            blk = rng.uniform(-1.0, 1.0, (colidx.size, bs, bs))
+            blk[colidx - 1 == rows] += 40.0 * np.eye(bs)
+            got["nz"] = blk.reshape(-1)
+        lsys.jac.nzval = got["nz"]
+        F = ja.ILUZeroPreconditioner(partition="blocks").update_preconditioner(lsys.jac)
+        assert F.info()["factor_kernel"] == ("program, rows form" if mode == 1 and bs == 1 else "program"), F.info()
+        got[mode] = F.factor_values().copy()
+    assert np.isfinite(got[1]).all() and np.abs(got[1]).max() > 0
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[2], got[1])
