@@ -163,3 +163,46 @@ def test_long_row_factor_program_forms_agree_bitwise(ja, kind):
         got[mode] = F.factor_values().copy()
     assert np.isfinite(got[1]).all() and np.abs(got[1]).max() > 0
     assert np.array_equal(got[0], got[1]) and np.array_equal(got[2], got[1])
+
+
+def test_factor_rows_form_with_rows_of_two_registers(ja):
+    """rows of 65..128 entries in one block (two registers per lane in ilu_factor_rows_kernel): hub cells joined to their ~100
+    graph-nearest cells on top of a polyhedral mesh; bitwise against the thread-per-row instruction form"""
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as cg
+    g = ja.polyhedral_dual_mesh(6000, grading=1.2)
+    nc, N = g["nc"], np.asarray(g["N"])
+    A = sp.coo_matrix((np.ones(N.shape[1]), (N[0] - 1, N[1] - 1)), shape=(nc, nc))
+    A = (A + A.T).tocsr()
+    extra = []
+    for hub in (nc // 7, nc // 2, (4 * nc) // 5):
+        order = cg.breadth_first_order(A, hub, directed=False, return_predecessors=False)[1:110]
+        have = set(A.indices[A.indptr[hub]:A.indptr[hub + 1]])
+        extra += [(hub + 1, int(c) + 1) for c in order if int(c) not in have]
+    N2 = np.concatenate([N, np.array(extra, dtype=N.dtype).T], axis=1)
+    rng = np.random.default_rng(3)
+    got = {}
+    for mode in (0, 1):
+        ctx = ja.HIPContext(0, ilu_factor_wave_per_row=mode)
+        disc = ja.TwoPointPotentialFlowHardCoded(ctx, N2, nc, reorder="blocks", block_rows=256)
+        lsys = ja.LinearizedSystem(disc)
+        rowptr, colidx = disc.pattern()
+        assert np.diff(rowptr).max() >= 100
+        if "nz" not in got:
+            rows = np.repeat(np.arange(nc), np.diff(rowptr))
+            nz = rng.uniform(-1.0, 1.0, colidx.size)
+            nz[colidx - 1 == rows] += 150.0
+            got["nz"] = nz
+        lsys.jac.nzval = got["nz"]
+        F = ja.ILUZeroPreconditioner(partition="blocks").update_preconditioner(lsys.jac)
+        fi = F.info()
+        assert fi["factor_kernel"] == ("program, rows form" if mode == 1 else "program"), fi
+        got[mode] = F.factor_values().copy()
+        # the hub rows keep most of their entries inside their block: more than 64 take part in the elimination
+        perm, bp = disc.ordering()
+        blk_of = np.repeat(np.arange(len(bp) - 1), np.diff(bp))
+        dev_of = np.empty(nc, dtype=np.int64); dev_of[perm - 1] = np.arange(nc)
+        inblock = [int(np.sum(blk_of[dev_of[colidx[rowptr[h] - 1:rowptr[h + 1] - 1] - 1]] == blk_of[dev_of[h]])) for h in (nc // 7, nc // 2, (4 * nc) // 5)]
+        got["inblock"] = inblock
+    assert max(got["inblock"]) > 64, got["inblock"]
+    assert np.isfinite(got[1]).all() and np.array_equal(got[0], got[1])
