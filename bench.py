@@ -708,9 +708,10 @@ def measured_traffic(kernel, args, cells, world):
     measurement -- quoted only if it was taken on exactly this kernel source (hash recorded next to it) and workload; otherwise
     null with the reason."""
     import glob
-    names = {"ilu0_apply": ["ilu_apply_jds_kernel<1, 1, 4, false, 0>", "ilu_apply_jds_kernel<1, 2, 4, false, 0>"],
-             "spmv": ["spmv_jds16_kernel<5, 1>", "spmv_jds16_kernel<5, 2>"], "assembly": ["assemble_pipe_kernel<0>"],
-             "ilu0_factor": ["ilu_factor_diag_kernel<1, 4, false>"]}
+    # kernel name prefixes (the trailing template arguments -- wavefronts per workgroup, layout flags -- vary with the options)
+    names = {"ilu0_apply": ["ilu_apply_jds_kernel<1, 1,", "ilu_apply_jds_kernel<1, 2,"],
+             "spmv": ["spmv_jds16_kernel<5, 1,", "spmv_jds16_kernel<5, 2,"], "assembly": ["assemble_pipe_kernel<0"],
+             "ilu0_factor": ["ilu_factor_diag_kernel<1, 4,"]}
     if world != 1 or args.law != "poisson" or cells != 10_025_988:
         return None, "PMC passes are committed for the default 1-GPU 10M-cell poisson workload only"
     want = kernel_source_hash()
@@ -721,7 +722,11 @@ def measured_traffic(kernel, args, cells, world):
                 d = json.load(f)
             if d.get("_meta", {}).get("kernel_source_hash") != want:
                 continue
-            vals = [d[n]["hbm_bytes_per_launch"] for n in names[kernel] if n in d]  # the fused variants alternate 1:1
+            vals = []  # the fused variants alternate 1:1
+            for pre in names[kernel]:
+                hit = [v["hbm_bytes_per_launch"] for k, v in d.items() if k.startswith(pre) and "hbm_bytes_per_launch" in v]
+                if len(hit) == 1:
+                    vals.append(hit[0])
             if vals:
                 return int(sum(vals) / len(vals)), f"{os.path.basename(path)} (same kernel sources, hash {want})"
         except Exception:  # noqa: BLE001
