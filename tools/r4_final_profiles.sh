@@ -1,8 +1,11 @@
 # the round's evidence on the final tree -> gpurun_out/r04/ (copied into profiles/r04_final_* afterwards)
 R=${GRAFT_REPO_ROOT:-$(dirname "$0")/..}; cd $R; O=$R/gpurun_out/r04; mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -x -q > $O/gpu_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/gpu_pytest.log | head -1
+# (SKIP_PMC=1: second call, after the PMC summary of the first was copied into profiles/ -- bench.py then quotes roofline.traffic)
+if [ -z "$SKIP_PMC" ]; then
 bash tools/collect_profiles.sh r04_final > $O/collect.log 2>&1
 PMC_PASSES="fetch write sq_time tcc" bash tools/pmc_passes.sh r04_final > $O/pmc.log 2>&1
+fi
 run() { tag=$1; shift; python bench.py --no-cpu "$@" > $O/bench_$tag.json 2> $O/bench_$tag.err; python - $O/bench_$tag.json $tag <<'PY'
 import json, sys
 try:
