@@ -2404,7 +2404,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
           int max_vals = 0, max_words = 0;
           size_t total = 0;
           bool rows = want_rows;
-          for (int64_t b = 0; b < nb && rows; ++b) rows = rows_ok[b] != 0;
+          size_t rows_total = 0;  // (32-bit program offsets: beyond them the instruction form, half the size, is kept)
+          for (int64_t b = 0; b < nb && rows; ++b) { rows = rows_ok[b] != 0; rows_total += progs_rows[b].size(); }
+          rows = rows && rows_total < (size_t)INT32_MAX;
           if (rows) progs.swap(progs_rows);
           M->prog_rows = rows;
           for (int64_t b = 0; b < nb; ++b) {
