@@ -52,6 +52,8 @@ int32_t jh_synchronize(jh_context ctx); /* synchronize(ctx), context.jl:72 */
  *   consumer_reduce (1)   BiCGStab: the kernel that needs a fused dot product sums its partials itself (no reduction launch)
  *   spmv_jagged (1), spmv_col_bits (0 = by size | 16 | 32), spmv_waves_per_xcd (0 = resident),
  *   spmv_waves (0 = auto | 4 | 8 | 16 wavefronts per workgroup), spmv_window (1), spmv_pipe (1)
+ *   spmv_nontemporal (-1 = by working set | 0 | 1)  matrix stream of the jagged SpMV (32-bit columns) with non-temporal loads:
+ *                         off when matrix, factors and vectors fit the 256 MB Infinity Cache (read when the layout is built)
  *   sync_loop (0)         1: no speculative Krylov iteration
  *   halo_overlap (0), fused_pack (1), comm_timeout_ms (600000; 0 = wait like a collective)
  *   fused_product (0), fuse_gather (1)

@@ -185,6 +185,7 @@ struct Comm;  // RCCL state (jh_comm.cpp)
   X(spmv_jagged, 1)           /* Krylov loop multiplies out of the jagged-slice copy when the matrix has one */               \
   X(spmv_col_bits, 0)         /* jagged column ids: 16 / 32, 0 = by size (16 from 3M rows) */                                  \
   X(spmv_waves_per_xcd, 0)    /* persistent wavefronts per XCD of the SpMV kernels, 0 = what is resident at once */            \
+  X(spmv_nontemporal, -1)     /* jagged SpMV, 32-bit columns: matrix stream non-temporal; -1 = by working set (read when the layout is built) */ \
   X(spmv_waves, 0)            /* wavefronts per workgroup of the jagged SpMV in the Krylov loop: 4 / 8 / 16, 0 = 16 */           \
   X(spmv_window, 1)           /* CSR tile SpMV: LDS window of x */                                                             \
   X(spmv_pipe, 1)             /* CSR tile SpMV with a fused dot: software-pipelined variant */                                 \
@@ -314,6 +315,7 @@ struct Pattern {
   struct Jagged {
     bool built = false, usable = false;  // usable: bs == 1 and at most JDS_KMAX entries per row
     int32_t nslices = 0, kmax = 0;
+    bool nontemporal = true;  // value / column stream with non-temporal loads (working set beyond the Infinity Cache)
     int64_t nent = 0;
     DevBuf<int32_t> d_base;  // [nslices + 1] first entry of every slice
     DevBuf<uint8_t> d_cnt;   // [nslices * 16] byte j: rows of the slice with more than j entries

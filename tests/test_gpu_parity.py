@@ -1552,3 +1552,23 @@ def test_context_options_api(ja):
             ja.HIPContext(0)
     finally:
         os.environ.pop("JH_OPTIONS", None)
+
+
+@pytest.mark.parametrize("nt", [0, 1])
+def test_jagged_spmv_stream_policy_same_bits(ja, oracle, nt):
+    """spmv_nontemporal: the matrix stream of the jagged SpMV through plain or non-temporal loads (chosen by working set against the
+    Infinity Cache when left at -1) -- a cache policy, the product's bits do not change"""
+    g, rng = tet_case(ja, (14, 12, 10), seed=5)
+    ctx = ja.HIPContext(0, spmv_nontemporal=nt)
+    assert ctx.get_option("spmv_nontemporal") == nt
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], g["nc"], reorder="blocks")
+    lsys = ja.LinearizedSystem(disc)
+    rowptr, colidx = disc.pattern()
+    nz = rng.standard_normal(colidx.size)
+    lsys.jac.nzval = nz
+    x = rng.standard_normal(g["nc"])
+    xv = ja.DeviceVector(disc, x)
+    y = ja.mul_(ja.DeviceVector(disc), lsys.jac, xv).download()
+    yj = ja.mul_(ja.DeviceVector(disc), lsys.jac, xv, jagged=True).download()
+    assert np.array_equal(y, yj)
+    assert relerr(y, oracle.spmv(g["nc"], 1, rowptr, colidx, nz, x)) < RTOL
