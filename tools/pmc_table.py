@@ -12,7 +12,7 @@ import re
 import statistics
 import sys
 
-KNOWN = ["ilu_apply_chunked_kernel", "ilu_apply_jds_kernel", "ilu_apply_blocks_pf_kernel", "ilu_factor_lds_kernel", "ilu_factor_wave_kernel", "ilu_factor_diag_kernel", "ilu_factor_prog_kernel",
+KNOWN = ["ilu_apply_chunked_kernel", "ilu_apply_jds_kernel", "ilu_apply_blocks_pf_kernel", "ilu_factor_lds_kernel", "ilu_factor_wave_kernel", "ilu_factor_diag_kernel", "ilu_factor_prog_kernel", "ilu_factor_rows_kernel",
          "spmv_pipe_kernel", "spmv_jds16_kernel", "spmv_jds_kernel", "spmv_tile_kernel", "jagged_copy_kernel", "assemble_pipe_kernel", "assemble_tile_kernel",
          "bicg_xr_dots_kernel", "bicg_reduce_publish_kernel", "bicg_init_kernel", "dot2_partial_kernel", "final_reduce_kernel"]
 
