@@ -99,8 +99,10 @@ void Pattern::build_jagged() {
   jag.d_src.upload(src, st);
   // stream policy of the 32-bit kernel (see stream_load): the Krylov loop's working set -- jagged values and columns, the ILU(0)
   // factors (about as many), ~10 vectors -- against the Infinity Cache
+  // (measured on the bench lattice: plain loads win up to 1.25M rows, the two tie at 1.6M = 256 MB by this count, non-temporal wins
+  // from 2M; the rank-local matrix of an 8-rank 10M-cell run, ghost rows included, counts 211 MB)
   const int64_t nt = ctx->opt.spmv_nontemporal;
-  jag.nontemporal = nt >= 0 ? nt != 0 : 12.0 * (double)nnzb + 100.0 * (double)n > 210e6;
+  jag.nontemporal = nt >= 0 ? nt != 0 : 12.0 * (double)nnzb + 100.0 * (double)n > 235e6;
   JH_HIP(hipStreamSynchronize(st));
   jag.usable = true;
 }
