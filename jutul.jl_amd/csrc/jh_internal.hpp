@@ -326,7 +326,7 @@ struct Pattern {
     DevBuf<uint16_t> d_col16;  // [nent + 64]
     DevBuf<int32_t> d_win;     // [2 * nslices] window origin (may be negative), first far entry
     DevBuf<int32_t> d_far;     // far columns of all slices (+ padding: lanes past a diagonal's count decode, too)
-    DevBuf<int32_t> d_src;   // [nent] CSR slot each jagged entry is copied from
+    DevBuf<uint16_t> d_src;  // [nent] CSR slot each jagged entry is copied from, relative to the first slot of its slice
   } jag;
   void build_tiles();
   void upload();
