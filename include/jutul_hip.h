@@ -62,8 +62,17 @@ int32_t jh_synchronize(jh_context ctx); /* synchronize(ctx), context.jl:72 */
  *   ilu_factor_wave_per_row (long rows; read when the preconditioner is created: 1 = rows-form programs (scalar matrices) | 2 = instruction-form
  *                            programs, wavefront per row | 0 = thread per row)
  *   asm_pipe (1), asm_pipe2_wgs (0), block_order (0 bisection | 1 onion)
- *   read_sync (0), setup_timing (0), jds_keep (0) */
+ *   read_sync (0), setup_timing (0), jds_keep (0)
+ *   xrank_consumer (-1 = when jh_comm_set_exclusive declared it | 0 | 1)  several ranks: the dot products of the Krylov loop are
+ *                         summed over the ranks inside the consuming kernels and the push-halo hand-shake runs inside the product
+ *                         kernel -- five launches per BiCGStab iteration as on one rank */
 int32_t jh_context_set_option(jh_context ctx, const char *key, int64_t value);
+/* Restricts every kernel of the context to the compute units [first_cu, first_cu + n_cus) of the device's CU-mask bit order
+ * (hipExtStreamCreateWithCUMask; consecutive bits alternate over the XCDs, so a contiguous range takes the same share of every
+ * XCD); n_cus <= 0 removes the mask.  For several ranks on ONE device -- the role of DebugPArrayBackend's ranks inside one
+ * process (src/ext/partitionedarrays_ext.jl:37-39) with real concurrency: with disjoint ranges no rank's waiting kernel can keep
+ * another rank's kernel off the chip (tools/micro/cu_mask_probe.hip).  Call before any other object of the context is created. */
+int32_t jh_context_set_cu_mask(jh_context ctx, int32_t first_cu, int32_t n_cus);
 int32_t jh_context_get_option(jh_context ctx, const char *key, int64_t *value);
 /* GPU timer on the context stream (HIP events) -- feeds report[:equations_time] & co (simulator.jl:427-433) */
 int32_t jh_timer_start(jh_context ctx);
@@ -289,6 +298,11 @@ int32_t jh_gmres(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh_vec x, double
  * run with atol = rtol = 1e-20 and stop as soon as ||r_k|| <= atol + rtol*||r_0|| holds at an iteration k >= n; that exit
  * is reported as status 3 ("user-requested exit": Krylov.jl leaves stats.solved false).  n <= 1: plain stopping rule. */
 int32_t jh_krylov_set_min_iterations(jh_krylov K, int64_t min_iterations);
+/* Which path the last BiCGStab solve of this workspace took (for the host to report and for tests to assert): out6 = [0] 1 = the
+ * dot products were finished by the kernels that consume them (no reduction launches), [1] 1 = over several ranks as well,
+ * [2] 1 = products out of the jagged-slice copy, [3] 1 = products fused into the preconditioner apply, [4] 1 = the ghost
+ * exchanges of the loop were push halos, [5] 1 = with their hand-shake inside the product kernel (no finish launch). */
+int32_t jh_krylov_last_path(jh_krylov K, int64_t *out6);
 /* PrecondWrapper-style instrumentation (linsolve/krylov.jl:5-25): accumulated HIP-event time [ms] and launch
  * count of [0] the SpMV and [1] the preconditioner apply inside jh_bicgstab / jh_newton_step.  Reads the
  * totals (ms2/count2 may be NULL), then optionally resets them and enables/disables further profiling.
@@ -338,7 +352,7 @@ int32_t jh_comm_init_ipc_only(jh_context ctx, int32_t nranks, int32_t rank);
 /* What carries this rank's data right now, for the host to report and check (simulate_parray builds all ranks itself,
  * ext/JutulPartitionedArraysExt/interface.jl:2-97; a host that launched N processes verifies that N ranks run).
  * out8: [0] ranks of the communicator (1 without one), [1] this rank, [2] ranks RCCL counts in its communicator
- * (ncclCommCount; 0 = no RCCL communicator), [3] 1 = scalar all-reduces through the mailboxes, [4] 1 = ghost exchanges through
+ * (ncclCommCount; 0 = no RCCL communicator), [3] 1 = scalar all-reduces through the mailboxes (3 = and finished by the consuming kernels, jh_comm_set_exclusive), [4] 1 = ghost exchanges through
  * the host callback, [5] 1 = in-process backend, [6] waits that timed out so far, [7] time limit of a wait in seconds.
  * Waits inside the mailbox all-reduce / push halo are time-limited (JH_COMM_TIMEOUT_S, default 600; 0 = unbounded): when a
  * peer never arrives, the running solve fails with a jh_last_error message naming this rank, the missing peer and the
@@ -356,6 +370,13 @@ int32_t jh_comm_set_halo_callback(jh_context ctx, jh_halo_callback fn, void *use
 int32_t jh_comm_ipc_export(jh_context ctx, char *handle64);
 int32_t jh_comm_ipc_attach(jh_context ctx, const char *handles, int32_t *ok);
 int32_t jh_comm_ipc_enable(jh_context ctx, int32_t enable);
+/* exclusive = 1: no two ranks of the communicator share compute units (one process per GPU -- the deployment -- or CU-masked
+ * contexts on one GPU).  The host knows, the library cannot.  With mailboxes enabled the BiCGStab loop then all-reduces its dot
+ * products (ext/JutulPartitionedArraysExt/krylov.jl:51-105) inside the kernels that consume them: workgroup 0 stores the local
+ * sums into the peers' mailboxes, every wavefront collects the peers' sums and adds them in rank order (identical bits on all
+ * ranks), and the push halo's signal / wait / copy (consistent!, linalg.jl:37-55) runs inside the product kernel.  Where ranks
+ * share compute units a chip-filling kernel waiting for a peer would keep that peer off the chip: leave it 0 (default). */
+int32_t jh_comm_set_exclusive(jh_context ctx, int32_t exclusive);
 /* In-process multi-rank backend (the analogue of DebugPArrayBackend / JuliaPArrayBackend,
  * src/ext/partitionedarrays_ext.jl:37-39): ranks are host threads of one process exchanging through host memory;
  * same pack/unpack kernels, halo plans and reduction placement as the RCCL path.  For tests on one GPU. */

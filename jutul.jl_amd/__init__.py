@@ -83,6 +83,11 @@ class HIPContext(_Handle):
         check(_L().jh_context_get_option(self.h, str(key).encode(), C.byref(v)))
         return v.value
 
+    def set_cu_mask(self, first_cu, n_cus):
+        """Every kernel of the context runs on the compute units [first_cu, first_cu + n_cus) only (several ranks on one GPU with
+        compute units of their own); n_cus <= 0 removes the mask.  Before any other object of the context is created."""
+        check(_L().jh_context_set_cu_mask(self.h, int(first_cu), int(n_cus)))
+
     def synchronize(self):
         check(_L().jh_synchronize(self.h))
 
@@ -152,6 +157,11 @@ class HIPContext(_Handle):
     def comm_ipc_enable(self, enable=True):
         check(_L().jh_comm_ipc_enable(self.h, 1 if enable else 0))
 
+    def comm_set_exclusive(self, exclusive=True):
+        """Declares that no two ranks share compute units (one process per GPU, or CU-masked contexts): the Krylov loop then
+        finishes its dot products over the ranks inside the consuming kernels (five launches per BiCGStab iteration)."""
+        check(_L().jh_comm_set_exclusive(self.h, 1 if exclusive else 0))
+
     def comm_finalize(self):
         check(_L().jh_comm_finalize(self.h))
 
@@ -159,7 +169,7 @@ class HIPContext(_Handle):
         """What carries this rank's data: dict(nranks, rank, rccl_ranks, mailbox, host_callback, local, timeouts, timeout_s)."""
         o = np.zeros(8, dtype=np.int64)
         check(_L().jh_comm_info(self.h, pi(o)))
-        return dict(nranks=int(o[0]), rank=int(o[1]), rccl_ranks=int(o[2]), mailbox=bool(o[3]), host_callback=bool(o[4]),
+        return dict(nranks=int(o[0]), rank=int(o[1]), rccl_ranks=int(o[2]), mailbox=bool(o[3]), consumer_allreduce=bool(o[3] & 2), host_callback=bool(o[4]),
                     local=bool(o[5]), timeouts=int(o[6]), timeout_s=int(o[7]))
 
     def allreduce(self, values, op="sum"):
@@ -659,6 +669,13 @@ class GenericKrylov(_Handle):
             self.A = A
         check(_L().jh_krylov_set_min_iterations(self.h, int(self.config.min_iterations)))
         return self.h
+
+    def last_path(self):
+        """Which path the last BiCGStab solve took: dict(consumer_reduce, consumer_allreduce, jagged, fused_product, push_halo,
+        halo_fold) (jh_krylov_last_path)."""
+        o = np.zeros(6, dtype=np.int64)
+        check(_L().jh_krylov_last_path(self.h, pi(o)))
+        return dict(zip(("consumer_reduce", "consumer_allreduce", "jagged", "fused_product", "push_halo", "halo_fold"), (bool(v) for v in o)))
 
     def profile(self, enable=True, reset=True):
         """PrecondWrapper-like counters: dict(spmv_ms, spmv_count, precond_ms, precond_count) since last reset.

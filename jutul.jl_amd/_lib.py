@@ -35,6 +35,7 @@ SIGNATURES = {
     "jh_synchronize": [H],
     "jh_context_set_option": [H, C.c_char_p, C.c_int64],
     "jh_context_get_option": [H, C.c_char_p, C.POINTER(C.c_int64)],
+    "jh_context_set_cu_mask": [H, C.c_int32, C.c_int32],
     "jh_timer_start": [H],
     "jh_timer_stop_ms": [H, F64P],
     "jh_tpfa_create": [H, C.c_int64, C.c_int64, I64P, C.c_int32, C.c_int32, I64P, C.c_int64, C.c_int64, C.POINTER(H)],
@@ -104,6 +105,7 @@ SIGNATURES = {
     "jh_diag_precond_create": [H, C.c_int32, C.c_double, C.POINTER(H)],
     "jh_krylov_create": [H, C.POINTER(H)],
     "jh_krylov_destroy": [H],
+    "jh_krylov_last_path": [H, I64P],
     "jh_krylov_profile": [H, C.c_int32, C.c_int32, F64P, I64P],
     "jh_bicgstab": [H, H, C.c_int32, H, H, C.c_double, C.c_double, C.c_int64, I64P, I32P, F64P, C.c_int64],
     "jh_gmres": [H, H, C.c_int32, H, H, C.c_double, C.c_double, C.c_int64, I64P, I32P, F64P, C.c_int64],
@@ -119,6 +121,7 @@ SIGNATURES = {
     "jh_comm_ipc_export": [H, C.c_char_p],
     "jh_comm_ipc_attach": [H, C.c_char_p, C.POINTER(C.c_int32)],
     "jh_comm_ipc_enable": [H, C.c_int32],
+    "jh_comm_set_exclusive": [H, C.c_int32],
     "jh_halo_ipc_export": [H, C.c_char_p],
     "jh_halo_ipc_attach": [H, C.c_char_p, I64P, I64P, C.POINTER(C.c_int32)],
     "jh_halo_ipc_selftest": [H, H, F64P, C.POINTER(C.c_int32)],

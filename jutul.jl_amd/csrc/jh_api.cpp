@@ -156,7 +156,13 @@ void Options::seed_from_env() {
     if (item.empty()) continue;
     const size_t eq = item.find('=');
     const std::string key = item.substr(0, eq);
-    const int64_t val = eq == std::string::npos ? 1 : atoll(item.c_str() + eq + 1);
+    int64_t val = 1;
+    if (eq != std::string::npos) {  // integers only: "sync_loop=on" must not silently become 0
+      const char *b = item.c_str() + eq + 1;
+      char *endp = nullptr;
+      val = std::strtoll(b, &endp, 10);
+      if (endp == b || *endp != '\0') JH_THROW("JH_OPTIONS: value of '" + key + "' is not an integer: '" + std::string(b) + "'");
+    }
     if (!set(key.c_str(), val)) JH_THROW("JH_OPTIONS: unknown option '" + key + "'");
   }
 }
@@ -186,6 +192,8 @@ extern "C" int32_t jh_context_create(int32_t device_id, jh_context *out) {
     c->device = device_id;
     c->opt.seed_from_env();
     JH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    JH_HIP(hipDeviceGetAttribute(&c->ncu_total, hipDeviceAttributeMultiprocessorCount, device_id));
+    c->ncu = c->ncu_total;
     JH_HIP(hipEventCreate(&c->ev0));
     JH_HIP(hipEventCreate(&c->ev1));
     for (auto &e : c->ev_step) JH_HIP(hipEventCreate(&e));
@@ -223,6 +231,31 @@ extern "C" int32_t jh_context_destroy(jh_context ctx) {
     ctx->stage.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+  });
+}
+// Restricts the context's stream -- every kernel of the context -- to the compute units [first_cu, first_cu + n_cus) of the
+// device's CU-mask bit order (hipExtStreamCreateWithCUMask; on gfx942 / gfx950 consecutive bits alternate over the XCDs, so a
+// contiguous range takes the same share of every XCD).  n_cus <= 0 removes the mask.  For several ranks on ONE device (tests,
+// proxies of a multi-GPU run): with disjoint ranges no rank's spinning kernel can keep another rank's kernel off the chip.  Call
+// it before any other object of the context is created; persistent grids are sized by the CUs the mask leaves.
+extern "C" int32_t jh_context_set_cu_mask(jh_context ctx, int32_t first_cu, int32_t n_cus) {
+  return guard([&] {
+    if (!ctx) JH_THROW("null context");
+    JH_HIP(hipSetDevice(ctx->device));
+    JH_HIP(hipStreamSynchronize(ctx->stream));
+    hipStream_t ns = nullptr;
+    if (n_cus <= 0) {
+      JH_HIP(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+      ctx->ncu = ctx->ncu_total;
+    } else {
+      if (first_cu < 0 || first_cu + n_cus > ctx->ncu_total) JH_THROW("CU range outside the device's " + std::to_string(ctx->ncu_total) + " compute units");
+      std::vector<uint32_t> mask((size_t)(ctx->ncu_total + 31) / 32, 0u);
+      for (int i = first_cu; i < first_cu + n_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+      JH_HIP(hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
+      ctx->ncu = n_cus;
+    }
+    (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = ns;
   });
 }
 extern "C" int32_t jh_synchronize(jh_context ctx) {

@@ -93,7 +93,8 @@ struct Comm {
   Mailbox *mail_self = nullptr;
   std::vector<Mailbox *> mail_peer;  // [nranks], mail_peer[rank] == mail_self
   DevBuf<Mailbox *> d_mail_peer;
-  DevBuf<unsigned long long> mail_ctr;  // [0] all-reduces this rank has executed (the epoch lives on the device, see MailArgs)
+  uint64_t mail_epoch = 0;  // scalar all-reduces enqueued so far (every rank enqueues the same sequence; see Mailbox)
+  bool exclusive_cus = false;  // every rank has compute units of its own (jh_comm_set_exclusive): kernels may wait for peers in all wavefronts
   // time limit of the in-solve waits in 100 MHz ticks (JH_COMM_TIMEOUT_S; default 600 s: ranks may legitimately enter a reduction
   // far apart -- lazy first-solve set-up, JIT compilation on one rank, several ranks time-sharing a GPU -- and a timeout is sticky)
   uint64_t wait_ticks = 60000000000ull;
@@ -117,7 +118,7 @@ static MailArgs next_mail_args(jh_context ctx, uint64_t timeout_ticks) {
   Comm &c = *ctx->comm;
   MailArgs A;
   A.self = c.mail_self; A.peers = c.d_mail_peer.p; A.rank = c.rank; A.nranks = c.nranks;
-  A.ctr = c.mail_ctr.p; A.timeout_ticks = timeout_ticks; A.err = const_cast<MailErr *>(c.mail_err);
+  A.epoch = ++c.mail_epoch; A.timeout_ticks = timeout_ticks; A.err = const_cast<MailErr *>(c.mail_err);
   return A;
 }
 bool comm_mail_args(jh_context ctx, int n, MailArgs *out) {
@@ -141,6 +142,13 @@ void comm_check_errors(jh_context ctx) {
            std::to_string(ctx->comm->wait_ticks / 100000000ull) + " s waiting for rank " + std::to_string(e->peer) + " (epoch " +
            std::to_string(e->epoch) + ", " + std::to_string(e->count) + " timed-out waits so far); the peer process died, hung or "
            "runs a different sequence of collectives.  Set JH_BENCH_NO_MAILBOX=1 / JH_BENCH_NO_PUSH=1 to fall back to RCCL.");
+}
+// consumer-side all-reduces (PendSum::mail): mailboxes on and every rank owns its compute units; option xrank_consumer 0 / 1
+// overrides (-1: as the host declared through jh_comm_set_exclusive)
+bool comm_xrank_consumer(jh_context ctx) {
+  if (!ctx->comm || ctx->comm->nranks == 1 || !ctx->comm->mail_enabled) return false;
+  const int64_t o = ctx->opt.xrank_consumer;
+  return o < 0 ? ctx->comm->exclusive_cus : o != 0;
 }
 int comm_timeouts(jh_context ctx) { return (ctx->comm && ctx->comm->mail_err) ? (int)ctx->comm->mail_err->count : 0; }
 
@@ -190,6 +198,23 @@ static void halo_push(jh_tpfa d, double *v, int bs, hipStream_t s, bool packed, 
   if (H.n_send && !packed) halo_push_pack_launch(s, H.d_push_dst[par].p, v, H.d_send_idx.p, H.n_send, bs);
   halo_push_finish_launch(s, c.mail_self, c.d_mail_peer.p, H.d_nbr.p, (int)H.nbr.size(), c.rank, e, H.landing + par * H.landing_stride, v,
                           H.d_recv_idx.p, H.n_recv, bs, const_cast<MailErr *>(c.mail_err), timeout_ticks);
+}
+bool halo_fold_args(jh_tpfa d, double *v, HaloFold *out) {
+  auto &H = d->halo;
+  if (!H.active || !H.push_enabled || !d->ctx->comm) return false;
+  Comm &c = *d->ctx->comm;
+  if (H.d_ready.n == 0) {
+    H.d_ready.alloc(1);
+    JH_HIP(hipMemsetAsync(H.d_ready.p, 0, sizeof(unsigned long long), d->ctx->stream));
+  }
+  const uint64_t e = ++H.push_epoch;
+  HaloFold F;
+  F.self = c.mail_self; F.peers = c.d_mail_peer.p; F.nbr = H.d_nbr.p; F.n_nbr = (int)H.nbr.size(); F.rank = c.rank;
+  F.epoch = e; F.landing = H.landing + (e & 1) * H.landing_stride; F.xg = v; F.recv_idx = H.d_recv_idx.p; F.n_recv = (int)H.n_recv;
+  F.interior_rows = (int)std::max<int64_t>(0, d->pat->interior_rows);
+  F.ready = H.d_ready.p; F.err = const_cast<MailErr *>(c.mail_err); F.timeout_ticks = c.wait_ticks;
+  *out = F;
+  return true;
 }
 // where the producer of the NEXT pushed vector must store send slot k (N doubles each); nullptr when pushing is off
 double *const *halo_push_targets(jh_tpfa d) {
@@ -360,7 +385,7 @@ extern "C" int32_t jh_comm_info(jh_context ctx, int64_t *out8) {
     out8[0] = 1;
     if (!ctx->comm) return;
     Comm &c = *ctx->comm;
-    out8[0] = c.nranks; out8[1] = c.rank; out8[2] = c.rccl_ranks; out8[3] = c.mail_enabled ? 1 : 0;
+    out8[0] = c.nranks; out8[1] = c.rank; out8[2] = c.rccl_ranks; out8[3] = c.mail_enabled ? (comm_xrank_consumer(ctx) ? 3 : 1) : 0;
     out8[4] = c.halo_cb ? 1 : 0; out8[5] = c.local ? 1 : 0; out8[6] = comm_timeouts(ctx); out8[7] = (int64_t)(c.wait_ticks / 100000000ull);
   });
 }
@@ -411,8 +436,6 @@ extern "C" int32_t jh_comm_ipc_export(jh_context ctx, char *handle64) {
       JH_HIP(hipMemset(c.mail_self, 0, mailbox_bytes()));
       JH_HIP(hipHostMalloc((void **)&c.mail_err, sizeof(MailErr), hipHostMallocMapped | hipHostMallocCoherent));
       std::memset((void *)c.mail_err, 0, sizeof(MailErr));
-      c.mail_ctr.alloc(1);
-      JH_HIP(hipMemset(c.mail_ctr.p, 0, sizeof(unsigned long long)));
       c.wait_ticks = (uint64_t)std::max<int64_t>(0, ctx->opt.comm_timeout_ms) * 100000ull;  // 100 MHz ticks; 0 = unbounded
     }
     hipIpcMemHandle_t h;
@@ -467,6 +490,16 @@ extern "C" int32_t jh_comm_ipc_attach(jh_context ctx, const char *handles, int32
     }
     if (!good) clear_mail_error(c);  // the fallback path must stay usable
     *ok = good ? 1 : 0;
+  });
+}
+
+// exclusive = 1: no two ranks of the communicator share compute units (one process per GPU, or CU-masked streams on one GPU,
+// jh_context_set_cu_mask) -- the host knows, the library cannot.  Lets the Krylov loop finish its dot products over the ranks
+// inside the consuming kernels and fold the push-halo hand-shake into the product kernel (no reduction / finish launches).
+extern "C" int32_t jh_comm_set_exclusive(jh_context ctx, int32_t exclusive) {
+  return guard([&] {
+    if (!ctx || !ctx->comm) JH_THROW("no communicator");
+    ctx->comm->exclusive_cus = exclusive != 0;
   });
 }
 

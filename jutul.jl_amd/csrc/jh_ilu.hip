@@ -1293,6 +1293,7 @@ struct PendRegs {
   static constexpr int CNT = GM == 2 ? 2 : 1;  // GM 1: <c, A y>; GM 2: (rho', ||r||^2)
   double v[CNT][PEND_MAX / 64];
   double rho, rho_next, cv, ts, tt, done;  // the device scalars of the update, requested together with the partials
+  XrRegs xr;                               // several ranks: the peers' sums (first poll issued with everything else)
 };
 template <int GM>
 __device__ __forceinline__ void apply_prologue_loads(const IluGather &G, PendRegs<GM> &R) {
@@ -1313,6 +1314,7 @@ __device__ __forceinline__ void apply_prologue_loads(const IluGather &G, PendReg
 #pragma unroll
     for (int k = 0; k < PendRegs<GM>::CNT; ++k) R.v[k][j] = (i < G.pend.nparts) ? G.pend.part[(size_t)k * G.pend.stride + i] : 0.0;
   }
+  if (G.pend.mail.self) xr_load(G.pend.mail, R.xr);
 }
 template <int GM>
 __device__ __forceinline__ bool apply_prologue(const IluGather &G, PendRegs<GM> &R, double &ca, double &cb) {
@@ -1329,12 +1331,19 @@ __device__ __forceinline__ bool apply_prologue(const IluGather &G, PendRegs<GM> 
       for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
       p[k] = a;
     }
+    if (G.pend.mail.self) {  // the sums over the ranks (krylov.jl:51-105), finished by every wavefront as well
+      if (blockIdx.x == 0) xr_push(G.pend.mail, p[0], p[1]);
+      xr_sum(G.pend.mail, R.xr, blockIdx.x == 0, p[0], p[1]);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // for the kernels behind this one
       G.sc_rw[G.pend.out_slot] = p[0];
       if (GM == 2) G.sc_rw[G.pend.out_slot + 1] = p[1];
     }
   }
   double dn = R.done;
+  // every wavefront holds (rho', ||r||^2) of the previous iteration: all of them see its outcome, not only workgroup 0, and the
+  // speculative apply past convergence leaves p and y alone
+  if (GM == 2 && pend && G.pub_rec && sqrt(p[1]) <= G.pub_eps) dn = 1.0;
   if (GM == 2 && G.pub_rec && blockIdx.x == 0) {  // workgroup 0 publishes the previous iteration's record and knows its outcome
     if (threadIdx.x == 0) {
       publish_record(G.sc_rw, G.pub_pair, G.pub_eps, G.pub_rec, G.pub_seq);  // raises the done flag on convergence

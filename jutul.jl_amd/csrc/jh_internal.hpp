@@ -208,6 +208,7 @@ struct Comm;  // RCCL state (jh_comm.cpp)
   X(read_sync, 0)             /* device scalars through copy + stream synchronise instead of the pinned record */              \
   X(comm_timeout_ms, 600000)  /* limit of the mailbox / push-halo waits inside kernels, 0 = wait like a collective */          \
   X(setup_timing, 0)          /* print the set-up phases */                                                                    \
+  X(xrank_consumer, -1)       /* several ranks: dots all-reduced inside the consuming kernels + push-halo hand-shake inside the product; -1 = when the host declared exclusive compute units (jh_comm_set_exclusive) */ \
   X(jds_keep, 0)              /* jh_spmv_jagged: do not refresh the jagged copy (timing probe) */
 struct Options {
 #define JH_OPT_FIELD(name, def) int64_t name = def;
@@ -220,9 +221,18 @@ struct Options {
 
 // Mailbox of the node-local scalar all-reduce / push halo (jh_comm_ipc_*, jh_halo_ipc_*; protocol in jh_halo.hip)
 constexpr int MAIL_R = 16, MAIL_V = 8;
+// Slot sets of the scalar all-reduces, used round robin by epoch.  A rank is at most one executed all-reduce ahead of the slowest
+// one (it cannot finish epoch e' before everybody has contributed to e', i.e. has finished reading the epoch before it), so two
+// live sets exist at any time; the epoch is counted by the HOST per enqueued all-reduce and the launches of a speculative Krylov
+// iteration past convergence consume their epochs without executing (on every rank alike: the done flag derives from all-reduced
+// bits), which leaves gaps of a few epochs between consecutive executed ones -- eight sets keep any two live epochs apart.
+constexpr int MAIL_S = 8;
 struct Mailbox {
-  double val[2][MAIL_R][MAIL_V];
-  unsigned long long flag[2][MAIL_R];
+  double val[MAIL_S][MAIL_R][MAIL_V];
+  unsigned long long flag[MAIL_S][MAIL_R];
+  // consumer-side all-reduce of one or two sums (xr_* below): per source rank four self-validating 8-byte granules
+  // {epoch tag : 32 | half of a double : 32} -- no flag, no second round trip: a reader that sees four matching tags has the data
+  unsigned long long gran[MAIL_S][MAIL_R][4];
   unsigned long long hflag[2][MAIL_R];  // push halo: epoch of the last exchange whose data rank r has delivered here
   unsigned long long abort;             // != 0 once a wait of THIS rank has timed out: its later waits give up at once
 };
@@ -236,21 +246,42 @@ struct MailArgs {
   Mailbox *self = nullptr;
   Mailbox *const *peers = nullptr;
   int rank = 0, nranks = 1;
-  // Epoch = 1 + the number of all-reduces this rank has EXECUTED, kept on the device: a launch that returns early on the
-  // solver's done flag consumes no epoch, so consecutive executed all-reduces always alternate slot parity (a host-side
-  // counter would skip the epochs of the speculative iteration and reuse the parity of the last executed one).
-  unsigned long long *ctr = nullptr;
+  unsigned long long epoch = 0;          // 1 + the number of all-reduces enqueued before this one (host counter, equal on all ranks)
   unsigned long long timeout_ticks = 0;  // 100 MHz ticks, 0 = wait like a collective
   MailErr *err = nullptr;
+};
+
+// Push-halo hand-shake inside the product kernel (consistent! before mul!, ext/JutulPartitionedArraysExt/linalg.jl:37-55, without
+// a launch of its own): workgroup 0 of the product raises this rank's flag in the neighbours' mailboxes (the rows were pushed by
+// the preceding kernel), waits for theirs, copies the landed values into the ghost rows of the vector with write-through stores
+// and publishes `ready`; the other workgroups multiply the interior slices first and look at `ready` (one relaxed poll, one
+// agent-scope acquire per workgroup) before their first slice that can touch a ghost column.  self == nullptr: no fold.
+struct HaloFold {
+  Mailbox *self = nullptr;
+  Mailbox *const *peers = nullptr;
+  const int32_t *nbr = nullptr;
+  int n_nbr = 0, rank = 0;
+  unsigned long long epoch = 0;        // push epoch of this exchange (its parity selects the landing buffer)
+  const double *landing = nullptr;     // this rank's landing buffer of that parity, receive-list order
+  double *xg = nullptr;                // the vector whose ghost rows are filled
+  const int32_t *recv_idx = nullptr;   // device row of every received cell
+  int n_recv = 0;
+  int interior_rows = 0;               // rows [0, interior_rows) have no ghost column
+  unsigned long long *ready = nullptr; // device word: epoch of the last exchange whose ghosts are in place
+  MailErr *err = nullptr;
+  unsigned long long timeout_ticks = 0;
 };
 
 }  // namespace jh
 
 // ---- handle structs ------------------------------------------------------------------------------------
+constexpr int jh_num_xcd = 8;
 struct jh_context_s {
   int device = 0;
   jh::Options opt;
   hipStream_t stream = nullptr;
+  int ncu_total = 256, ncu = 256;  // compute units of the device / of the stream (jh_context_set_cu_mask)
+  int cus_per_xcd() const { return std::max(1, ncu / jh_num_xcd); }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_step[6] = {};  // jh_newton_step: factor / solve / update brackets, read once at the end of the step
   // reduction scratch: partial sums [NSLOT][max_blocks], device scalars, pinned host mirror
@@ -370,6 +401,7 @@ struct jh_tpfa_s {
     jh::DevBuf<int32_t> d_nbr;                 // neighbour ranks on the device
     uint64_t push_epoch = 0;
     bool push_attached = false, push_enabled = false;
+    jh::DevBuf<unsigned long long> d_ready;    // HaloFold::ready
   } halo;
 };
 
@@ -461,7 +493,10 @@ constexpr int JDS_FAR = 0xE000;   // first 16-bit column code that is an index i
 constexpr int JDS_BACK = 0x7000;  // the slice's column window starts this many rows before its first row
 bool sell_refresh(jh_csr A);  // false: the matrix has no jagged form (block size > 1 or long rows) -> CSR tile kernels
 int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done,
-                bool reduce_now = true, int waves = 4);
+                bool reduce_now = true, int waves = 4, const HaloFold *fold = nullptr);
+// jh_comm.cpp: the next push exchange of v as a HaloFold for the kernel that reads v (advances the push epoch); false: the push
+// halo is off
+bool halo_fold_args(jh_tpfa d, double *v, HaloFold *out);
 void spmv_dot_reduce(jh_context ctx, const SpmvDot *dot, int nparts, const double *done);
 void ensure_partials(jh_context ctx, size_t min_stride);
 void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max, const double *done = nullptr,
@@ -496,6 +531,12 @@ struct PendSum {
   unsigned stride = 0;           // second sum at part + stride
   int nparts = 0, count = 0;     // count 1 or 2
   int out_slot = 0;
+  // Several ranks (mail.self != nullptr): the local sums are all-reduced by the consumer as well (xr_push / xr_sum): wavefront 0 of
+  // workgroup 0 stores them into every peer's mailbox, every consuming wavefront collects the peers' sums from its own mailbox and
+  // adds them in rank order -- the same bits on every wavefront of every rank, still no launch between producer and consumer.
+  // Every wavefront of a chip-filling kernel then waits for the PEERS' workgroup 0: only where each rank has compute units of
+  // its own (one process per GPU, or CU-masked streams on a shared one), option xrank_consumer.
+  MailArgs mail;
 };
 // BiCGStab vector update fused into the gather phase of the ILU(0) apply (see ilu_apply_chunked_kernel)
 struct IluGather {
@@ -554,8 +595,8 @@ __device__ __forceinline__ void pend_sum_wave(const PendSum &P, double &s0, doub
 // All-reduce of p[0..n) (n <= MAIL_V, global or LDS memory, in place) over the ranks of the node.  Called by ALL threads of a
 // workgroup of >= 64 threads (threads 0..63 work, everybody joins the barrier); op 0 sum, 1 max (NaN propagating).  Each rank
 // stores its contribution into every rank's mailbox (xGMI peer stores, system-scope release on the epoch flag), waits
-// until all ranks have written into its own, and sums in rank order -- identical bits everywhere.  Two slot sets alternate
-// with the epoch parity: a rank cannot finish epoch e+1 before everybody has finished reading epoch e.
+// until all ranks have written into its own, and sums in rank order -- identical bits everywhere.  MAIL_S slot sets are used
+// round robin by epoch (see Mailbox).
 // A wait that ran out of time: tell the host who was missing (it turns that into a jh_last_error failure, comm_check_errors)
 // and make every later wait of this rank give up at once, so that the kernels already enqueued drain instead of each
 // sitting out its own time limit.
@@ -585,8 +626,8 @@ __device__ __forceinline__ bool mailbox_wait(const unsigned long long *flag, uns
   return true;
 }
 __device__ __forceinline__ void mailbox_allreduce_body(const MailArgs &A, double *p, int n, int op) {
-  const unsigned long long epoch = *A.ctr + 1ull;  // read by every thread before thread 0 advances it at the end
-  const int lane = threadIdx.x, par = (int)(epoch & 1ull);
+  const unsigned long long epoch = A.epoch;
+  const int lane = threadIdx.x, par = (int)(epoch % (unsigned long long)MAIL_S);
   if (lane < A.nranks) {
     Mailbox *dst = A.peers[lane];
     for (int i = 0; i < n; ++i) __hip_atomic_store(&dst->val[par][A.rank][i], p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -605,7 +646,107 @@ __device__ __forceinline__ void mailbox_allreduce_body(const MailArgs &A, double
     p[lane] = acc;
   }
   __syncthreads();
-  if (threadIdx.x == 0) *A.ctr = epoch;
+}
+
+// ---- push-halo hand-shake inside a kernel (HaloFold) ---------------------------------------------------------------------------
+// exchanger: all NT threads of ONE workgroup
+template <int NT>
+__device__ __forceinline__ void halo_fold_exchange(const HaloFold &H) {
+  const int par = (int)(H.epoch & 1ull);
+  if ((int)threadIdx.x < H.n_nbr) {
+    const int q = H.nbr[threadIdx.x];
+    // my rows for q are in place (stored by the previous kernel on this stream): tell q, then wait for q's
+    __hip_atomic_store(&H.peers[q]->hflag[par][H.rank], H.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!mailbox_wait(&H.self->hflag[par][q], H.epoch, H.timeout_ticks, H.self)) mailbox_wait_failed(H.self, H.err, 2ull, q, H.epoch);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H.n_recv; i += NT) {
+    const double v = __hip_atomic_load(H.landing + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(H.xg + H.recv_idx[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: visible to every XCD
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every writing wavefront drains before the flag
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(H.ready, H.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// consumer: all threads of a workgroup, once, before the first gather that can touch a ghost row
+__device__ __forceinline__ void halo_fold_wait(const HaloFold &H) {
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == 0) {
+      const unsigned long long t0 = wall_clock64();
+      unsigned spins = 0;
+      while (__hip_atomic_load(H.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < H.epoch) {
+        // (the exchanger reports a peer that never arrives; its own time limit ends this wait a little later)
+        if (H.timeout_ticks && (++spins & 15u) == 0 && wall_clock64() - t0 > H.timeout_ticks + 100000000ull) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 (one wavefront per workgroup)
+  }
+  __syncthreads();
+}
+
+// ---- consumer-side all-reduce of a PendSum over the ranks ------------------------------------------------------------------------
+// ext/JutulPartitionedArraysExt/krylov.jl:51-105 sums every dot over the ranks (MPI all-reduce inside PartitionedArrays' dot).
+// Granule i of a rank's contribution: (epoch tag << 32) | 32 bits of the sums (i = 0, 1: low / high half of s0; 2, 3: of s1).
+struct XrRegs {
+  unsigned long long g[4];  // lane r < nranks, r != rank: rank r's granules as last loaded
+};
+__device__ __forceinline__ void xr_load(const MailArgs &A, XrRegs &R) {
+  const int lane = threadIdx.x & 63;
+  if (lane < A.nranks && lane != A.rank) {
+    const unsigned long long *g = A.self->gran[A.epoch % (unsigned long long)MAIL_S][lane];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) R.g[i] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// ONE wavefront of the launch (wavefront 0 of workgroup 0), all 64 lanes: the local sums go to every peer
+__device__ __forceinline__ void xr_push(const MailArgs &A, double s0, double s1) {
+  const int lane = threadIdx.x & 63;
+  if (lane < A.nranks && lane != A.rank) {
+    unsigned long long *g = A.peers[lane]->gran[A.epoch % (unsigned long long)MAIL_S][A.rank];
+    const unsigned long long tag = (A.epoch & 0xffffffffull) << 32;
+    const unsigned long long b0 = (unsigned long long)__double_as_longlong(s0), b1 = (unsigned long long)__double_as_longlong(s1);
+    __hip_atomic_store(g + 0, tag | (b0 & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(g + 1, tag | (b0 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(g + 2, tag | (b1 & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(g + 3, tag | (b1 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// All 64 lanes of a wavefront, R from an earlier xr_load: waits until every peer's granules carry this epoch's tag, then replaces
+// (s0, s1) -- the local sums, the same bits in every lane -- by the sums over the ranks in rank order.  report: this wavefront
+// tells the host about a wait that ran out of time (one reporter per launch is enough; everybody gives up).
+__device__ __forceinline__ void xr_sum(const MailArgs &A, XrRegs &R, bool report, double &s0, double &s1) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long tag = A.epoch & 0xffffffffull;
+  double v0 = 0.0, v1 = 0.0;
+  if (lane < A.nranks && lane != A.rank) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned spins = 0;
+    for (;;) {
+      if ((R.g[0] >> 32) == tag && (R.g[1] >> 32) == tag && (R.g[2] >> 32) == tag && (R.g[3] >> 32) == tag) break;
+      if (A.timeout_ticks) {
+        bool giveup = wall_clock64() - t0 > A.timeout_ticks;
+        if (!giveup && (++spins & 63u) == 0) giveup = __hip_atomic_load(&A.self->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+        if (giveup) {
+          if (report) mailbox_wait_failed(A.self, A.err, 1ull, lane, A.epoch);
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(2);
+      xr_load(A, R);
+    }
+    v0 = __longlong_as_double((long long)((R.g[0] & 0xffffffffull) | (R.g[1] << 32)));
+    v1 = __longlong_as_double((long long)((R.g[2] & 0xffffffffull) | (R.g[3] << 32)));
+  }
+  double a0 = 0.0, a1 = 0.0;
+  for (int r = 0; r < A.nranks; ++r) {  // rank order: identical bits on every rank
+    const double t0 = (r == A.rank) ? s0 : __shfl(v0, r, 64);
+    const double t1 = (r == A.rank) ? s1 : __shfl(v1, r, 64);
+    a0 = r == 0 ? t0 : a0 + t0;
+    a1 = r == 0 ? t1 : a1 + t1;
+  }
+  s0 = a0;
+  s1 = a1;
 }
 
 // Second stage of the deterministic two-stage reductions: ONE 1024-thread block sums (or maxes) nparts partials of

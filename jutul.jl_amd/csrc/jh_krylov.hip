@@ -28,6 +28,7 @@ void ilu_factor(jh_ilu M);
 void halo_exchange(jh_tpfa d, double *v, int bs, bool packed = false, bool push = false);
 void comm_check_errors(jh_context ctx);
 int comm_size(jh_context ctx);
+bool comm_xrank_consumer(jh_context ctx);
 }  // namespace jh
 using namespace jh;
 
@@ -38,6 +39,8 @@ struct jh_krylov_s {
   int64_t len_dot = 0;  // owned part (dots / norms)
   DevBuf<double> r, p, c, s, q, y, z, d, v, t, xalt;
   int64_t min_its = 1;  // IterativeSolverConfig.min_iterations (krylov.jl:120-131)
+  int64_t last_path[6] = {0, 0, 0, 0, 0, 0};  // jh_krylov_last_path
+  int64_t launches = 0;  // kernels enqueued by the iteration being enqueued (counted at the launch sites of the loop)
   int64_t cur_it = 0;  // Krylov iteration the launches being enqueued belong to (profiling marks of speculative ones are dropped)
   // GMRES workspace: Krylov basis (grows on demand, Krylov.jl `restart = false`), device/pinned Hessenberg column
   std::vector<std::unique_ptr<DevBuf<double>>> gV;
@@ -116,10 +119,26 @@ __global__ __launch_bounds__(NT) void bicg_xr_dots_kernel(const double *x_in, do
                                                           const double *done, PendSum pend) {
   if (done && *done != 0.0) return;
   __shared__ double sm[2 * (NT / 64)];
-  double ts = sc[S_TS], tt = sc[S_TT];
+  double ts = 0.0, tt = 0.0;
   if (pend.part) {
-    pend_sum_wave(pend, ts, tt);
+    if (pend.mail.self) {  // several ranks: wavefront 0 of every workgroup collects the peers' sums, the others take them from LDS
+      __shared__ double xs2[2];
+      if (threadIdx.x < 64) {
+        XrRegs xr;
+        xr_load(pend.mail, xr);
+        pend_sum_wave(pend, ts, tt);
+        if (blockIdx.x == 0) xr_push(pend.mail, ts, tt);
+        xr_sum(pend.mail, xr, blockIdx.x == 0, ts, tt);
+        if (threadIdx.x == 0) { xs2[0] = ts; xs2[1] = tt; }
+      }
+      __syncthreads();
+      ts = xs2[0]; tt = xs2[1];
+    } else {
+      pend_sum_wave(pend, ts, tt);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc[S_TS] = ts; sc[S_TT] = tt; }
+  } else {  // (workgroup 0 may be storing the pair when it is pending: read only when it is not)
+    ts = sc[S_TS]; tt = sc[S_TT];
   }
   const double alpha = sc[rho_slot] / sc[S_CV];
   const double omega = bicg_omega(ts, tt);
@@ -181,7 +200,13 @@ __global__ __launch_bounds__(NT) void bicg_xr_dots_kernel(const double *x_in, do
 __global__ __launch_bounds__(64) void bicg_pend_publish_kernel(PendSum pend, double *sc, const double *done, double eps, double *rec, double seq) {
   if (done && *done != 0.0) return;
   double p0, p1;
+  XrRegs xr;
+  if (pend.mail.self) xr_load(pend.mail, xr);
   pend_sum_wave(pend, p0, p1);
+  if (pend.mail.self) {
+    xr_push(pend.mail, p0, p1);
+    xr_sum(pend.mail, xr, true, p0, p1);
+  }
   if (threadIdx.x == 0) {
     sc[pend.out_slot] = p0;
     sc[pend.out_slot + 1] = p1;
@@ -337,24 +362,34 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   // sums its partials itself (PendSum) -- <c, A y> in the s-update apply, (<t,s>, <t,t>) in the x,r kernel, (rho', ||r||^2) in the
   // next iteration's p-update apply, whose workgroup 0 also publishes the record.  Four one-workgroup launches per iteration gone;
   // the producers run with larger workgroups so that a full-chip launch leaves at most PEND_MAX partials.
-  const bool pend_ok = ctx->opt.consumer_reduce && !fmul && jagged && right && ilu_can_fuse_gather(M) && !dist && comm_size(ctx) == 1;
+  // Several ranks: the same, with the sums over the ranks finished by the consumers too (PendSum::mail) -- where every rank has
+  // compute units of its own (comm_xrank_consumer); otherwise the dots go through the reduction launch that carries the all-reduce.
+  const bool xrank = comm_xrank_consumer(ctx) && !(dist && want_overlap);
+  const bool pend_ok = ctx->opt.consumer_reduce && !fmul && jagged && right && ilu_can_fuse_gather(M) && (comm_size(ctx) == 1 || xrank);
+  auto pend_mail = [&](PendSum &ps) { if (xrank && !comm_mail_args(ctx, 2, &ps.mail)) JH_THROW("consumer-side all-reduce without mailboxes"); };
+  // ... and the push halo's signal / wait / copy runs inside the product kernel that reads the vector (HaloFold) instead of a
+  // finish launch: five launches per iteration as on one rank
+  const bool halo_fold = pend_ok && xrank && dist && disc->halo.push_enabled && ilu_can_pack_halo(M) && P.bs == 1;
   PendSum pend_spmv;  // partials of the last product with a fused dot
   // 16 wavefronts per workgroup: <= 512 partials for the consumers above, and the faster product at every size measured (10M rows
   // 0.160 vs 0.174-0.182 ms with 4, one workgroup per CU; 1.25M rows 26.1 vs 27.4 us) -- also where the dots still go through the
   // reduction launch (several ranks)
   const int spmv_waves = ctx->opt.spmv_waves ? (int)ctx->opt.spmv_waves : 16;
   auto spmv = [&](double *in, double *out, const SpmvDot *dot, bool packed = false) {
-    if (dist) halo_exchange(disc, in, P.bs, packed, true);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
+    HaloFold hf;
+    const bool fold = halo_fold && packed && spmv_waves == 16 && halo_fold_args(disc, in, &hf);
+    if (dist && !fold) halo_exchange(disc, in, P.bs, packed, true);  // consistent!(X) before every mul! (ext/.../linalg.jl:46)
     K->mark(0, st);
     if (jagged) {
       // the event pair brackets the product kernel alone (what rocprofv3 reports for it); the second stage of its fused dot,
       // with the all-reduce over the ranks, follows -- or is left to the consuming kernel
-      const int nparts = k_spmv_sell(K->A, in, out, 1.0, 0.0, dot, done, false, spmv_waves);
+      const int nparts = k_spmv_sell(K->A, in, out, 1.0, 0.0, dot, done, false, spmv_waves, fold ? &hf : nullptr);
       K->mark(0, st);
       if (dot && dot->mode) {
         if (pend_ok && nparts <= PEND_MAX) {
           pend_spmv.part = ctx->partials.p; pend_spmv.stride = (unsigned)ctx->partial_stride; pend_spmv.nparts = nparts;
           pend_spmv.count = dot->mode == 2 ? 2 : 1; pend_spmv.out_slot = dot->slot;
+          pend_mail(pend_spmv);
         } else {
           pend_spmv = PendSum();
           spmv_dot_reduce(ctx, dot, nparts, done);
@@ -531,6 +566,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       pend_spmv = PendSum();
       PendSum px;
       px.part = xpart; px.stride = (unsigned)ctx->partial_stride; px.nparts = (int)g.x; px.count = 2; px.out_slot = rn;
+      pend_mail(px);
       if (lag == 1 && k < itmax) { pend_xr = px; pend_rec = rec; pend_seq = seq; pend_pair = rn; pend_eps = eps_at(k); }
       else hipLaunchKernelGGL(bicg_pend_publish_kernel, dim3(1), dim3(64), 0, st, px, sc, done, eps_at(k), rec, seq);
       return;
@@ -553,6 +589,8 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     // p-update: deferred into the next iteration's first ILU apply when fused
     if (!fuse) hipLaunchKernelGGL(bicg_p_kernel, vgrid(n), dim3(256), 0, st, K->p.p, K->r.p, vv, sc, rs, rn, n);
   };
+  K->last_path[0] = pend_ok; K->last_path[1] = pend_ok && xrank; K->last_path[2] = jagged; K->last_path[3] = fmul;
+  K->last_path[4] = dist && disc->halo.push_enabled; K->last_path[5] = halo_fold;
   int64_t it = 0, enq = 0;
   while (!solved && it < itmax && status == 0) {
     while (enq < std::min<int64_t>(itmax, it + 1 + lag)) enqueue(++enq);
@@ -721,6 +759,17 @@ extern "C" int32_t jh_krylov_set_min_iterations(jh_krylov K, int64_t min_iterati
   return guard([&] {
     if (!K) JH_THROW("null handle");
     K->min_its = min_iterations < 1 ? 1 : min_iterations;
+  });
+}
+
+// Which path the last BiCGStab solve of this workspace took: out6 = [0] 1 = dot products finished by the consuming kernels (no
+// reduction launches), [1] 1 = over several ranks as well (mailbox granules), [2] 1 = products out of the jagged-slice copy,
+// [3] 1 = products fused into the preconditioner apply, [4] 1 = ghost exchanges of the loop are push halos, [5] 1 = their
+// hand-shake runs inside the product kernel (no finish launch).
+extern "C" int32_t jh_krylov_last_path(jh_krylov K, int64_t *out6) {
+  return guard([&] {
+    if (!K || !out6) JH_THROW("null argument");
+    for (int i = 0; i < 6; ++i) out6[i] = K->last_path[i];
   });
 }
 

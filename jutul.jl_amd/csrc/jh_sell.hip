@@ -186,28 +186,60 @@ __device__ __forceinline__ void jds_dot_partial(double d0, double d1, int dotv, 
     if (dotv == 2) part[pstride + blockIdx.x] = b[0];
   }
 }
-template <int KU, int DOT, int NW, bool NT>
+// Steps of a persistent product workgroup: workgroup b runs on XCD b % 8 (observed placement, performance only) and every XCD
+// sweeps one contiguous eighth of the super-slices (NW slices = 64 NW rows, one per wavefront of the workgroup).  FOLD (push-halo
+// hand-shake inside the kernel, HaloFold): workgroup 0 is the exchanger and takes no slices; the others sweep an eighth of the
+// INTERIOR super-slices first and an eighth of the rest -- boundary and ghost rows, the last device rows -- afterwards, behind
+// halo_fold_wait.
+template <int NW, bool FOLD>
+struct JSteps {
+  int ilo, ni, blo, nb;  // this XCD's interior / other super-slices
+  int t0, dt;            // first step and step stride of this workgroup
+  int w, nslices;
+  __device__ __forceinline__ JSteps(int nslices_, int interior_rows, int w_) : w(w_), nslices(nslices_) {
+    const int nsup = (nslices + NW - 1) / NW;
+    const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, wgs = gridDim.x / NUM_XCD;
+    const int sbs = FOLD ? min(nsup, max(0, interior_rows) / (64 * NW)) : nsup;
+    const int ci = (sbs + NUM_XCD - 1) / NUM_XCD, cb = (nsup - sbs + NUM_XCD - 1) / NUM_XCD;
+    ilo = xcd * ci;
+    ni = max(0, min(sbs, ilo + ci) - ilo);
+    blo = sbs + xcd * cb;
+    nb = max(0, min(nsup, blo + cb) - blo);
+    const int ex = (FOLD && xcd == 0) ? 1 : 0;  // the exchanger is workgroup 0 of XCD 0
+    t0 = wg - ex;
+    dt = wgs - ex;
+  }
+  __device__ __forceinline__ int steps() const { return ni + nb; }
+  // slice of this wavefront at step t; >= nslices: none
+  __device__ __forceinline__ int slice(int t) const {
+    if (t >= ni + nb) return 0x3fffffff;
+    return NW * (t < ni ? ilo + t : blo + (t - ni)) + w;
+  }
+};
+template <int KU, int DOT, int NW, bool NT, bool FOLD>
 __global__ __launch_bounds__(64 * NW) void spmv_jds_kernel(const int32_t *__restrict__ base, const uint4 *__restrict__ cnt16,
                                                        const uint8_t *__restrict__ perm, const int32_t *__restrict__ jcol,
                                                        const double *__restrict__ jval, int nslices, int nrows,
                                                        const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
                                                        const double *__restrict__ dw, int dot_rows, double *__restrict__ part,
-                                                       size_t pstride, const double *done) {
+                                                       size_t pstride, const double *done, HaloFold H) {
   if (done && *done != 0.0) return;
   __shared__ double tr[NW][64];
   __shared__ double red[2 * NW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // workgroup b runs on XCD b % 8 (observed placement, performance only): each XCD sweeps one contiguous eighth of the slices
-  const int nsup = (nslices + NW - 1) / NW;  // steps: NW slices = 64 NW rows each
-  const int chunk = (nsup + NUM_XCD - 1) / NUM_XCD;
-  const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, wgs = gridDim.x / NUM_XCD;
-  const int stride = wgs * NW;
-  const int s_end = min(nslices, NW * min(nsup, (xcd + 1) * chunk));
-  const int s_loop_end = NW * min(nsup, (xcd + 1) * chunk);  // uniform over the workgroup (the barrier below)
+  if (FOLD && blockIdx.x == 0) {  // the exchanger: ghost rows of x, no slices, an empty dot partial
+    halo_fold_exchange<64 * NW>(H);
+    if (DOT && tid == 0) { part[0] = 0.0; if (DOT == 2) part[pstride] = 0.0; }
+    return;
+  }
+  const double *xx = FOLD ? H.xg : x;  // (FOLD: the ghost rows change during the launch -- not through the restrict pointer)
+  const JSteps<NW, FOLD> S(nslices, H.interior_rows, w);
+  const int T = S.steps(), dt = S.dt;  // uniform over the workgroup (the barrier below)
+  bool crossed = false;
   double d0 = 0.0, d1 = 0.0;
   auto ldesc = [&](int s, JDesc &D) {
-    if (s < s_end) { D.base = base[s]; D.c = cnt16[s]; }
+    if (s < nslices) { D.base = base[s]; D.c = cnt16[s]; }
     else { D.base = 0; D.c = make_uint4(0, 0, 0, 0); }
   };
   auto lent = [&](int s, const JDesc &D, JEnt<KU> &E) {
@@ -222,19 +254,21 @@ __global__ __launch_bounds__(64 * NW) void spmv_jds_kernel(const int32_t *__rest
 #undef JH_LENT
     E.prow = (int)perm[(size_t)min(s, nslices - 1) * 64 + lane];
   };
-  int s = NW * (xcd * chunk + wg) + w;
+  int t = S.t0;
   JDesc dc, dn, dnn;
   JEnt<KU> ec, en;
-  ldesc(s, dc);
-  ldesc(s + stride, dn);
-  lent(s, dc, ec);
-  for (; s - w < s_loop_end; s += stride) {
-    ldesc(s + 2 * stride, dnn);
-    lent(s + stride, dn, en);
+  ldesc(S.slice(t), dc);
+  ldesc(S.slice(t + dt), dn);
+  lent(S.slice(t), dc, ec);
+  for (; t < T; t += dt) {
+    const int s = S.slice(t);
+    ldesc(S.slice(t + 2 * dt), dnn);
+    lent(S.slice(t + dt), dn, en);
     __syncthreads();  // keeps the wavefronts of the workgroup on neighbouring slices
+    if (FOLD && !crossed && t >= S.ni) { halo_fold_wait(H); crossed = true; }  // the ghost rows of x are in place from here on
     double xg[KU];
     // (unconditional as well: an unused lane holds some other entry's column id, a valid index)
-#define JH_GATH(J) if (J < KU) xg[J < KU ? J : 0] = x[ec.col[J < KU ? J : 0]];
+#define JH_GATH(J) if (J < KU) xg[J < KU ? J : 0] = xx[ec.col[J < KU ? J : 0]];
     JH_GATH(0) JH_GATH(1) JH_GATH(2) JH_GATH(3) JH_GATH(4) JH_GATH(5) JH_GATH(6) JH_GATH(7)
 #undef JH_GATH
     double acc = 0.0;
@@ -243,7 +277,7 @@ __global__ __launch_bounds__(64 * NW) void spmv_jds_kernel(const int32_t *__rest
 #undef JH_ACC
     // lane -> row: through the wavefront's LDS strip (the LDS operations of one wavefront complete in order), so that y is
     // stored -- and the dot weights are read -- as 512 contiguous bytes
-    const int nr = (s < s_end) ? min(64, nrows - s * 64) : 0;
+    const int nr = (s < nslices) ? min(64, nrows - s * 64) : 0;
     if (lane < nr) tr[w][ec.prow] = acc;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -276,28 +310,31 @@ struct JDesc16 {
   int base, cb, fo;
   uint4 c;
 };
-template <int KU, int DOT, int NW>
+template <int KU, int DOT, int NW, bool FOLD>
 __global__ __launch_bounds__(64 * NW) void spmv_jds16_kernel(const int32_t *__restrict__ base, const uint4 *__restrict__ cnt16,
                                                          const uint8_t *__restrict__ perm, const uint16_t *__restrict__ jcol,
                                                          const int2 *__restrict__ win, const int32_t *__restrict__ far,
                                                          const double *__restrict__ jval, int nslices, int nrows,
                                                          const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
                                                          const double *__restrict__ dw, int dot_rows, double *__restrict__ part,
-                                                         size_t pstride, const double *done) {
+                                                         size_t pstride, const double *done, HaloFold H) {
   if (done && *done != 0.0) return;
   __shared__ double tr[NW][64];
   __shared__ double red[2 * NW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nsup = (nslices + NW - 1) / NW;
-  const int chunk = (nsup + NUM_XCD - 1) / NUM_XCD;
-  const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, wgs = gridDim.x / NUM_XCD;
-  const int stride = wgs * NW;
-  const int s_end = min(nslices, NW * min(nsup, (xcd + 1) * chunk));
-  const int s_loop_end = NW * min(nsup, (xcd + 1) * chunk);  // uniform over the workgroup (the barrier below)
+  if (FOLD && blockIdx.x == 0) {  // the exchanger (see spmv_jds_kernel)
+    halo_fold_exchange<64 * NW>(H);
+    if (DOT && tid == 0) { part[0] = 0.0; if (DOT == 2) part[pstride] = 0.0; }
+    return;
+  }
+  const double *xx = FOLD ? H.xg : x;
+  const JSteps<NW, FOLD> S(nslices, H.interior_rows, w);
+  const int T = S.steps(), dt = S.dt;  // uniform over the workgroup (the barrier below)
+  bool crossed = false;
   double d0 = 0.0, d1 = 0.0;
   auto ldesc = [&](int s, JDesc16 &D) {
-    if (s < s_end) { D.base = base[s]; D.c = cnt16[s]; const int2 wf = win[s]; D.cb = wf.x; D.fo = wf.y; }
+    if (s < nslices) { D.base = base[s]; D.c = cnt16[s]; const int2 wf = win[s]; D.cb = wf.x; D.fo = wf.y; }
     else { D.base = 0; D.c = make_uint4(0, 0, 0, 0); D.cb = 0; D.fo = 0; }
   };
   auto lraw = [&](int s, const JDesc16 &D, JRaw<KU> &E) {
@@ -323,30 +360,32 @@ __global__ __launch_bounds__(64 * NW) void spmv_jds16_kernel(const int32_t *__re
     }
     E.prow = R.prow;
   };
-  int s = NW * (xcd * chunk + wg) + w;
+  int t = S.t0;
   JDesc16 dc, dn, dnn, dnnn;
   JRaw<KU> rn, rnn;
   JEnt<KU> ec, en;
-  ldesc(s, dc);
-  ldesc(s + stride, dn);
-  ldesc(s + 2 * stride, dnn);
-  lraw(s, dc, rn);
+  ldesc(S.slice(t), dc);
+  ldesc(S.slice(t + dt), dn);
+  ldesc(S.slice(t + 2 * dt), dnn);
+  lraw(S.slice(t), dc, rn);
   decode(dc, rn, ec);
-  lraw(s + stride, dn, rn);
-  for (; s - w < s_loop_end; s += stride) {
-    ldesc(s + 3 * stride, dnnn);
-    lraw(s + 2 * stride, dnn, rnn);
+  lraw(S.slice(t + dt), dn, rn);
+  for (; t < T; t += dt) {
+    const int s = S.slice(t);
+    ldesc(S.slice(t + 3 * dt), dnnn);
+    lraw(S.slice(t + 2 * dt), dnn, rnn);
     decode(dn, rn, en);  // (its far-list loads complete during this slice's gathers)
     __syncthreads();  // keeps the wavefronts of the workgroup on neighbouring slices
+    if (FOLD && !crossed && t >= S.ni) { halo_fold_wait(H); crossed = true; }
     double xg[KU];
-#define JH_GATH(J) if (J < KU) xg[J < KU ? J : 0] = x[ec.col[J < KU ? J : 0]];
+#define JH_GATH(J) if (J < KU) xg[J < KU ? J : 0] = xx[ec.col[J < KU ? J : 0]];
     JH_GATH(0) JH_GATH(1) JH_GATH(2) JH_GATH(3) JH_GATH(4) JH_GATH(5) JH_GATH(6) JH_GATH(7)
 #undef JH_GATH
     double acc = 0.0;
 #define JH_ACC(J) if (J < KU) { const double t = acc + ec.val[J < KU ? J : 0] * xg[J < KU ? J : 0]; acc = (lane < jcount<J>(dc.c)) ? t : acc; }
     JH_ACC(0) JH_ACC(1) JH_ACC(2) JH_ACC(3) JH_ACC(4) JH_ACC(5) JH_ACC(6) JH_ACC(7)
 #undef JH_ACC
-    const int nr = (s < s_end) ? min(64, nrows - s * 64) : 0;
+    const int nr = (s < nslices) ? min(64, nrows - s * 64) : 0;
     if (lane < nr) tr[w][ec.prow] = acc;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -403,8 +442,9 @@ static int resident_per_cu(KernelT kernel, int threads) {
 
 // reduce_now = false: the caller launches the second stage of the fused dot itself (spmv_dot_reduce with the returned count) or
 // hands the partials to the consuming kernel (PendSum).  waves: wavefronts per workgroup, 4 / 8 / 16 (see spmv_jds_kernel).
+// fold: push-halo hand-shake inside the launch (HaloFold); the caller checked sell_can_fold.
 int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done, bool reduce_now,
-                int waves) {
+                int waves, const HaloFold *fold) {
   jh_context ctx = A->ctx;
   const Pattern &P = *A->pat;
   const auto &J = P.jag;
@@ -412,31 +452,40 @@ int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta,
   if (waves != 4 && waves != 8 && waves != 16) JH_THROW("jagged-slice SpMV: 4, 8 or 16 wavefronts per workgroup");
   const int mode = dot ? dot->mode : 0;
   const int nsup = (J.nslices + waves - 1) / waves;
-  const int chunk = (nsup + NUM_XCD - 1) / NUM_XCD;
+  const bool folded = fold && fold->self;
+  // steps of the busiest XCD (JSteps)
+  int chunk = (nsup + NUM_XCD - 1) / NUM_XCD;
+  if (folded) {
+    const int sbs = std::min<int>(nsup, std::max(0, fold->interior_rows) / (64 * waves));
+    chunk = (sbs + NUM_XCD - 1) / NUM_XCD + (nsup - sbs + NUM_XCD - 1) / NUM_XCD;
+  }
   const double *dw = dot ? dot->w : nullptr;
   const int drows = dot ? (int)dot->n_rows : 0;
+  const HaloFold H = folded ? *fold : HaloFold();
   dim3 block(64 * waves);
   int nparts = 0;
   auto launch = [&](auto kernel, auto... args) {
-    // persistent grid: what is resident at once (32 CUs per XCD), or option spmv_waves_per_xcd
+    // persistent grid: what is resident at once (32 CUs per XCD, fewer under a CU mask), or option spmv_waves_per_xcd
     const int cap = ctx->opt.spmv_waves_per_xcd > 0 ? std::max<int>(1, (int)ctx->opt.spmv_waves_per_xcd / waves)
-                                                    : 32 * resident_per_cu(kernel, 64 * waves);
-    dim3 grid((unsigned)(std::max(1, std::min(chunk, cap)) * NUM_XCD));
+                                                    : ctx->cus_per_xcd() * resident_per_cu(kernel, 64 * waves);
+    // (folded: one more workgroup per XCD -- XCD 0's first one is the exchanger -- and never fewer than two)
+    dim3 grid((unsigned)(std::max(folded ? 2 : 1, std::min(chunk + (folded ? 1 : 0), cap)) * NUM_XCD));
     if (mode) ensure_partials(ctx, (size_t)grid.x);
     hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, args..., A->jval.p, J.nslices, (int)P.n, x, y, alpha, beta, dw, drows,
-                       ctx->partials.p, ctx->partial_stride, done);
+                       ctx->partials.p, ctx->partial_stride, done, H);
     nparts = (int)grid.x;
   };
-#define JH_JDS(KU, DV, NWV)                                                                                                             \
+#define JH_JDS(KU, DV, NWV, FO)                                                                                                             \
   do {                                                                                                                                 \
-    if (J.nontemporal) launch(spmv_jds_kernel<KU, DV, NWV, true>, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), J.d_perm.p, J.d_col.p); \
-    else launch(spmv_jds_kernel<KU, DV, NWV, false>, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), J.d_perm.p, J.d_col.p);              \
+    if (J.nontemporal) launch(spmv_jds_kernel<KU, DV, NWV, true, FO>, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), J.d_perm.p, J.d_col.p); \
+    else launch(spmv_jds_kernel<KU, DV, NWV, false, FO>, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), J.d_perm.p, J.d_col.p);              \
   } while (0)
-#define JH_JDS16(KU, DV, NWV)                                                                                               \
-  launch(spmv_jds16_kernel<KU, DV, NWV>, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), J.d_perm.p, J.d_col16.p, \
+#define JH_JDS16(KU, DV, NWV, FO)                                                                                               \
+  launch(spmv_jds16_kernel<KU, DV, NWV, FO>, J.d_base.p, reinterpret_cast<const uint4 *>(J.d_cnt.p), J.d_perm.p, J.d_col16.p, \
          reinterpret_cast<const int2 *>(J.d_win.p), J.d_far.p)
-#define JH_JDS_M(K, KU, NWV) do { if (mode == 0) K(KU, 0, NWV); else if (mode == 1) K(KU, 1, NWV); else K(KU, 2, NWV); } while (0)
-#define JH_JDS_W(K, KU) do { if (waves == 4) JH_JDS_M(K, KU, 4); else if (waves == 8) JH_JDS_M(K, KU, 8); else JH_JDS_M(K, KU, 16); } while (0)
+#define JH_JDS_M(K, KU, NWV, FO) do { if (mode == 0) K(KU, 0, NWV, FO); else if (mode == 1) K(KU, 1, NWV, FO); else K(KU, 2, NWV, FO); } while (0)
+#define JH_JDS_W(K, KU) do { if (folded) JH_JDS_M(K, KU, 16, true); else if (waves == 4) JH_JDS_M(K, KU, 4, false); else if (waves == 8) JH_JDS_M(K, KU, 8, false); else JH_JDS_M(K, KU, 16, false); } while (0)
+  if (folded && waves != 16) JH_THROW("folded push halo: 16 wavefronts per workgroup");
   if (J.d_col.n == 0) {  // 16-bit column codes (default)
     if (J.kmax <= 5) JH_JDS_W(JH_JDS16, 5); else JH_JDS_W(JH_JDS16, 8);
   } else {

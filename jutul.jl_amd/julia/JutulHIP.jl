@@ -555,7 +555,9 @@ struct HIPDistributedExecutor <: Jutul.JutulExecutor
     nranks::Int
 end
 
-function setup_distributed!(ctx::HIPContext, nranks::Integer, rank::Integer, bcast, allgather)
+# exclusive_devices: every rank drives a GPU of its own (the deployment: one process per GPU) -- the Krylov loop then finishes its
+# dot products over the ranks inside the consuming kernels (jh_comm_set_exclusive); pass false when ranks share a device.
+function setup_distributed!(ctx::HIPContext, nranks::Integer, rank::Integer, bcast, allgather; exclusive_devices::Bool = true)
     id = zeros(UInt8, 128)
     if rank == 0
         @jh :jh_comm_unique_id (Ptr{UInt8},) id
@@ -570,6 +572,7 @@ function setup_distributed!(ctx::HIPContext, nranks::Integer, rank::Integer, bca
     @jh :jh_comm_ipc_attach (Handle, Ptr{UInt8}, Ref{Int32}) ctx.handle all ok
     everyone = minimum(allgather(ok[])) == 1
     @jh :jh_comm_ipc_enable (Handle, Int32) ctx.handle Int32(everyone)
+    @jh :jh_comm_set_exclusive (Handle, Int32) ctx.handle Int32(everyone && exclusive_devices)
     info = zeros(Int64, 8)
     @jh :jh_comm_info (Handle, Ptr{Int64}) ctx.handle info
     info[1] == nranks && info[3] == nranks || error("communicator has $(info[1]) ranks ($(info[3]) in RCCL), expected $nranks")
