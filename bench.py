@@ -211,6 +211,16 @@ def main():
         k, _, v = kv.partition("=")
         options[k.strip()] = int(v) if v else 1
     ctx = ja.HIPContext(device, **options)
+    # Several ranks on ONE device with compute units of their own (JH_BENCH_CU_MASK=1: rank r gets CUs [r*256/N, (r+1)*256/N)):
+    # the proxy of one-process-per-GPU the test box allows -- a kernel whose wavefronts wait for a peer cannot keep it off the chip
+    cu_masked = shared_device and os.environ.get("JH_BENCH_CU_MASK") == "1"
+    if cu_masked:
+        ctx.set_cu_mask(rank * (256 // world), 256 // world)
+    elif world == 1 and os.environ.get("JH_BENCH_CUS"):  # one rank on a share of the chip: the proxy's no-communication reference
+        ctx.set_cu_mask(0, int(os.environ["JH_BENCH_CUS"]))
+    # every rank has compute units of its own: the Krylov loop finishes its dots over the ranks inside the consuming kernels and
+    # hand-shakes the push halo inside the product kernel (five launches per iteration, as on one rank)
+    exclusive = world > 1 and (not shared_device or cu_masked) and os.environ.get("JH_BENCH_NO_XRANK") != "1"
     mailbox = push = attached_all = False
     force_dist = os.environ.get("JH_BENCH_FORCE_DIST") == "1"  # exercise the distributed code path on one rank
     host_halo = False
@@ -259,6 +269,7 @@ def main():
             attached_all = bool(int(flag[0]))
             mailbox = attached_all and os.environ.get("JH_BENCH_NO_MAILBOX") != "1"
             ctx.comm_ipc_enable(mailbox)
+            ctx.comm_set_exclusive(exclusive and mailbox)
         cells = sub["cells"] - 1
         n_owned = sub["n_owned"]
         disc = ja.TwoPointPotentialFlowHardCoded(ctx, sub["N"], sub["n_local"], block_n=N, reorder="blocks", block_rows=args.block_rows,
@@ -525,6 +536,7 @@ def main():
                        "ranks_seen": ranks_seen, "devices_used": devices_used, "rccl_ranks": cinfo["rccl_ranks"],
                        "scalar_allreduce": ("mailbox" if mailbox else "rccl") if world > 1 else None,
                        "krylov_halo": ("push" if push else ("host-callback" if host_halo else "rccl")) if world > 1 else None,
+                       "krylov_path": ks.last_path(), "cu_masked_ranks": cu_masked,
                        "halo": ("host-callback (test mode)" if host_halo else "rccl") if world > 1 else None,
                        "comm_timeouts": timeouts, "comm_timeout_s": cinfo["timeout_s"],
                        "ilu_blocks": info["nblocks"], "ilu_max_levels": info["max_levels"],

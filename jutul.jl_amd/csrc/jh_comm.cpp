@@ -194,7 +194,7 @@ static void halo_push(jh_tpfa d, double *v, int bs, hipStream_t s, bool packed, 
   Comm &c = *d->ctx->comm;
   if (timeout_ticks == ~0ull) timeout_ticks = c.wait_ticks;
   const uint64_t e = ++H.push_epoch;
-  const int par = (int)(e & 1);
+  const int par = (int)(e % HALO_S);
   if (H.n_send && !packed) halo_push_pack_launch(s, H.d_push_dst[par].p, v, H.d_send_idx.p, H.n_send, bs);
   halo_push_finish_launch(s, c.mail_self, c.d_mail_peer.p, H.d_nbr.p, (int)H.nbr.size(), c.rank, e, H.landing + par * H.landing_stride, v,
                           H.d_recv_idx.p, H.n_recv, bs, const_cast<MailErr *>(c.mail_err), timeout_ticks);
@@ -210,7 +210,7 @@ bool halo_fold_args(jh_tpfa d, double *v, HaloFold *out) {
   const uint64_t e = ++H.push_epoch;
   HaloFold F;
   F.self = c.mail_self; F.peers = c.d_mail_peer.p; F.nbr = H.d_nbr.p; F.n_nbr = (int)H.nbr.size(); F.rank = c.rank;
-  F.epoch = e; F.landing = H.landing + (e & 1) * H.landing_stride; F.xg = v; F.recv_idx = H.d_recv_idx.p; F.n_recv = (int)H.n_recv;
+  F.epoch = e; F.landing = H.landing + (e % HALO_S) * H.landing_stride; F.xg = v; F.recv_idx = H.d_recv_idx.p; F.n_recv = (int)H.n_recv;
   F.interior_rows = (int)std::max<int64_t>(0, d->pat->interior_rows);
   F.ready = H.d_ready.p; F.err = const_cast<MailErr *>(c.mail_err); F.timeout_ticks = c.wait_ticks;
   *out = F;
@@ -219,7 +219,7 @@ bool halo_fold_args(jh_tpfa d, double *v, HaloFold *out) {
 // where the producer of the NEXT pushed vector must store send slot k (N doubles each); nullptr when pushing is off
 double *const *halo_push_targets(jh_tpfa d) {
   auto &H = d->halo;
-  return H.push_enabled ? H.d_push_dst[(H.push_epoch + 1) & 1].p : nullptr;
+  return H.push_enabled ? H.d_push_dst[(H.push_epoch + 1) % HALO_S].p : nullptr;
 }
 
 // packed: the producer of v has already written the send buffer (fused ILU(0) apply); push: inside the Krylov loop, use the
@@ -521,8 +521,8 @@ extern "C" int32_t jh_halo_ipc_export(jh_tpfa d, char *handle64) {
     JH_HIP(hipSetDevice(d->ctx->device));
     if (!H.landing) {
       H.landing_stride = std::max<int64_t>(1, H.n_recv * d->N);
-      JH_HIP(hipExtMallocWithFlags((void **)&H.landing, sizeof(double) * 2 * H.landing_stride, hipDeviceMallocUncached));
-      JH_HIP(hipMemset(H.landing, 0, sizeof(double) * 2 * H.landing_stride));
+      JH_HIP(hipExtMallocWithFlags((void **)&H.landing, sizeof(double) * HALO_S * H.landing_stride, hipDeviceMallocUncached));
+      JH_HIP(hipMemset(H.landing, 0, sizeof(double) * HALO_S * H.landing_stride));
     }
     hipIpcMemHandle_t h;
     JH_HIP(hipIpcGetMemHandle(&h, H.landing));
@@ -551,7 +551,7 @@ extern "C" int32_t jh_halo_ipc_attach(jh_tpfa d, const char *nbr_handles, const 
       if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return; }
       H.peer_landing[i] = (double *)ptr;
     }
-    for (int par = 0; par < 2; ++par) {
+    for (int par = 0; par < HALO_S; ++par) {
       std::vector<double *> dst((size_t)H.n_send);
       for (int i = 0; i < nn; ++i) {
         const int64_t stride = std::max<int64_t>(1, nbr_stride[i] * d->N);

@@ -34,7 +34,7 @@ void mailbox_allreduce_launch(hipStream_t s, const MailArgs &A, double *p, int n
 // ILU(0) apply, or this pack kernel) stores every boundary row straight into the landing buffers of the ranks that hold it
 // as a ghost (peer-mapped uncached memory, xGMI stores).  The finish kernel, next on the stream (so those stores are
 // released), raises this rank's flag in every neighbour's mailbox, waits for the neighbours' flags in its own, and copies
-// the landed values into the ghost rows.  Landing buffers alternate with the parity of the exchange counter.
+// the landed values into the ghost rows.  HALO_S landing buffers are used round robin by the exchange counter.
 __global__ void halo_push_pack_kernel(double *const *dst, const double *v, const int32_t *idx, int64_t n, int bs) {
   for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
     double *d = dst[k];
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void halo_push_finish_kernel(Mailbox *self, Ma
                                                                int rank, unsigned long long epoch, const double *landing, double *v,
                                                                const int32_t *recv_idx, int64_t n_recv, int bs, MailErr *err,
                                                                unsigned long long timeout_ticks) {
-  const int par = (int)(epoch & 1ull);
+  const int par = (int)(epoch % (unsigned long long)HALO_S);
   if (threadIdx.x < n_nbr) {
     const int q = nbr[threadIdx.x];
     if (blockIdx.x == 0)  // my rows for q are in place (previous kernel on this stream): tell q

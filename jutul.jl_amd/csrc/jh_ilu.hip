@@ -1712,7 +1712,7 @@ __global__ __launch_bounds__(64) void ilu_apply_jds_kernel(IluDev F, const doubl
           const size_t o = (size_t)dev * BS + e;
           double v;
           if (GM == 0) {
-            v = gr[g].a[e];
+            v = (dev < G.n_owned_rows) ? gr[g].a[e] : 0.0;  // (ghost input zeroed when the caller says where the ghosts start)
           } else if (GM == 1) {
             v = (dev < G.n_owned_rows) ? gr[g].a[e] - ca * gr[g].b[e] : 0.0;
             G.out[o] = v;
@@ -2957,6 +2957,22 @@ void ilu_apply(jh_ilu M, const double *b, double *x) {
 }
 bool ilu_can_fuse_gather(jh_ilu M) {
   return M && M->kind == 0 && M->lds_mode && M->threads == 64 && M->rowmap_local && M->ctx->opt.fuse_gather;
+}
+// x = M^-1 b with the ghost rows of b taken as zero (rows >= n_owned_rows; parray_preconditioner_apply!, linalg.jl:78-88) and the
+// rows neighbouring ranks hold as ghosts stored into the halo send buffer / landing buffers by the same launch -- the first
+// apply of a solve, which has no vector update to fuse.  Only on the chunk-jagged layout (ilu_can_pack_halo && M->jag).
+bool ilu_can_pack_halo(jh_ilu M);
+bool ilu_can_apply_pack(jh_ilu M) { return ilu_can_pack_halo(M) && M->jag && M->kind == 0; }
+void ilu_apply_pack(jh_ilu M, const double *b, double *x, int n_owned_rows) {
+  if (!M->factored) JH_THROW("ILU(0) applied before jh_ilu0_factor");
+  if (!ilu_can_apply_pack(M)) JH_THROW("packed apply needs the chunk-jagged layout and a matching halo plan");
+  IluDev F = dev_view(M);
+  F.send_ptr = M->d_send_ptr.p; F.send_local = M->d_send_local.p; F.send_slot = M->d_send_slot.p;
+  F.send_buf = M->A->disc->halo.d_send_buf.p;
+  F.send_dst = halo_push_targets(M->A->disc);
+  IluGather G;
+  G.n_owned_rows = n_owned_rows;
+  ilu_apply_jagged(M, F, b, x, G);
 }
 // x = M^-1 * (fused vector update), see IluGather / ilu_apply_chunked_kernel
 // true if ilu_apply_fused(..., pack = true) can fill the halo send buffer of the matrix' discretisation

@@ -227,13 +227,16 @@ constexpr int MAIL_R = 16, MAIL_V = 8;
 // iteration past convergence consume their epochs without executing (on every rank alike: the done flag derives from all-reduced
 // bits), which leaves gaps of a few epochs between consecutive executed ones -- eight sets keep any two live epochs apart.
 constexpr int MAIL_S = 8;
+// Landing buffers / flags of the push halo, round robin by exchange epoch: consecutive EXECUTED exchanges must not share a set (a
+// neighbour may still be copying out of the previous one), and the launches of a speculative Krylov iteration skip their epochs.
+constexpr int HALO_S = 4;
 struct Mailbox {
   double val[MAIL_S][MAIL_R][MAIL_V];
   unsigned long long flag[MAIL_S][MAIL_R];
   // consumer-side all-reduce of one or two sums (xr_* below): per source rank four self-validating 8-byte granules
   // {epoch tag : 32 | half of a double : 32} -- no flag, no second round trip: a reader that sees four matching tags has the data
   unsigned long long gran[MAIL_S][MAIL_R][4];
-  unsigned long long hflag[2][MAIL_R];  // push halo: epoch of the last exchange whose data rank r has delivered here
+  unsigned long long hflag[HALO_S][MAIL_R];  // push halo: epoch of the last exchange whose data rank r has delivered here
   unsigned long long abort;             // != 0 once a wait of THIS rank has timed out: its later waits give up at once
 };
 // What a timed-out wait leaves behind for the host (pinned, host-coherent memory): code 1 = scalar all-reduce, 2 = push halo;
@@ -393,11 +396,11 @@ struct jh_tpfa_s {
     bool direct_recv = false;          // each neighbour's ghosts are consecutive device rows: no unpack
     std::vector<int32_t> recv_row0;    // first device row of every neighbour's ghosts (direct_recv)
     // "push" exchange over peer-mapped memory (jh_halo_ipc_*): senders store their boundary rows straight into the
-    // receiver's landing buffer (uncached, 2 parities x n_recv x N doubles, receive-list order)
+    // receiver's landing buffer (uncached, HALO_S sets x n_recv x N doubles, receive-list order)
     double *landing = nullptr;                 // this rank's landing buffer
-    int64_t landing_stride = 0;                // doubles per parity
+    int64_t landing_stride = 0;                // doubles per set
     std::vector<double *> peer_landing;        // per neighbour: that rank's landing buffer, mapped here
-    jh::DevBuf<double *> d_push_dst[2];        // per send slot and parity: where the cell's N doubles go
+    jh::DevBuf<double *> d_push_dst[jh::HALO_S]; // per send slot and landing set: where the cell's N doubles go
     jh::DevBuf<int32_t> d_nbr;                 // neighbour ranks on the device
     uint64_t push_epoch = 0;
     bool push_attached = false, push_enabled = false;
@@ -461,8 +464,8 @@ void k_gather_blocks(hipStream_t s, double *dst, const double *src, const int32_
                      bool scatter);
 // dot products: result(s) land in ctx->scalars[slot..]; deterministic two-stage reduction
 void k_dot(jh_context ctx, const double *a, const double *b, int64_t n, int slot);
-void k_dot2(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, int slot);
-void k_dot2_to(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, double *out);
+void k_dot2(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, int slot, const MailArgs *mail = nullptr);
+void k_dot2_to(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, double *out, const MailArgs *mail = nullptr);
 void k_absmax_strided(jh_context ctx, const double *r, int64_t ncell, int bs, int slot);
 void k_absstats(jh_context ctx, const double *a, const double *b, int64_t ncell, int bs, int slot);  // 4 scalars per variable from `slot`
 double read_scalar(jh_context ctx, int slot);                  // sync + D2H
@@ -652,7 +655,7 @@ __device__ __forceinline__ void mailbox_allreduce_body(const MailArgs &A, double
 // exchanger: all NT threads of ONE workgroup
 template <int NT>
 __device__ __forceinline__ void halo_fold_exchange(const HaloFold &H) {
-  const int par = (int)(H.epoch & 1ull);
+  const int par = (int)(H.epoch % (unsigned long long)HALO_S);
   if ((int)threadIdx.x < H.n_nbr) {
     const int q = H.nbr[threadIdx.x];
     // my rows for q are in place (stored by the previous kernel on this stream): tell q, then wait for q's

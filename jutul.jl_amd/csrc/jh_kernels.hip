@@ -174,16 +174,17 @@ void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max
     hipLaunchKernelGGL(final_reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, nparts, count, ctx->scalars.p + slot, done, ma);
 }
 
-void k_dot2_to(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, double *out) {
+// mail: the sums are all-reduced over the ranks in the second stage's launch (mailboxes)
+void k_dot2_to(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, double *out, const MailArgs *mail) {
   ensure_partials(ctx, 0);
   int g = grid_for(n);
   if (g > RED_BLOCKS) g = RED_BLOCKS;
   hipLaunchKernelGGL(dot2_partial_kernel, dim3(g), dim3(256), 0, ctx->stream, a, b, c, d, n, ctx->partials.p, ctx->partial_stride);
   hipLaunchKernelGGL(final_reduce_kernel<false>, dim3(1), dim3(FIN_THREADS), 0, ctx->stream, ctx->partials.p, ctx->partial_stride, g,
-                     c ? 2 : 1, out, (const double *)nullptr, MailArgs());
+                     c ? 2 : 1, out, (const double *)nullptr, mail ? *mail : MailArgs());
 }
-void k_dot2(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, int slot) {
-  k_dot2_to(ctx, a, b, c, d, n, ctx->scalars.p + slot);
+void k_dot2(jh_context ctx, const double *a, const double *b, const double *c, const double *d, int64_t n, int slot, const MailArgs *mail) {
+  k_dot2_to(ctx, a, b, c, d, n, ctx->scalars.p + slot, mail);
 }
 void k_dot(jh_context ctx, const double *a, const double *b, int64_t n, int slot) { k_dot2(ctx, a, b, nullptr, nullptr, n, slot); }
 

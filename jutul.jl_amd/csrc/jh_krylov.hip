@@ -22,6 +22,8 @@ void ilu_apply_mul(jh_ilu M, const IluGather &G, const double *b, double *x, dou
 int ilu_eprod(jh_ilu M, const double *x, double *q, const SpmvDot *dot, const double *done);
 void ilu_eprod_refresh(jh_ilu M);
 bool ilu_can_pack_halo(jh_ilu M);
+bool ilu_can_apply_pack(jh_ilu M);
+void ilu_apply_pack(jh_ilu M, const double *b, double *x, int n_owned_rows);
 void halo_exchange_begin(jh_tpfa d, double *v, int bs, bool packed = false);
 void halo_exchange_end(jh_tpfa d);
 void ilu_factor(jh_ilu M);
@@ -333,6 +335,8 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     K->mark(1, st);
   };
   auto dot2 = [&](const double *a, const double *bb, const double *c2, const double *d2, int slot) {
+    MailArgs ma;
+    if (comm_mail_args(ctx, c2 ? 2 : 1, &ma)) { k_dot2(ctx, a, bb, c2, d2, nd, slot, &ma); return; }  // all-reduce in the reduction launch
     k_dot2(ctx, a, bb, c2, d2, nd, slot);
     comm_allreduce_dev(ctx, sc + slot, c2 ? 2 : 1, 0);
   };
@@ -410,13 +414,12 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   } else {
     k_fill(st, x, n, 0.0);
     k_copy(st, K->c.p, b_in, n);  // scratch copy of b (the ghost zeroing of the preconditioner must not touch b)
-    if (dist) halo_exchange(disc, K->c.p, P.bs);  // consistent!(b) (ext/.../krylov.jl:54)
+    if (dist) halo_exchange(disc, K->c.p, P.bs, false, true);  // consistent!(b) (ext/.../krylov.jl:54); a push exchange where enabled
     if (left) prec(K->c.p, K->r.p); else k_copy(st, K->r.p, K->c.p, n);  // r0 = M^-1 b
     k_copy(st, K->p.p, K->r.p, n);
-    k_copy(st, K->c.p, K->r.p, n);  // c = r0
+    if (left) k_copy(st, K->c.p, K->r.p, n);  // c = r0 (without left preconditioning c holds it already)
     // rho = <c,r>, ||r||^2 -> pair 0
-    k_dot2(ctx, K->c.p, K->r.p, K->r.p, K->r.p, nd, S_PAIR0);
-    comm_allreduce_dev(ctx, sc + S_PAIR0, 2, 0);
+    dot2(K->c.p, K->r.p, K->r.p, K->r.p, S_PAIR0);
   }
   double h2[2];
   read_scalars(ctx, S_PAIR0, 2, h2);
@@ -502,6 +505,12 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       apply_mul(IluGather(), K->p.p, K->y.p, K->q.p, d1);
       yy = K->y.p;
       v_done = true;
+    } else if (right && pack && ilu_can_apply_pack(M)) {  // first iteration: y = N^-1 p, ghost input zeroed, send rows leave with it
+      K->mark(1, st);
+      ilu_apply_pack(M, K->p.p, K->y.p, ghost_from);
+      K->mark(1, st);
+      yy = K->y.p;
+      y_packed = true;
     } else if (right) { prec(K->p.p, K->y.p); yy = K->y.p; }
     double *vv = K->q.p;
     if (v_done) {
@@ -607,7 +616,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   if (solved) status = (manual && rnorm > eps_auto) ? 3 : 0;
   else if (status == 0 && it >= itmax) status = 1;
   if (it & 1) k_copy(st, x, X[1], n);  // iterate of the last accepted iteration
-  if (dist) halo_exchange(disc, x, P.bs);  // consistent!(x) (ext/.../krylov.jl:75)
+  if (dist) halo_exchange(disc, x, P.bs, false, true);  // consistent!(x) (ext/.../krylov.jl:75)
   K->A->jval_fresh = false;  // the values may change before the next solve
   *iters_out = it;
   K->collect(it);
