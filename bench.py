@@ -89,6 +89,12 @@ def parse_args(argv=None):
     ap.add_argument("--compressibility", type=float, default=0.0,
                     help="--law compressible: fluid compressibility c in rho = rho0 exp(c (p - p_ref)) (0 = 1e-3); with dt = 5 a value of "
                          "0.2 gives the accumulation term the weight it has in the Poisson headline and a genuinely nonlinear residual")
+    ap.add_argument("--max-newton", type=int, default=15,
+                    help="--timesteps: max_nonlinear_iterations of a ministep (simulator.jl:555-617); a ministep that needs more is cut in half")
+    ap.add_argument("--source-period", type=int, default=0,
+                    help="--timesteps: the two point sources alternate between full and quarter rate every k time steps (a rate "
+                         "schedule): a transient that recurs inside the timed region instead of decaying in the warm-up")
+    ap.add_argument("--source", type=float, default=1.0, help="scale of the two point sources (injector / producer)")
     ap.add_argument("--newton-tol", type=float, default=1e-3, help="--timesteps: convergence tolerance on max|r_e| (models.jl:818-883)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="context option (jh_context_set_option, include/jutul_hip.h), repeatable: A/B runs")
@@ -295,12 +301,12 @@ def main():
     law.set_state(U_loc)
     law.set_state0(U_loc)
     if src_cells:
-        law.set_sources(src_cells, source_values(np, args.law, src_sign))
+        law.set_sources(src_cells, [args.source * v for v in source_values(np, args.law, src_sign)])
     law.set_update_limits(update_limits(np, args.law))
     prec = ja.ILUZeroPreconditioner(partition="blocks")
     ks = ja.GenericKrylov("bicgstab", preconditioner=prec, relative_tolerance=args.rtol, max_iterations=200 if N == 2 else 100,
                           precond_side=args.precond_side)
-    sim = ja.Simulator(law, ks, tolerance=args.newton_tol)
+    sim = ja.Simulator(law, ks, tolerance=args.newton_tol, max_nonlinear_iterations=args.max_newton, max_timestep_cuts=12)
     t0 = time.time()
     prec.update_preconditioner(sim.lsys.jac)  # symbolic phase (levels, maps); the first factorisation of zeros is harmless
     setup["ilu_symbolic_s"] = time.time() - t0
@@ -326,9 +332,18 @@ def main():
         law.update_state0()
         return rep
 
+    ministeps = []  # every ministep of the run (dt, success, iterations); reset before the timed region
+
+    tstep = [0]
+
     def step_timestep():
+        if args.source_period > 0 and src_cells:  # forces change between report steps (apply_forces!, outside the Newton loop)
+            sgn = 0.25 if (tstep[0] // args.source_period) % 2 else 1.0  # rate schedule: full / quarter rate
+            law.set_sources(src_cells, [sgn * args.source * v for v in source_values(np, args.law, src_sign)])
+        tstep[0] += 1
         sim.reports = []
         sim.solve_timestep(args.dt)   # state0 <- state on success (update_after_step!), ministep cuts on failure
+        ministeps.extend(sim.last_ministeps)
         return sim.reports
 
     seams = None
@@ -344,7 +359,7 @@ def main():
         st = m.adopt(disc, law, sim.lsys)
         krylov = dict(preconditioner=dict(handle=prec.h), storage=ks._workspace(sim.lsys.jac), solver="bicgstab")
         host_state0 = [np.ascontiguousarray(U_loc.reshape(-1, N)[:, e]) for e in range(N)]  # storage.state0[k]
-        src_v = np.asarray(source_values(np, args.law, src_sign), dtype=np.float64).reshape(-1, N)
+        src_v = args.source * np.asarray(source_values(np, args.law, src_sign), dtype=np.float64).reshape(-1, N)
         lim = update_limits(np, args.law)
         cfg = ks.config
         seams = dict(mirror=m, storage=st, n=0, outputs=0, t_out=0.0)
@@ -395,6 +410,7 @@ def main():
         seams["outputs"], seams["t_out"] = 0, 0.0
     ks.profile(enable=args.profile_stride or (8 if world == 1 else 32), reset=True)  # HIP-event pairs around every n-th iteration's SpMV / ILU launches
     barrier()
+    del ministeps[:]
     t0 = time.perf_counter()
     reps = [step() for _ in range(args.steps)]
     barrier()
@@ -412,7 +428,9 @@ def main():
         nonlinear = {"timesteps": args.steps, "newton_iterations": len(solved), "assemblies": len(allr),
                      "newton_iterations_per_timestep": round(len(solved) / max(1, args.steps), 3),
                      "linear_iterations_per_newton_iteration": round(float(np.mean([r.linear_iterations for r in solved])), 2) if solved else None,
-                     "ministeps": len(sim.last_ministeps) if args.steps == 1 else None,
+                     "ministeps": len(ministeps), "timestep_cuts": sum(1 for m in ministeps if not m["success"]),
+                     "max_newton_iterations_in_a_ministep": max((m["iterations"] for m in ministeps), default=0),
+                     "max_nonlinear_iterations": args.max_newton, "source_scale": args.source, "source_period": args.source_period,
                      "newton_tolerance": args.newton_tol,
                      "convergence_check_ms": round(float(np.mean([r.assembly_ms for r in checks])), 4) if checks else None,
                      "convergence_check_share_of_step": round(float(np.sum([r.assembly_ms for r in checks])) * 1e-3 / elapsed, 4) if checks else None,
@@ -479,6 +497,10 @@ def main():
     # ILU(0) refactor: every Jacobian value read once, every kept factor value + inverted pivot written once, + the 4-byte
     # maps (">= 2*8*nnz + pattern")
     B_fac = 8.0 * N * N * (nnz_loc + kept + n_loc) + 4.0 * (kept + n_loc)
+    # the same operators WITHOUT the BLAS-1 work fused into their launches (SURVEY 8d's operator-only formulas): frac_strict
+    B_spmv_strict = (8.0 * N * N + 4) * nnz_loc + (4 + 16.0 * N) * n_loc
+    B_ilu_strict = (8.0 * N * N + 4) * kept + (8.0 * N * N + 8 + 16 * N) * n_loc
+    strict = {"spmv": B_spmv_strict, "ilu0_apply": B_ilu_strict, "ilu0_apply+spmv": B_spmv_strict + B_ilu_strict}
     kern = {}
     kern["assembly"] = dict(ms=asm_ms, launches=len(reps), bytes=B_asm)
     kern["ilu0_factor"] = dict(ms=fac_ms, launches=len(reps), bytes=B_fac)
@@ -503,13 +525,18 @@ def main():
         k["gbs"] = k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
         k["total_ms"] = k["ms"] * k["launches"]
         k["frac_of_peak"] = k["gbs"] / HBM_PEAK_GBS
+    for n, k in kern.items():  # operator-only bytes (no fused vector passes) over the same launch time
+        k["frac_strict"] = (strict.get(n, k["bytes"]) / (k["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if k["ms"] > 0 else 0.0
     dom = max(kern, key=lambda n: kern[n]["total_ms"])
     traffic, traffic_note = measured_traffic(dom, args, nc_g, world)
     roofline = dict(bound="hbm", kernel=dom, achieved=round(kern[dom]["gbs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(kern[dom]["gbs"] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_note=traffic_note,
+                    frac=round(kern[dom]["gbs"] / HBM_PEAK_GBS, 4), frac_strict=round(kern[dom]["frac_strict"], 4),
+                    frac_note="frac: SURVEY 8d bytes of the operator + the BiCGStab vector passes fused into its launch; "
+                              "frac_strict: the operator's own bytes only, same launch time",
+                    traffic=traffic, traffic_note=traffic_note,
                     kernels={n: dict(avg_ms=round(k["ms"], 4), launches=k["launches"], timed_launches=k.get("timed", k["launches"]),
                                      algorithmic_bytes=int(k["bytes"]),
-                                     gbs=round(k["gbs"], 1), frac=round(k["frac_of_peak"], 4),
+                                     gbs=round(k["gbs"], 1), frac=round(k["frac_of_peak"], 4), frac_strict=round(k["frac_strict"], 4),
                                      share_of_step=round(k["total_ms"] / (elapsed * 1e3), 4), **({"parts": k["parts"]} if "parts" in k else {}))
                              for n, k in kern.items()})
 
@@ -790,7 +817,7 @@ def cpu_baseline(args, nc_gpu):
     p = LAW_PAR[args.law]
     itmax = 200 if N == 2 else 100
     lim = update_limits(np, args.law)
-    src = source_values(np, args.law, [1.0, -1.0])
+    src = [args.source * v for v in source_values(np, args.law, [1.0, -1.0])]
 
     def leg(order, seconds, kernels):
         m, _ = make_mesh(ja, args, args.cpu_cells, scramble=order != "natural")
@@ -878,6 +905,9 @@ def cpu_baseline(args, nc_gpu):
     c = leg("rcm", args.cpu_seconds * 0.3, False)
     scale = lambda x: round(x["rate"] * x["nc"] / nc_gpu, 5)
     return {"value": scale(b), "unit": "Newton iterations/s", "cores": threads, "kind": "port",
+            "definition": "v2 (BENCH_r04 on): value = the natural-numbering leg, per-kernel figures (kernels) on that numbering too; "
+                          "v1 (BENCH_r01-r03): value = the scrambled-numbering leg, now value_scrambled_numbering -- speed-ups "
+                          "against `value` are not comparable across that change",
             "cores_note": f"{threads} OpenMP threads = min(logical CPUs {os.cpu_count()}, affinity, cgroup CPU quota)",
             "numbering": "natural (the mesh generator's own cell numbering)",
             "linear_iterations_per_step": round(float(np.mean(b["its"])), 2), "linear_iterations_first_steps": (b["wits"] + b["its"])[:8],

@@ -211,7 +211,9 @@ int32_t jh_law_get_variable(jh_law L, int32_t which, int32_t e, double *out);
 /* hipHostRegister / hipHostUnregister of a host array the caller keeps alive (Jutul's state0[k] arrays live as long as the
  * simulator storage): page-locks it so that uploads / downloads are direct DMA transfers.  Every other caller-owned array that
  * crosses this interface is ordinary (pageable) memory: the library copies it through its own page-locked bounce buffer and the
- * call returns when the copy is complete -- the caller may free or reuse the array at once. */
+ * call returns when the copy is complete -- the caller may free or reuse the array at once.
+ * A range that is page-locked already (by another component) is success and stays that component's: jh_host_unregister only
+ * releases what jh_host_register itself pinned, and is a no-op for anything else. */
 int32_t jh_host_register(void *ptr, int64_t bytes);
 int32_t jh_host_unregister(void *ptr);
 int32_t jh_law_update_state0(jh_law L);                /* state0 <- state (update_after_step!, models.jl:983-1011) */

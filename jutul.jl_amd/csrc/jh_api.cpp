@@ -6,6 +6,9 @@
 #include <vector>
 #include <unordered_map>
 
+#include <map>
+#include <mutex>
+
 #include "jh_internal.hpp"
 
 namespace jh {
@@ -132,6 +135,10 @@ inline void check(int32_t rc) {  // nested C-ABI call failed: the message is alr
 // ---- options ----------------------------------------------------------------------------------------------------
 namespace jh {
 bool Options::set(const char *key, int64_t v) {
+  // launch geometries that go into kernels unchanged: only the shapes the kernels are written for (a factor workgroup of fewer
+  // than 64 threads has no wavefront to walk its rows; a partial wavefront would share rows with another one)
+  if (std::strcmp(key, "ilu_factor_threads") == 0 && v != 0 && v != 64 && v != 128 && v != 256 && v != 512)
+    JH_THROW("option ilu_factor_threads: 0 (default), 64, 128, 256 or 512");
 #define JH_OPT_SET(name, def) if (std::strcmp(key, #name) == 0) { name = v; return true; }
   JH_OPTION_LIST(JH_OPT_SET)
 #undef JH_OPT_SET
@@ -621,17 +628,31 @@ extern "C" int32_t jh_law_get_variable(jh_law L, int32_t which, int32_t e, doubl
     JH_HIP(hipStreamSynchronize(ctx->stream));
   });
 }
+// The ranges THIS library page-locked.  A range somebody else registered (hipErrorHostMemoryAlreadyRegistered: fully or partly
+// page-locked already, which is what the caller asked for) is not ours to release: jh_host_unregister leaves it alone.
+namespace {
+std::mutex g_reg_mutex;
+std::map<void *, size_t> g_registered;
+}  // namespace
 extern "C" int32_t jh_host_register(void *ptr, int64_t bytes) {
   return guard([&] {
     if (!ptr || bytes <= 0) JH_THROW("bad host range");
     const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
-    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return; }  // page-locked already: what was asked for
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return; }
     JH_HIP(e);
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    g_registered[ptr] = (size_t)bytes;
   });
 }
 extern "C" int32_t jh_host_unregister(void *ptr) {
   return guard([&] {
     if (!ptr) JH_THROW("null argument");
+    {
+      std::lock_guard<std::mutex> lk(g_reg_mutex);
+      auto it = g_registered.find(ptr);
+      if (it == g_registered.end()) return;  // not pinned by jh_host_register: another component's registration stays
+      g_registered.erase(it);
+    }
     JH_HIP(hipHostUnregister(ptr));
   });
 }

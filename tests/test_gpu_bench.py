@@ -32,6 +32,7 @@ def check(d, steps, warmup):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert set(r["kernels"]) in ({"assembly", "spmv", "ilu0_apply", "ilu0_factor"}, {"assembly", "ilu0_apply+spmv", "ilu0_factor"})
     assert "traffic" in r and "traffic_note" in r
+    assert 0 < r["frac_strict"] <= r["frac"] + 1e-9 and all("frac_strict" in k for k in r["kernels"].values())
 
 
 def test_bench_single_process_with_cpu_baseline():
@@ -163,3 +164,18 @@ def test_bench_selftest_only_two_processes():
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
     assert d["ok"] and d["selftest"]["paths"]["krylov_halo"] == "host-callback"
+
+
+def test_bench_nonlinear_timesteps_line():
+    """bench.py --law compressible --timesteps (the nonlinear line of configs[4]): a step is a time step through
+    Simulator.solve_timestep; value counts the Newton iterations that solved a linear system, config.nonlinear reports the loop."""
+    d = run([sys.executable, "bench.py", "--cells", "200000", "--steps", "4", "--warmup", "1", "--no-cpu", "--law", "compressible",
+             "--compressibility", "4", "--newton-tol", "1e-8", "--rtol", "1e-6", "--max-newton", "6", "--timesteps"])
+    check(d, 4, 1)
+    n = d["config"]["nonlinear"]
+    assert n["timesteps"] == 4 and n["ministeps"] >= 4 and n["timestep_cuts"] == n["ministeps"] - 4
+    assert n["newton_iterations"] >= 2 * 4  # genuinely nonlinear: more than one Newton update per time step
+    assert n["assemblies"] == n["newton_iterations"] + n["ministeps"]  # every ministep ends with an assembly + convergence test
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 4 - n["newton_iterations"]) < 1e-2 * n["newton_iterations"]
+    assert "workload" in d["config"] and "full Newton loop" in d["config"]["workload"]
+    assert d["roofline"]["frac_strict"] <= d["roofline"]["frac"] + 1e-9
