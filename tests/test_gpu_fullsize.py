@@ -312,6 +312,61 @@ def test_1M_cells_nonlinear_timesteps_match_the_oracle_newton_sequence(ja, oracl
     assert max(gpu_its) >= 3        # genuinely nonlinear: more than one Newton update per time step
 
 
+def test_1M_cells_two_phase_newton_sequence_matches_the_oracle(ja, oracle):
+    """configs[3]'s law (immiscible two-phase, 2x2 blocks, SPU upwinding) at 1M cells as a Newton SEQUENCE against the oracle (the
+    scalar twin is the test above): two implicit time steps through Simulator.solve_timestep with Jutul's saturation update
+    limits (absolute increment 0.2, bounds [0, 1]: choose_increment, variables/utils.jl:110-174) against the oracle's loop --
+    assemble -> converged? -> block-ILU(0) refactor + BiCGStab -> limited update -- with the same control flow: equal Newton
+    iteration counts per time step, states to 1e-6 of each variable's scale.  Linear solves at rtol 1e-8 on both sides."""
+    from bench import LAW_PAR, apply_update, dims_for_cells, initial_state, source_values, update_limits
+    from jutul_amd import dd
+    ctx = ja.HIPContext(0)
+    g = ja.tet_lattice_mesh(*dims_for_cells(1_000_000))
+    nc = g["nc"]
+    T = g["T"] / g["T"].mean()
+    vol = g["volumes"]
+    par = LAW_PAR["twophase"]
+    X0 = initial_state(np, "twophase", nc)
+    src_c, src_v = [1, nc], np.asarray(source_values(np, "twophase", [1.0, -1.0]))
+    lim = update_limits(np, "twophase")
+    dt, tol, nsteps = 0.5, 1e-7, 2   # (the oracle's 2x2 solves at rtol 1e-8 are the slow part: ~70 s per time step)
+    disc = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], nc, block_n=2, reorder="blocks")
+    law = ja.ConservationLaw(disc, "twophase", **par)
+    law.set_face_trans(T); law.set_volumes(vol); law.set_state(X0); law.set_state0(X0); law.set_sources(src_c, src_v)
+    law.set_update_limits(lim)
+    ks = ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"), relative_tolerance=1e-8,
+                          max_iterations=400)
+    sim = ja.Simulator(law, ks, tolerance=tol)
+    gpu_its, gpu_states = [], []
+    for _ in range(nsteps):
+        gpu_its.append(sim.solve_timestep(dt))
+        assert len(sim.last_ministeps) == 1 and sim.last_ministeps[0]["success"]
+        gpu_states.append(law.get_state())
+    osys = oracle.TPFASystem(g["N"], nc, nblk=2)
+    olaw = oracle.Law("twophase", dt, rho0=par["rho0"], comp=par["compressibility"], mu=par["viscosity"], p_ref=par["p_ref"])
+    part = dd.partition_rcb(g["cell_centroids"], 8)
+    X = X0.copy()
+    Fo = None
+    for step in range(nsteps):
+        Xp = X.copy()
+        for it in range(1, 17):
+            nz, r = osys.assemble(olaw, X, Xp, vol, T, src_cells=src_c, src_values=src_v)
+            if it > 1 and np.abs(r).max() < tol:
+                break
+            if Fo is None:
+                Fo = oracle.ILU0(nc, 2, osys.rowptr, osys.colidx, nz, partition=part)
+            else:
+                Fo.refactor(nz)
+            x, st = oracle.bicgstab(nc, 2, osys.rowptr, osys.colidx, nz, r, prec=Fo, side="right", rtol=1e-8, atol=1e-30, itmax=400)
+            assert st["solved"]
+            X = apply_update(np, X, -x, lim)
+        assert it == gpu_its[step], (step, it, gpu_its)
+        G, O = gpu_states[step].reshape(-1, 2), X.reshape(-1, 2)
+        for e in range(2):
+            assert np.abs(G[:, e] - O[:, e]).max() <= 1e-6 * np.abs(O[:, e]).max(), (step, e)
+    assert max(gpu_its) >= 2
+
+
 def test_3M_cells_oracle_parity_where_the_defaults_switch(ja, oracle):
     """Oracle parity at a size where the library's defaults change code path: >= 3M rows -> 16-bit column codes in the jagged
     SpMV (no environment override), >= 2M cells -> 512-row bisection blocks, ~100 tiles per XCD chunk.  Assembly, jh_spmv,
