@@ -740,37 +740,53 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def traffic_tag(args, cells):
+    """name of the workload in profiles/r*_traffic_<tag>_1gpu.json (the default workload keeps its historic name)"""
+    if args.law == "poisson" and args.mesh == "lattice" and cells == 10_025_988:
+        return "10M"
+    return f"{args.law}_{args.mesh}_{cells}"
+
+
 def measured_traffic(kernel, args, cells, world):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate passes on
-    this same command, FETCH doubled per the gfx950 correction; tools/collect_profiles.sh + tools/pmc_summary.py ->
-    profiles/<tag>_traffic_*.json).  PMC counters cannot be read from inside the benchmark, so this is the committed
-    measurement -- quoted only if it was taken on exactly this kernel source (hash recorded next to it) and workload; otherwise
-    null with the reason."""
+    this same command, FETCH doubled per the gfx950 correction; tools/pmc_passes.sh + tools/pmc_table.py ->
+    profiles/<round>_traffic_<workload>_1gpu.json).  PMC counters cannot be read from inside the benchmark, so this is the
+    committed measurement -- quoted only if it was taken on exactly this kernel source (hash recorded next to it) and workload;
+    otherwise null with the reason."""
     import glob
-    # kernel name prefixes (the trailing template arguments -- wavefronts per workgroup, layout flags -- vary with the options)
-    names = {"ilu0_apply": ["ilu_apply_jds_kernel<1, 1,", "ilu_apply_jds_kernel<1, 2,"],
-             "spmv": ["spmv_jds16_kernel<5, 1,", "spmv_jds16_kernel<5, 2,"], "assembly": ["assemble_pipe_kernel<0"],
-             "ilu0_factor": ["ilu_factor_diag_kernel<1, 4,"]}
-    if world != 1 or args.law != "poisson" or cells != 10_025_988:
-        return None, "PMC passes are committed for the default 1-GPU 10M-cell poisson workload only"
+    N = 2 if args.law == "twophase" else 1
+    # kernel name prefixes (the trailing template arguments -- wavefronts per workgroup, layout flags -- vary with the options);
+    # per logical kernel the variants that alternate 1:1 inside a solve, first family found in the file wins
+    names = {"ilu0_apply": [[f"ilu_apply_jds_kernel<{N}, 1,", f"ilu_apply_jds_kernel<{N}, 2,"]],
+             "spmv": [["spmv_jds16_kernel<5, 1,", "spmv_jds16_kernel<5, 2,"], ["spmv_jds_kernel<5, 1,", "spmv_jds_kernel<5, 2,"],
+                      ["spmv_jds16_kernel<8, 1,", "spmv_jds16_kernel<8, 2,"], ["spmv_jds_kernel<8, 1,", "spmv_jds_kernel<8, 2,"],
+                      [f"spmv_tile_kernel<{N}, 1,", f"spmv_tile_kernel<{N}, 2,"]],
+             "assembly": [["assemble_pipe_kernel<"], [f"assemble_tile_kernel<{N}"]],
+             "ilu0_factor": [[f"ilu_factor_diag_kernel<{N},"], [f"ilu_factor_wave_kernel<{N},"], ["ilu_factor_prog_kernel<"], ["ilu_factor_rows_kernel<"]]}
+    if world != 1 or kernel not in names:
+        return None, "PMC passes are committed for 1-GPU workloads only"
+    tag = traffic_tag(args, cells)
     want = kernel_source_hash()
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_10M_1gpu.json")), reverse=True)
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{tag}_1gpu.json")), reverse=True)
+    if not cands:
+        return None, f"no PMC pass is committed for this workload (profiles/r*_traffic_{tag}_1gpu.json; tools/pmc_passes.sh)"
     for path in cands:
         try:
             with open(path) as f:
                 d = json.load(f)
             if d.get("_meta", {}).get("kernel_source_hash") != want:
                 continue
-            vals = []  # the fused variants alternate 1:1
-            for pre in names[kernel]:
-                hit = [v["hbm_bytes_per_launch"] for k, v in d.items() if k.startswith(pre) and "hbm_bytes_per_launch" in v]
-                if len(hit) == 1:
-                    vals.append(hit[0])
-            if vals:
-                return int(sum(vals) / len(vals)), f"{os.path.basename(path)} (same kernel sources, hash {want})"
+            for family in names[kernel]:
+                vals = []
+                for pre in family:
+                    hit = [v["hbm_bytes_per_launch"] for k, v in d.items() if k.startswith(pre) and "hbm_bytes_per_launch" in v]
+                    if len(hit) == 1:
+                        vals.append(hit[0])
+                if vals:
+                    return int(sum(vals) / len(vals)), f"{os.path.basename(path)} (same kernel sources, hash {want})"
         except Exception:  # noqa: BLE001
             continue
-    return None, f"no committed PMC pass matches the current kernel sources (hash {want}): re-run tools/collect_profiles.sh"
+    return None, f"no committed PMC pass of this workload matches the current kernel sources (hash {want}): re-run tools/pmc_passes.sh"
 
 
 def usable_cores():
