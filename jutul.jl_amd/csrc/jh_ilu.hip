@@ -1327,6 +1327,19 @@ __device__ __forceinline__ bool apply_prologue(const IluGather &G, PendRegs<GM> 
       double a = R.v[k][0];
 #pragma unroll
       for (int j = 1; j < PEND_MAX / 64; ++j) a += R.v[k][j];
+      // (more than PEND_MAX partials -- the CSR tile product of a large block matrix: the later batches in sequence, same order as
+      // pend_sum_wave)
+      for (int base = PEND_MAX; base < G.pend.nparts; base += PEND_MAX) {
+        const int lane = threadIdx.x & 63;
+        double w[PEND_MAX / 64];
+#pragma unroll
+        for (int j = 0; j < PEND_MAX / 64; ++j) {
+          const int i = base + lane + 64 * j;
+          w[j] = (i < G.pend.nparts) ? G.pend.part[(size_t)k * G.pend.stride + i] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < PEND_MAX / 64; ++j) a += w[j];
+      }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
       p[k] = a;

@@ -528,7 +528,8 @@ namespace jh {
 // BiCGStab iteration: 16 % of an iteration at 1.25M cells per GPU).  No atomics, no flags, no spinning: the kernel boundary that
 // is there anyway orders partials and consumer.  Workgroup 0 of the consumer also stores the sums to sc[out_slot (, +1)] for the
 // kernels behind it.  Producers that feed a PendSum run with at most PEND_MAX workgroups (8 loads per lane and sum).
-constexpr int PEND_MAX = 512;
+constexpr int PEND_MAX = 512;     // partials a wavefront sums per batch (8 loads per lane and sum, all in flight together)
+constexpr int PEND_LIMIT = 2048;  // most partials a consumer sums itself (the CSR tile product leaves up to 256 per XCD): batches in sequence
 struct PendSum {
   const double *part = nullptr;  // nullptr: nothing pending, the scalars are in sc[]
   unsigned stride = 0;           // second sum at part + stride
@@ -577,16 +578,19 @@ __device__ __forceinline__ void publish_record(double *sc, int pair_slot, double
 // PendSum: called by all 64 lanes of a wavefront; every lane returns the same sums (s1 only when count == 2)
 __device__ __forceinline__ void pend_sum_wave(const PendSum &P, double &s0, double &s1) {
   const int lane = threadIdx.x & 63;
-  double v0[PEND_MAX / 64], v1[PEND_MAX / 64];
+  double a0 = 0.0, a1 = 0.0;
+  for (int base = 0; base < P.nparts; base += PEND_MAX) {  // (one batch unless the producer was the CSR tile product of a large matrix)
+    double v0[PEND_MAX / 64], v1[PEND_MAX / 64];
 #pragma unroll
-  for (int j = 0; j < PEND_MAX / 64; ++j) {  // all loads first
-    const int i = lane + 64 * j;
-    v0[j] = (i < P.nparts) ? P.part[i] : 0.0;
-    v1[j] = (P.count == 2 && i < P.nparts) ? P.part[P.stride + i] : 0.0;
+    for (int j = 0; j < PEND_MAX / 64; ++j) {  // all loads first
+      const int i = base + lane + 64 * j;
+      v0[j] = (i < P.nparts) ? P.part[i] : 0.0;
+      v1[j] = (P.count == 2 && i < P.nparts) ? P.part[P.stride + i] : 0.0;
+    }
+    if (base == 0) { a0 = v0[0]; a1 = v1[0]; } else { a0 += v0[0]; a1 += v1[0]; }
+#pragma unroll
+    for (int j = 1; j < PEND_MAX / 64; ++j) { a0 += v0[j]; a1 += v1[j]; }
   }
-  double a0 = v0[0], a1 = v1[0];
-#pragma unroll
-  for (int j = 1; j < PEND_MAX / 64; ++j) { a0 += v0[j]; a1 += v1[j]; }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {  // a + b == b + a: both partners of an exchange end with the same bits
     a0 += __shfl_xor(a0, off, 64);

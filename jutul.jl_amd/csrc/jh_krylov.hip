@@ -369,11 +369,13 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   // Several ranks: the same, with the sums over the ranks finished by the consumers too (PendSum::mail) -- where every rank has
   // compute units of its own (comm_xrank_consumer); otherwise the dots go through the reduction launch that carries the all-reduce.
   const bool xrank = comm_xrank_consumer(ctx) && !(dist && want_overlap);
-  const bool pend_ok = ctx->opt.consumer_reduce && !fmul && jagged && right && ilu_can_fuse_gather(M) && (comm_size(ctx) == 1 || xrank);
+  // (the CSR tile product -- block matrices, rows of more than 8 entries -- feeds the consumers as well: up to PEND_LIMIT partials)
+  const bool pend_ok = ctx->opt.consumer_reduce && !fmul && right && ilu_can_fuse_gather(M) && (comm_size(ctx) == 1 || xrank) &&
+                       !(dist && want_overlap);
   auto pend_mail = [&](PendSum &ps) { if (xrank && !comm_mail_args(ctx, 2, &ps.mail)) JH_THROW("consumer-side all-reduce without mailboxes"); };
   // ... and the push halo's signal / wait / copy runs inside the product kernel that reads the vector (HaloFold) instead of a
   // finish launch: five launches per iteration as on one rank
-  const bool halo_fold = pend_ok && xrank && dist && disc->halo.push_enabled && ilu_can_pack_halo(M) && P.bs == 1;
+  const bool halo_fold = pend_ok && jagged && xrank && dist && disc->halo.push_enabled && ilu_can_pack_halo(M) && P.bs == 1;
   PendSum pend_spmv;  // partials of the last product with a fused dot
   // 16 wavefronts per workgroup: <= 512 partials for the consumers above, and the faster product at every size measured (10M rows
   // 0.160 vs 0.174-0.182 ms with 4, one workgroup per CU; 1.25M rows 26.1 vs 27.4 us) -- also where the dots still go through the
@@ -390,7 +392,7 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
       const int nparts = k_spmv_sell(K->A, in, out, 1.0, 0.0, dot, done, false, spmv_waves, fold ? &hf : nullptr);
       K->mark(0, st);
       if (dot && dot->mode) {
-        if (pend_ok && nparts <= PEND_MAX) {
+        if (pend_ok && nparts <= PEND_LIMIT) {
           pend_spmv.part = ctx->partials.p; pend_spmv.stride = (unsigned)ctx->partial_stride; pend_spmv.nparts = nparts;
           pend_spmv.count = dot->mode == 2 ? 2 : 1; pend_spmv.out_slot = dot->slot;
           pend_mail(pend_spmv);
@@ -398,6 +400,20 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
           pend_spmv = PendSum();
           spmv_dot_reduce(ctx, dot, nparts, done);
         }
+      }
+      return;
+    }
+    if (pend_ok && dot && dot->mode) {  // the second stage of the fused dot is left to the consuming kernel here, too
+      SpmvRange all{0, P.ntiles, 0, false};
+      const int nparts = k_spmv(ctx, P, K->A->val.p, in, out, 1.0, 0.0, dot, done, &all);
+      K->mark(0, st);
+      if (nparts <= PEND_LIMIT) {
+        pend_spmv.part = ctx->partials.p; pend_spmv.stride = (unsigned)ctx->partial_stride; pend_spmv.nparts = nparts;
+        pend_spmv.count = dot->mode == 2 ? 2 : 1; pend_spmv.out_slot = dot->slot;
+        pend_mail(pend_spmv);
+      } else {
+        pend_spmv = PendSum();
+        spmv_dot_reduce(ctx, dot, nparts, done);
       }
       return;
     }

@@ -22,11 +22,11 @@ def run_world(world, kind, port, extra=None):
     assert r.returncode == 0 and f"XRANK_OK {world} {kind}" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("world,kind", [(2, "poisson"), (4, "poisson")])
+@pytest.mark.parametrize("world,kind", [(2, "poisson"), (4, "poisson"), (2, "twophase")])
 def test_cu_masked_ranks_consumer_side_allreduce(world, kind):
     """2 and 4 CU-masked ranks: residual histories bit-identical on all ranks and run to run, equal to the reduction-launch path
     to rounding, Newton update equal to the single-process one."""
-    run_world(world, kind, 29680 + world)
+    run_world(world, kind, 29680 + world + (10 if kind == "twophase" else 0))
 
 
 def test_cu_masked_ranks_larger_subdomains():
