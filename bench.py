@@ -62,6 +62,10 @@ def parse_args(argv=None):
     ap.add_argument("--grading", type=float, default=2.0, help="--mesh delaunay / polyhedral: point density grading (1 = uniform)")
     ap.add_argument("--block-rows", type=int, default=0,
                     help="rows per block-Jacobi ILU(0) block; 0 = the library default for the rank-local size (512, 256 below 2M cells)")
+    ap.add_argument("--block-weights", default="trans", choices=["none", "trans"],
+                    help="trans (default): the device blocks (= block-Jacobi ILU(0) partition) are cut on the graph weighted by the face "
+                         "transmissibilities (jh_tpfa_create_weighted) -- the reference's Metis partition of the |A|-weighted graph "
+                         "(precond/ilu.jl:37-60, partitioning.jl:29-51,64-78); none: unweighted bisection")
     ap.add_argument("--rtol", type=float, default=1e-3)
     ap.add_argument("--dt", type=float, default=0.0, help="0 = 5.0 (0.5 for --law twophase)")
     ap.add_argument("--cpu-cells", type=int, default=1_000_000)
@@ -232,7 +236,8 @@ def main():
     host_halo = False
     t0 = time.time()
     if world == 1 and not force_dist:
-        disc = ja.TwoPointPotentialFlowHardCoded(ctx, mesh["N"], nc_g, block_n=N, reorder="blocks", block_rows=args.block_rows)
+        disc = ja.TwoPointPotentialFlowHardCoded(ctx, mesh["N"], nc_g, block_n=N, reorder="blocks", block_rows=args.block_rows,
+                                                 face_weights=T if args.block_weights == "trans" else None)
         T_loc, vol_loc, U_loc = T, vol, U0
         src_cells = [1, nc_g]
         src_sign = [1.0, -1.0]
@@ -279,7 +284,7 @@ def main():
         cells = sub["cells"] - 1
         n_owned = sub["n_owned"]
         disc = ja.TwoPointPotentialFlowHardCoded(ctx, sub["N"], sub["n_local"], block_n=N, reorder="blocks", block_rows=args.block_rows,
-                                                 n_owned=n_owned)
+                                                 n_owned=n_owned, face_weights=T[sub["faces"] - 1] if args.block_weights == "trans" else None)
         disc.set_halo(n_owned, sub["neighbors"], sub["send"], sub["recv"])
         if host_halo:
             ctx.comm_set_halo_callback(dd.packed_exchange(sub))
@@ -556,7 +561,7 @@ def main():
                                    f"assembly + block-Jacobi ILU(0) factor + BiCGStab(rtol={args.rtol})",
                        "cells": nc_g, "faces": nf_g, "mesh": args.mesh, "law": args.law, "law_parameters": {k: list(v) if isinstance(v, tuple) else v for k, v in LAW_PAR[args.law].items()},
                        "block_n": N, "dt": args.dt,
-                       "block_rows": args.block_rows or "library default", "ilu_max_block_rows": info["max_block_rows"],
+                       "block_rows": args.block_rows or "library default", "block_weights": args.block_weights, "ilu_max_block_rows": info["max_block_rows"],
                        "parallelism": f"dd{world}" if world > 1 else "single", "precond_side": ks.config.precond_side,
                        "path": args.path, "seams": seams_extra, "nonlinear": nonlinear, "options": {k: v for k, v in options.items() if k != "comm_timeout_ms"},
                        "launcher": os.environ.get("JH_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "direct"),

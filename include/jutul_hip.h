@@ -61,7 +61,8 @@ int32_t jh_synchronize(jh_context ctx); /* synchronize(ctx), context.jl:72 */
  *   ilu_factor_threads (0 = 512; rows-form programs 256), ilu_diag_factor (1), ilu_prog (1), ilu_factor_global (0),
  *   ilu_factor_wave_per_row (long rows; read when the preconditioner is created: 1 = rows-form programs (scalar matrices) | 2 = instruction-form
  *                            programs, wavefront per row | 0 = thread per row)
- *   asm_pipe (1), asm_pipe2_wgs (0), block_order (0 bisection | 1 onion)
+ *   asm_pipe (1), asm_pipe2_wgs (0), block_order (0 bisection | 1 onion), block_weights (1: use the face weights of
+ *   jh_tpfa_create_weighted | 0: ignore them)
  *   read_sync (0), setup_timing (0), jds_keep (0)
  *   xrank_consumer (-1 = when jh_comm_set_exclusive declared it | 0 | 1)  several ranks: the dot products of the Krylov loop are
  *                         summed over the ranks inside the consuming kernels and the push-halo hand-shake runs inside the product
@@ -98,6 +99,15 @@ int32_t jh_timer_stop_ms(jh_context ctx, double *ms);
  * utils.jl:178-184) the number of owned cells; ghosts stay the last device rows.  <= 0 or nc: no ghosts. */
 int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const int64_t *N, int32_t block_n, int32_t reorder,
                        const int64_t *partition, int64_t block_rows, int64_t n_owned, jh_tpfa *out);
+/* The same with |coupling| per face (nf doubles: the transmissibilities; NULL = unweighted): with JH_REORDER_BLOCKS and no
+ * partition given, the graph bisection that forms the device blocks -- the block-Jacobi ILU(0) partition -- minimises the cut
+ * WEIGHT, i.e. drops weak couplings first.  This is what the reference does: ILUZeroPreconditioner partitions the |A|-weighted
+ * graph of the matrix (precond/ilu.jl:37-60 -> generate_lookup -> generate_metis_graph, partitioning.jl:20-51,64-78).  Worth
+ * 10-25 % of the BiCGStab iterations on the bench grids (profiles/r05_*weights*).  The weights are only used here: transmissibilities
+ * for the assembly are handed over with jh_law_set_data. */
+int32_t jh_tpfa_create_weighted(jh_context ctx, int64_t nc, int64_t nf, const int64_t *N, const double *face_weights,
+                                int32_t block_n, int32_t reorder, const int64_t *partition, int64_t block_rows, int64_t n_owned,
+                                jh_tpfa *out);
 int32_t jh_tpfa_destroy(jh_tpfa d);
 int32_t jh_tpfa_sizes(jh_tpfa d, int64_t *nc, int64_t *nf, int64_t *nhf, int64_t *nnzb, int32_t *block_n);
 /* conn_pos / conn_data (flux.jl:161-190): face_pos[nc+1]; self/other/face/face_sign [nhf] */

@@ -194,7 +194,9 @@ class TwoPointPotentialFlowHardCoded(_Handle):
     N: 2 x nf neighborship (1-based)."""
     _destroy = "jh_tpfa_destroy"
 
-    def __init__(self, context, N, nc, block_n=1, reorder="none", partition=None, block_rows=0, n_owned=0):
+    def __init__(self, context, N, nc, block_n=1, reorder="none", partition=None, block_rows=0, n_owned=0, face_weights=None):
+        """face_weights: |coupling| per face (the transmissibilities) -- the device blocks (reorder="blocks" without a partition)
+        then cut weak couplings first, like the reference's Metis partition of the |A|-weighted graph (partitioning.jl:64-78)."""
         super().__init__()
         self.ctx = context
         N = np.asarray(N, dtype=np.int64)
@@ -202,8 +204,12 @@ class TwoPointPotentialFlowHardCoded(_Handle):
         self.nc, self.nf, self.block_n = int(nc), int(N.shape[1]), int(block_n)
         Nf = i64(np.asfortranarray(N).T.reshape(-1))  # column-major 2 x nf
         part = i64(partition) if partition is not None else None
-        check(_L().jh_tpfa_create(context.h, self.nc, self.nf, pi(Nf), int(block_n), REORDER[reorder], pi(part),
-                                  int(block_rows), int(n_owned), C.byref(self.h)))
+        fw = None
+        if face_weights is not None:
+            fw = f64(np.asarray(face_weights).reshape(-1))
+            assert fw.size == self.nf
+        check(_L().jh_tpfa_create_weighted(context.h, self.nc, self.nf, pi(Nf), pf(fw), int(block_n), REORDER[reorder], pi(part),
+                                           int(block_rows), int(n_owned), C.byref(self.h)))
         nnzb = C.c_int64()
         check(_L().jh_tpfa_sizes(self.h, None, None, None, C.byref(nnzb), None))
         self.nhf, self.nnzb = 2 * self.nf, nnzb.value

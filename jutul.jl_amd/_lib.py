@@ -39,6 +39,7 @@ SIGNATURES = {
     "jh_timer_start": [H],
     "jh_timer_stop_ms": [H, F64P],
     "jh_tpfa_create": [H, C.c_int64, C.c_int64, I64P, C.c_int32, C.c_int32, I64P, C.c_int64, C.c_int64, C.POINTER(H)],
+    "jh_tpfa_create_weighted": [H, C.c_int64, C.c_int64, I64P, F64P, C.c_int32, C.c_int32, I64P, C.c_int64, C.c_int64, C.POINTER(H)],
     "jh_tpfa_destroy": [H],
     "jh_tpfa_sizes": [H, I64P, I64P, I64P, I64P, I32P],
     "jh_tpfa_get_conn": [H, I64P, I64P, I64P, I64P, I64P],

@@ -205,6 +205,7 @@ struct Comm;  // RCCL state (jh_comm.cpp)
   X(asm_pipe, 1)              /* persistent pipelined assembly kernel (scalar laws) */                                         \
   X(asm_pipe2_wgs, 0)         /* 2x2-block laws: workgroups per XCD of the pipelined kernel, 0 = tile kernel */                \
   X(block_order, 0)           /* device blocks: 0 recursive bisection, 1 breadth-first "onion" (set before jh_tpfa_create) */  \
+  X(block_weights, 1)         /* device blocks: cut weak couplings first when jh_tpfa_create_weighted is given face weights (0: ignore them) */ \
   X(read_sync, 0)             /* device scalars through copy + stream synchronise instead of the pinned record */              \
   X(comm_timeout_ms, 600000)  /* limit of the mailbox / push-halo waits inside kernels, 0 = wait like a collective */          \
   X(setup_timing, 0)          /* print the set-up phases */                                                                    \

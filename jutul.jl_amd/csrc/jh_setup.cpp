@@ -177,7 +177,11 @@ struct PhaseTimer {
 // half-faces at 512 cells per block on the tet lattice = 24.0 instead of 26.6 BiCGStab iterations at 2M cells, and a
 // dependency depth of the radius, not the diameter.  Block ids follow the bisection tree (neighbouring blocks are close in
 // memory); inside a block the cells are ordered breadth-first from a centre.
-static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, std::vector<int32_t> &perm, std::vector<int32_t> &block_ptr, bool timing) {
+// fw: |coupling| per face (nf doubles, scaled so that their mean is 1) or nullptr -- the cuts then prefer weak couplings (the
+// reference partitions the |A|-weighted graph of the matrix for its block-Jacobi ILU(0), precond/ilu.jl:37-60 ->
+// generate_metis_graph, partitioning.jl:64-78)
+static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, std::vector<int32_t> &perm, std::vector<int32_t> &block_ptr, bool timing,
+                                const double *fw) {
   const int64_t nparts = std::max<int64_t>(1, (nc + block_rows / 2) / block_rows);
   const int64_t max_part = std::max<int64_t>(block_rows + block_rows / 8, (nc + nparts - 1) / nparts);
   std::vector<int32_t> label;
@@ -223,19 +227,24 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
     for (int64_t i = 0; i < nc; ++i) ptr2[i + 1] += ptr2[i];
     std::vector<int32_t> nbr2;
     resize_parallel(nbr2, (size_t)ptr2[nc]);
+    std::vector<double> w2;
+    if (fw) resize_parallel(w2, (size_t)ptr2[nc]);
     parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
       for (int64_t i = b; i < e; ++i) {
         const int32_t c = ord[i];
         int64_t w = ptr2[i];
         for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k)
-          if (A.nbr[k] < nc) nbr2[w++] = newid[A.nbr[k]];
+          if (A.nbr[k] < nc) {
+            if (fw) w2[w] = fw[std::abs(A.sface[k]) - 1];
+            nbr2[w++] = newid[A.nbr[k]];
+          }
       }
     });
     std::vector<int32_t> lab2, cells;
     resize_parallel(lab2, (size_t)nc);
     resize_parallel(cells, (size_t)nc);
     parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { std::iota(cells.begin() + b, cells.begin() + e, (int32_t)b); });
-    PGraph G{nc, ptr2.data(), nbr2.data(), nullptr};
+    PGraph G{nc, ptr2.data(), nbr2.data(), fw ? w2.data() : nullptr};
     pt.lap("  blocks: graph");
     partition_bisect(G, std::move(cells), nparts, 0.04, max_part, lab2, (int32_t)(first_piece - 1));
     pt.lap("  blocks: bisection");
@@ -260,13 +269,14 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
 }
 
 static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block_rows, std::vector<int32_t> &perm,
-                         std::vector<int32_t> &block_ptr, int64_t &interior_rows, int32_t &interior_blocks, bool onion, bool timing) {
+                         std::vector<int32_t> &block_ptr, int64_t &interior_rows, int32_t &interior_blocks, bool onion, bool timing,
+                         const double *fw) {
   // cells >= nc (ghosts of a rank-local subdomain) are never absorbed; they form the last block
   perm.clear();
   perm.reserve(nc_all);
   block_ptr.assign(1, 0);
   // onion (option block_order = 1): round 1's blocks grown along the rim of the assigned region; default: graph bisection (above)
-  if (!onion) blocks_by_bisection(A, nc, block_rows, perm, block_ptr, timing);
+  if (!onion) blocks_by_bisection(A, nc, block_rows, perm, block_ptr, timing, fw);
   std::vector<int32_t> blk(nc_all, -1);
   for (int64_t c = nc; c < nc_all; ++c) blk[c] = INT32_MAX;
   std::vector<int32_t> cand;  // frontier candidates for the next seed (FIFO)
@@ -421,6 +431,11 @@ using namespace jh;
 extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const int64_t *N, int32_t block_n,
                                   int32_t reorder, const int64_t *partition, int64_t block_rows, int64_t n_owned,
                                   jh_tpfa *out) {
+  return jh_tpfa_create_weighted(ctx, nc, nf, N, nullptr, block_n, reorder, partition, block_rows, n_owned, out);
+}
+extern "C" int32_t jh_tpfa_create_weighted(jh_context ctx, int64_t nc, int64_t nf, const int64_t *N, const double *face_weights,
+                                           int32_t block_n, int32_t reorder, const int64_t *partition, int64_t block_rows,
+                                           int64_t n_owned, jh_tpfa *out) {
   return guard([&] {
     if (!ctx || !out) JH_THROW("null argument");
     if (nc < 1 || nf < 0) JH_THROW("bad sizes");
@@ -463,8 +478,21 @@ extern "C" int32_t jh_tpfa_create(jh_context ctx, int64_t nc, int64_t nf, const 
         // 192 rows the factorisation program of a block exceeds 64 KB of LDS: 3.1 -> 4.5 ms)
         if (deg > 7.0) block_rows = std::max<int64_t>(64, (int64_t)(block_rows * 5.0 / deg) / 32 * 32);
       }
+      // |coupling| per face for the bisection, mean 1 (the refinement's give-up thresholds are absolute); non-finite -> 0
+      std::vector<double> fw;
+      if (face_weights && nf > 0 && ctx->opt.block_weights != 0) {
+        resize_parallel(fw, (size_t)nf);
+        double sum = 0.0;
+        for (int64_t f = 0; f < nf; ++f) { const double v = std::fabs(face_weights[f]); fw[f] = std::isfinite(v) ? v : 0.0; sum += fw[f]; }
+        if (sum > 0.0) {
+          const double sc = (double)nf / sum;
+          parallel_ranges(nf, 1 << 18, [&](int64_t b, int64_t e) { for (int64_t f = b; f < e; ++f) fw[f] *= sc; });
+        } else {
+          fw.clear();
+        }
+      }
       order_blocks(A, nc, n_owned, block_rows, pat->perm, pat->block_ptr, pat->interior_rows, pat->interior_blocks,
-                   ctx->opt.block_order == 1, ctx->opt.setup_timing != 0);
+                   ctx->opt.block_order == 1, ctx->opt.setup_timing != 0, fw.empty() ? nullptr : fw.data());
     } else if (reorder != JH_REORDER_NONE) {
       JH_THROW("unknown reorder mode");
     }

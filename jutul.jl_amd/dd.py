@@ -349,7 +349,7 @@ def setup_rank_problem(ctx, N, part, rank, T, vol, X0, kind="poisson", block_n=1
     sub = local_subdomain(N, part, rank + 1, ghost_order=ghost_order)
     cells = sub["cells"] - 1
     disc = TwoPointPotentialFlowHardCoded(ctx, sub["N"], sub["n_local"], block_n=block_n, reorder=reorder,
-                                          block_rows=block_rows, n_owned=sub["n_owned"])
+                                          block_rows=block_rows, n_owned=sub["n_owned"], face_weights=np.asarray(T)[sub["faces"] - 1])
     disc.set_halo(sub["n_owned"], sub["neighbors"], sub["send"], sub["recv"])
     law = ConservationLaw(disc, kind, **(law_params or {}))
     law.set_face_trans(np.asarray(T)[sub["faces"] - 1])

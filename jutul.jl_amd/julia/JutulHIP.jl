@@ -187,7 +187,9 @@ function setup_equation_storage(model::HIPModel,
     nc = Jutul.number_of_cells(model.domain)
     ne = Jutul.number_of_equations_per_entity(model, eq)
     disc = Ref{Handle}(C_NULL)
-    @jh :jh_tpfa_create (Handle, Int64, Int64, Ptr{Int64}, Int32, Int32, Ptr{Int64}, Int64, Int64, Ref{Handle}) ctx.handle nc size(N, 2) N Int32(ne) Int32(1) C_NULL ctx.block_rows ctx.n_owned disc
+    # the face transmissibilities double as the weights of the device-block partition: weak couplings are cut first, like the Metis
+    # partition of the |A|-weighted graph behind ILUZeroPreconditioner (precond/ilu.jl:37-60, partitioning.jl:64-78)
+    @jh :jh_tpfa_create_weighted (Handle, Int64, Int64, Ptr{Int64}, Ptr{Float64}, Int32, Int32, Ptr{Int64}, Int64, Int64, Ref{Handle}) ctx.handle nc size(N, 2) N Float64.(hip_face_trans(model, storage)) Int32(ne) Int32(1) C_NULL ctx.block_rows ctx.n_owned disc
     law = Ref{Handle}(C_NULL)
     src = hip_law_source(model, eq)
     par = hip_law_params(model, eq)

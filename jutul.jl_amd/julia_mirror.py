@@ -72,7 +72,8 @@ class JuliaMirror:
         with self._fn("setup_equation_storage"):
             N = np.asarray(N, dtype=np.int64)
             Nf = i64(np.asfortranarray(N).T.reshape(-1))
-            check(L.jh_tpfa_create(ctx.h, nc, N.shape[1], pi(Nf), ne, 1, None, int(block_rows), int(n_owned), C.byref(s.disc)))
+            check(L.jh_tpfa_create_weighted(ctx.h, nc, N.shape[1], pi(Nf), pf(f64(face_trans)), ne, 1, None, int(block_rows), int(n_owned),
+                                            C.byref(s.disc)))
             par = f64(params) if params is not None else None
             if law_source is None:
                 check(L.jh_law_create(s.disc, int(law_kind), pf(par), C.byref(s.law)))
