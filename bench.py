@@ -862,7 +862,10 @@ def cpu_baseline(args, nc_gpu):
         osys.rowptr, osys.colidx = o.touch_copy(osys.rowptr), o.touch_copy(osys.colidx)
         law = o.Law(args.law, args.dt, rho0=p["rho0"], comp=p["compressibility"], mu=p["viscosity"], p_ref=p["p_ref"])
         # Jutul's CSR path uses block-Jacobi ILU(0) with one block per thread (precond/ilu.jl:37-60)
-        part = dd.partition_rcb(m["cell_centroids"], threads) if threads > 1 else None
+        # ... from a graph partition of the |A|-weighted cell graph (Metis in the reference: generate_lookup -> generate_metis_graph,
+        # partitioning.jl:20-51,64-78; here jh_partition_graph with the transmissibilities as weights -- the GPU leg's blocks are cut
+        # on the same weighted graph)
+        part = dd.partition_graph(m["N"], nc, threads, face_weights=np.asarray(T)) if threads > 1 else None
         nz, r = osys.assemble(law, U, U0, vol, T, src_cells=[1, nc], src_values=src)
         F = o.ILU0(nc, N, osys.rowptr, osys.colidx, nz, partition=part)
         state = dict(U=U, U0=U0)
@@ -926,7 +929,9 @@ def cpu_baseline(args, nc_gpu):
     c = leg("rcm", args.cpu_seconds * 0.3, False)
     scale = lambda x: round(x["rate"] * x["nc"] / nc_gpu, 5)
     return {"value": scale(b), "unit": "Newton iterations/s", "cores": threads, "kind": "port",
-            "definition": "v2 (BENCH_r04 on): value = the natural-numbering leg, per-kernel figures (kernels) on that numbering too; "
+            "definition": "v3 (BENCH_r05 on): as v2, with the one-block-per-thread ILU(0) partition cut on the transmissibility-weighted graph "
+                          "(the reference's Metis partition; v2 used coordinate bisection); "
+                          "v2 (BENCH_r04): value = the natural-numbering leg, per-kernel figures (kernels) on that numbering too; "
                           "v1 (BENCH_r01-r03): value = the scrambled-numbering leg, now value_scrambled_numbering -- speed-ups "
                           "against `value` are not comparable across that change",
             "cores_note": f"{threads} OpenMP threads = min(logical CPUs {os.cpu_count()}, affinity, cgroup CPU quota)",

@@ -1,4 +1,5 @@
 // C-ABI glue: contexts, vectors, matrices, laws.  See include/jutul_hip.h for the reference seams.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -65,7 +66,13 @@ Bounce &bounce() {
   }
   return *lease.b;
 }
+// Option upload_bounce (process-wide: the copy helpers have no context): 0 hands the caller's pointer to hipMemcpyAsync +
+// hipStreamSynchronize directly -- the path on which round 3 saw "Memory access fault by GPU" once in ~10 runs of the GPU suite and
+// which no isolated reproducer (tools/micro/upload_lifetime.hip) could break since; kept switchable so that the second copy can
+// be measured off and the fault hunted with the real workload (tools/upload_soak.sh).
+std::atomic<int> g_upload_bounce{1};
 bool page_locked(const void *host) {
+  if (!g_upload_bounce.load(std::memory_order_relaxed)) return true;  // (treated like page-locked memory: copied directly)
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, host) != hipSuccess) {
     (void)hipGetLastError();  // "invalid value" for ordinary host memory: not an error of ours
@@ -135,6 +142,7 @@ inline void check(int32_t rc) {  // nested C-ABI call failed: the message is alr
 // ---- options ----------------------------------------------------------------------------------------------------
 namespace jh {
 bool Options::set(const char *key, int64_t v) {
+  if (std::strcmp(key, "upload_bounce") == 0) g_upload_bounce.store(v != 0, std::memory_order_relaxed);
   // launch geometries that go into kernels unchanged: only the shapes the kernels are written for (a factor workgroup of fewer
   // than 64 threads has no wavefront to walk its rows; a partial wavefront would share rows with another one)
   if (std::strcmp(key, "ilu_factor_threads") == 0 && v != 0 && v != 64 && v != 128 && v != 256 && v != 512)

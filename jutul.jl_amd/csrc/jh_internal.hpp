@@ -208,6 +208,7 @@ struct Comm;  // RCCL state (jh_comm.cpp)
   X(block_weights, 1)         /* device blocks: cut weak couplings first when jh_tpfa_create_weighted is given face weights (0: ignore them) */ \
   X(read_sync, 0)             /* device scalars through copy + stream synchronise instead of the pinned record */              \
   X(comm_timeout_ms, 600000)  /* limit of the mailbox / push-halo waits inside kernels, 0 = wait like a collective */          \
+  X(upload_bounce, 1)         /* PROCESS-WIDE: caller arrays cross PCIe through the library's page-locked bounce buffer; 0 = straight from the caller's (pageable) memory */ \
   X(setup_timing, 0)          /* print the set-up phases */                                                                    \
   X(xrank_consumer, -1)       /* several ranks: dots all-reduced inside the consuming kernels + push-halo hand-shake inside the product; -1 = when the host declared exclusive compute units (jh_comm_set_exclusive) */ \
   X(jds_keep, 0)              /* jh_spmv_jagged: do not refresh the jagged copy (timing probe) */
