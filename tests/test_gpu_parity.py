@@ -492,6 +492,58 @@ def test_device_blocks_come_from_graph_bisection(ja, ctx):
     assert perm2[sub["n_owned"]:].min() > sub["n_owned"] and perm2[: sub["n_owned"]].max() <= sub["n_owned"]
 
 
+def test_device_blocks_cut_weak_couplings_first(ja, oracle):
+    """jh_tpfa_create_weighted: with the face transmissibilities as edge weights the device blocks (= block-Jacobi ILU(0)
+    partition) are what the reference's Metis partition of the |A|-weighted graph is (precond/ilu.jl:37-60 -> generate_metis_graph,
+    partitioning.jl:64-78): a valid partition under the same size cap whose cut WEIGHT is well below the unweighted one's (the cut
+    face COUNT may rise); the host-facing tables do not change; option block_weights = 0 reproduces the unweighted blocks; and a
+    BiCGStab solve of the same system takes no more iterations with the weighted blocks."""
+    g = ja.tet_lattice_mesh(22, 20, 18)
+    nc, N = g["nc"], g["N"]
+    T = g["T"] / g["T"].mean()
+    assert T.max() / T.min() > 20          # the Kuhn tets' transmissibilities span two decades: there is something to choose
+    rows = 256
+
+    def blocks(ctx, **kw):
+        disc = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, reorder="blocks", block_rows=rows, **kw)
+        perm, bp = disc.ordering()
+        assert np.array_equal(np.sort(perm), np.arange(1, nc + 1))
+        sizes = np.diff(bp)
+        assert sizes.min() >= 1 and sizes.max() <= rows + rows // 8 and len(sizes) == (nc + rows // 2) // rows
+        blk = np.zeros(nc, dtype=np.int64)
+        blk[perm - 1] = np.repeat(np.arange(len(sizes)), sizes)
+        cut = blk[N[0] - 1] != blk[N[1] - 1]
+        return disc, perm, bp, cut.mean(), T[cut].sum() / T.sum()
+
+    ctx = ja.HIPContext(0)
+    du, pu, bu, cut_u, w_u = blocks(ctx)
+    dw, pw, bw, cut_w, w_w = blocks(ctx, face_weights=T)
+    assert w_w < 0.75 * w_u, (w_w, w_u)     # (lattice: 0.164 -> 0.099)
+    assert abs(w_u - cut_u) < 0.03           # unweighted: the cut takes faces as they come
+    for a, b in zip(du.pattern(), dw.pattern()):
+        assert np.array_equal(a, b)          # host numbering untouched
+    # weights in arbitrary units (SI transmissibilities ~1e-12) give the same blocks: they are scaled to mean 1 inside
+    _, ps, bs_, _, _ = blocks(ctx, face_weights=1e-12 * T)
+    assert np.array_equal(ps, pw) and np.array_equal(bs_, bw)
+    ctx0 = ja.HIPContext(0, block_weights=0)
+    _, p0, b0, _, _ = blocks(ctx0, face_weights=T)
+    assert np.array_equal(p0, pu) and np.array_equal(b0, bu)
+    # the same linear system, both partitions: the weighted blocks need no more iterations (lattice at this size: 16 vs 19)
+    its = []
+    for disc in (du, dw):
+        law = ja.ConservationLaw(disc, "poisson")
+        law.set_face_trans(T); law.set_volumes(g["volumes"])
+        U = 1.0 + 0.1 * np.sin(np.arange(nc) * 0.001)     # smooth state: a residual the preconditioner has to work for
+        law.set_state(U); law.set_state0(U); law.set_sources([1, nc], [1.0, -1.0])
+        lsys = ja.LinearizedSystem(disc)
+        law.update_equation_and_linearized_system(50.0, lsys.jac, lsys.r)
+        ks = ja.GenericKrylov("bicgstab", preconditioner=ja.ILUZeroPreconditioner(partition="blocks"), relative_tolerance=1e-8, max_iterations=300)
+        out = ja.linear_solve(lsys, ks)
+        assert out["ok"]
+        its.append(out["iterations"])
+    assert its[1] <= its[0], its
+
+
 @pytest.mark.parametrize("wave", [None, "0", "1", "2", "3"])
 @pytest.mark.parametrize("bs", [1, 2, 3])
 @pytest.mark.parametrize("grid", ["bipartite", "bipartite7", "triangles"])
