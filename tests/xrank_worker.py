@@ -95,7 +95,9 @@ assert all(a[1] == allh[0][1] for a in allh), "residual histories differ between
 m = min(len(h0), len(h1), 10)
 assert abs(len(h0) - len(h1)) <= max(1, len(h0) // 20), (len(h0), len(h1))
 assert np.allclose(h1[:m], h0[:m], rtol=1e-7), (h1[:m], h0[:m])
-assert np.abs(x1 - x0).max() <= 1e-7 * np.abs(x0).max()
+# (both solves stop at ||r|| <= 1e-9 ||r0||: the solutions agree to that times the conditioning -- a 2x2 system mixes pressure and
+# saturation scales)
+assert np.abs(x1 - x0).max() <= (1e-7 if nblk == 1 else 1e-5) * np.abs(x0).max()
 # the Newton update through the fused step (jh_newton_step) on the consumer-side path
 ctx.set_option("xrank_consumer", 1)
 sim = ja.Simulator(law, krylov(), tolerance=1e-9)
