@@ -30,7 +30,7 @@ run poly2M --mesh polyhedral --cells 2000000
 run cartesian10M --mesh cartesian
 run seams10 --path seams
 run nonlinear10M --law compressible --compressibility 0.5 --newton-tol 1e-7 --timesteps
-run nonlinear10M_hard --law compressible --compressibility 4 --newton-tol 1e-8 --rtol 1e-6 --max-newton 4 --timesteps
+run nonlinear10M_hard --law compressible --compressibility 4 --newton-tol 1e-8 --rtol 1e-6 --max-newton 8 --timesteps
 run unweighted10M --block-weights none
 run unweighted1M25 --cells 1253160 --block-weights none
 JH_BENCH_FORCE_DIST=1 python bench.py --no-cpu > $O/bench_dist_1rank.json 2> $O/bench_dist_1rank.err
