@@ -221,11 +221,12 @@ def main():
         k, _, v = kv.partition("=")
         options[k.strip()] = int(v) if v else 1
     ctx = ja.HIPContext(device, **options)
-    # Several ranks on ONE device with compute units of their own (JH_BENCH_CU_MASK=1: rank r gets CUs [r*256/N, (r+1)*256/N)):
+    # Several ranks on ONE device with compute units of their own (JH_BENCH_CU_MASK=1: rank r gets CUs [r*C/N, (r+1)*C/N) of the device's C):
     # the proxy of one-process-per-GPU the test box allows -- a kernel whose wavefronts wait for a peer cannot keep it off the chip
     cu_masked = shared_device and os.environ.get("JH_BENCH_CU_MASK") == "1"
     if cu_masked:
-        ctx.set_cu_mask(rank * (256 // world), 256 // world)
+        ncu_dev = torch.cuda.get_device_properties(device).multi_processor_count
+        ctx.set_cu_mask(rank * (ncu_dev // world), ncu_dev // world)
     elif world == 1 and os.environ.get("JH_BENCH_CUS"):  # one rank on a share of the chip: the proxy's no-communication reference
         ctx.set_cu_mask(0, int(os.environ["JH_BENCH_CUS"]))
     # every rank has compute units of its own: the Krylov loop finishes its dots over the ranks inside the consuming kernels and

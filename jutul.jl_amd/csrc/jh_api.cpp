@@ -253,22 +253,30 @@ extern "C" int32_t jh_context_destroy(jh_context ctx) {
 // contiguous range takes the same share of every XCD).  n_cus <= 0 removes the mask.  For several ranks on ONE device (tests,
 // proxies of a multi-GPU run): with disjoint ranges no rank's spinning kernel can keep another rank's kernel off the chip.  Call
 // it before any other object of the context is created; persistent grids are sized by the CUs the mask leaves.
+hipStream_t jh_context_s::new_stream() const {
+  hipStream_t ns = nullptr;
+  if (ncu >= ncu_total) {
+    JH_HIP(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+  } else {
+    std::vector<uint32_t> mask((size_t)(ncu_total + 31) / 32, 0u);
+    for (int i = cu_first; i < cu_first + ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    JH_HIP(hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
+  }
+  return ns;
+}
 extern "C" int32_t jh_context_set_cu_mask(jh_context ctx, int32_t first_cu, int32_t n_cus) {
   return guard([&] {
     if (!ctx) JH_THROW("null context");
     JH_HIP(hipSetDevice(ctx->device));
     JH_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->comm_stream) JH_THROW("jh_context_set_cu_mask after the context's communication stream was created: set the mask first");
+    if (n_cus > 0 && (first_cu < 0 || first_cu + n_cus > ctx->ncu_total))
+      JH_THROW("CU range outside the device's " + std::to_string(ctx->ncu_total) + " compute units");
+    const int old_first = ctx->cu_first, old_n = ctx->ncu;
+    ctx->cu_first = n_cus > 0 ? first_cu : 0;
+    ctx->ncu = n_cus > 0 ? n_cus : ctx->ncu_total;
     hipStream_t ns = nullptr;
-    if (n_cus <= 0) {
-      JH_HIP(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
-      ctx->ncu = ctx->ncu_total;
-    } else {
-      if (first_cu < 0 || first_cu + n_cus > ctx->ncu_total) JH_THROW("CU range outside the device's " + std::to_string(ctx->ncu_total) + " compute units");
-      std::vector<uint32_t> mask((size_t)(ctx->ncu_total + 31) / 32, 0u);
-      for (int i = first_cu; i < first_cu + n_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-      JH_HIP(hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
-      ctx->ncu = n_cus;
-    }
+    try { ns = ctx->new_stream(); } catch (...) { ctx->cu_first = old_first; ctx->ncu = old_n; throw; }
     (void)hipStreamDestroy(ctx->stream);
     ctx->stream = ns;
   });

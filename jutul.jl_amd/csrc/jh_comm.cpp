@@ -293,7 +293,7 @@ void halo_exchange_begin(jh_tpfa d, double *v, int bs, bool packed) {
   if (!d->halo.active) return;
   jh_context ctx = d->ctx;
   if (!ctx->comm_stream) {
-    JH_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    ctx->comm_stream = ctx->new_stream();  // (under the context's CU mask, if it has one)
     JH_HIP(hipEventCreateWithFlags(&ctx->ev_halo_ready, hipEventDisableTiming));
     JH_HIP(hipEventCreateWithFlags(&ctx->ev_halo_done, hipEventDisableTiming));
   }

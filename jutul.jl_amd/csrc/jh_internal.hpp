@@ -286,6 +286,8 @@ struct jh_context_s {
   jh::Options opt;
   hipStream_t stream = nullptr;
   int ncu_total = 256, ncu = 256;  // compute units of the device / of the stream (jh_context_set_cu_mask)
+  int cu_first = 0;                // first bit of the CU mask (ncu < ncu_total: every stream of the context carries it)
+  hipStream_t new_stream() const;  // a non-blocking stream under the context's CU mask (jh_api.cpp)
   int cus_per_xcd() const { return std::max(1, ncu / jh_num_xcd); }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_step[6] = {};  // jh_newton_step: factor / solve / update brackets, read once at the end of the step
@@ -472,6 +474,8 @@ void k_absmax_strided(jh_context ctx, const double *r, int64_t ncell, int bs, in
 void k_absstats(jh_context ctx, const double *a, const double *b, int64_t ncell, int bs, int slot);  // 4 scalars per variable from `slot`
 double read_scalar(jh_context ctx, int slot);                  // sync + D2H
 void read_scalars(jh_context ctx, int slot, int count, double *out);
+double read_scalars_begin(jh_context ctx, int slot, int count);  // publishing kernel enqueued; work enqueued next overlaps the host's wait
+void read_scalars_end(jh_context ctx, double seq, int slot, int count, double *out);
 // Optional dot-product epilogue of the SpMV: mode 1 -> sum(w .* y) ; mode 2 -> sum(y .* w), sum(y .* y); rows >= n_rows
 // (ghost rows) do not contribute.  Results land in ctx->scalars[slot (, slot+1)] after an ordered final reduction.
 struct SpmvDot {
@@ -497,6 +501,7 @@ constexpr int JDS_KMAX = 8;
 constexpr int JDS_FAR = 0xE000;   // first 16-bit column code that is an index into the slice's far list
 constexpr int JDS_BACK = 0x7000;  // the slice's column window starts this many rows before its first row
 bool sell_refresh(jh_csr A);  // false: the matrix has no jagged form (block size > 1 or long rows) -> CSR tile kernels
+bool sell_usable(jh_csr A);   // the same answer without launching the copy (builds the jagged pattern on first use)
 int k_spmv_sell(jh_csr A, const double *x, double *y, double alpha, double beta, const SpmvDot *dot, const double *done,
                 bool reduce_now = true, int waves = 4, const HaloFold *fold = nullptr);
 // jh_comm.cpp: the next push exchange of v as a HaloFold for the kernel that reads v (advances the push epoch); false: the push

@@ -249,16 +249,22 @@ __global__ void publish_scalars_kernel(const double *sc, int count, double *dst,
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(dst + (JH_NSCALARS - 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-void read_scalars(jh_context ctx, int slot, int count, double *out) {
+// Two halves, so that a caller can enqueue work that does not depend on the scalars between the publishing kernel and the host's
+// wait for it (the device goes on while the host reads).  begin returns the record's sequence number (0: the synchronous path).
+double read_scalars_begin(jh_context ctx, int slot, int count) {
   const bool use_sync = ctx->opt.read_sync != 0;
-  if (use_sync || !ctx->h_rd || count >= JH_NSCALARS - 1) {
+  if (use_sync || !ctx->h_rd || count >= JH_NSCALARS - 1) return 0.0;
+  const double seq = (double)(++ctx->rd_seq);
+  hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->scalars.p + slot, count, ctx->h_rd, seq);
+  return seq;
+}
+void read_scalars_end(jh_context ctx, double seq, int slot, int count, double *out) {
+  if (seq == 0.0) {
     JH_HIP(hipMemcpyAsync(ctx->h_scalars + slot, ctx->scalars.p + slot, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
     JH_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < count; ++i) out[i] = ctx->h_scalars[slot + i];
     return;
   }
-  const double seq = (double)(++ctx->rd_seq);
-  hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->scalars.p + slot, count, ctx->h_rd, seq);
   volatile double *r = ctx->h_rd;
   SpinPacer pace;
   for (;;) {
@@ -275,6 +281,9 @@ void read_scalars(jh_context ctx, int slot, int count, double *out) {
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   for (int i = 0; i < count; ++i) out[i] = r[i];
+}
+void read_scalars(jh_context ctx, int slot, int count, double *out) {
+  read_scalars_end(ctx, read_scalars_begin(ctx, slot, count), slot, count, out);
 }
 double read_scalar(jh_context ctx, int slot) {
   double v;

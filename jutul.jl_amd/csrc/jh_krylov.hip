@@ -348,7 +348,8 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   const bool fmul = right && ilu_can_fuse_gather(M) && ilu_can_fuse_product(M) && !(dist && want_overlap);
   const bool fmul_pack = fmul && dist && ilu_can_pack_halo(M);
   // the matrix does not change during the solve: multiply out of its jagged-slice copy when it has one (jh_sell.hip)
-  const bool jagged = !fmul && sell_refresh(K->A);
+  // (the copy itself is enqueued behind the start-of-solve reduction: it runs while the host waits for ||r0||)
+  const bool jagged = !fmul && sell_usable(K->A);
   if (fmul) ilu_eprod_refresh(M);
   // x = M^-1 (input), out = A x with the fused dot; event pairs: [1] the apply launch, [0] the out-of-block launch
   auto apply_mul = [&](const IluGather &G, double *bin, double *xv, double *out, const SpmvDot &dot) {
@@ -438,7 +439,9 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
     dot2(K->c.p, K->r.p, K->r.p, K->r.p, S_PAIR0);
   }
   double h2[2];
-  read_scalars(ctx, S_PAIR0, 2, h2);
+  const double rd_seq = read_scalars_begin(ctx, S_PAIR0, 2);
+  if (jagged && !sell_refresh(K->A)) JH_THROW("jagged copy of the matrix failed");
+  read_scalars_end(ctx, rd_seq, S_PAIR0, 2, h2);
   double rho = h2[0];
   double rnorm = std::sqrt(h2[1]);
   // min_iterations > 1 (krylov.jl:120-131, 199-206): the reference hands Krylov.jl atol = rtol = 1e-20 and lets a callback
@@ -842,19 +845,30 @@ extern "C" int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_
     // -- convergence (check_convergence, models.jl:818-883)
     k_absmax_strided(ctx, r->d.p, n_owned, L->N, S_ERR);
     comm_allreduce_dev(ctx, ctx->scalars.p + S_ERR, L->N, 1);
-    double err[3] = {0, 0, 0};
-    read_scalars(ctx, S_ERR, L->N, err);
-    JH_HIP(hipEventElapsedTime(&ms, e0, e1));
-    rep->assembly_ms = ms;
-    bool conv = true;
-    for (int e = 0; e < L->N; ++e) {
-      if (e < 2) rep->error[e] = err[e];
-      if (!(err[e] < tol)) conv = false;
-    }
-    rep->converged = conv ? 1 : 0;
     // force_solve: 0 = solve unless converged (check_before_solve, simulator.jl:435-441); 1 = always solve
-    // (iteration <= min_nonlinear_iterations, :484); -1 = assemble + check only (solve = false past max_iter, :566-570)
-    if (force_solve < 0 || (conv && force_solve == 0)) return;
+    // (iteration <= min_nonlinear_iterations, :484); -1 = assemble + check only (solve = false past max_iter, :566-570).
+    // With force_solve = 1 the outcome of the check decides nothing here: it is read at the end of the step, together with the
+    // event pairs, instead of idling the device for a host round trip in front of the factorisation (the S_ERR slots are not
+    // touched by the solve).
+    const bool defer_check = force_solve > 0;
+    auto read_check = [&] {
+      double err[3] = {0, 0, 0};
+      read_scalars(ctx, S_ERR, L->N, err);
+      float ms_a = 0;
+      JH_HIP(hipEventElapsedTime(&ms_a, e0, e1));
+      rep->assembly_ms = ms_a;
+      bool conv = true;
+      for (int e = 0; e < L->N; ++e) {
+        if (e < 2) rep->error[e] = err[e];
+        if (!(err[e] < tol)) conv = false;
+      }
+      rep->converged = conv ? 1 : 0;
+      return conv;
+    };
+    if (!defer_check) {
+      const bool conv = read_check();
+      if (force_solve < 0 || (conv && force_solve == 0)) return;
+    }
     // -- linear solve.  The host does not wait between the phases (every wait is an idle gap on the device): the event pairs are
     // read once at the end of the step
     hipEvent_t *ev = ctx->ev_step;
@@ -880,6 +894,7 @@ extern "C" int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_
       JH_HIP(hipEventRecord(ev[5], st));
     }
     JH_HIP(hipEventSynchronize(bad ? ev[3] : ev[5]));
+    if (defer_check) (void)read_check();
     JH_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
     rep->precond_ms = ms;
     JH_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));

@@ -408,12 +408,16 @@ __global__ __launch_bounds__(64 * NW) void spmv_jds16_kernel(const int32_t *__re
 }  // namespace
 
 // Copies the current values of A into the jagged-slice order; true if the Krylov loop can multiply with k_spmv_sell.
-bool sell_refresh(jh_csr A) {
-  A->jval_fresh = false;
+bool sell_usable(jh_csr A) {
   if (!A->ctx->opt.spmv_jagged) return false;
   Pattern &P = *A->pat;
   if (!P.jag.built) P.build_jagged();
-  if (!P.jag.usable) return false;
+  return P.jag.usable;
+}
+bool sell_refresh(jh_csr A) {
+  A->jval_fresh = false;
+  if (!sell_usable(A)) return false;
+  Pattern &P = *A->pat;
   if (A->jval.n < (size_t)P.jag.nent + 64) {
     A->jval.alloc((size_t)P.jag.nent + 64);
     JH_HIP(hipMemsetAsync(A->jval.p + P.jag.nent, 0, 64 * sizeof(double), A->ctx->stream));  // (the padding the last diagonal's lanes load)

@@ -46,7 +46,7 @@ def krylov():
 
 part = dd.partition_rcb(g["cell_centroids"], world)
 ctx = ja.HIPContext(0, comm_timeout_ms=60000)
-ncu = 256 // world
+ncu = torch.cuda.get_device_properties(0).multi_processor_count // world
 ctx.set_cu_mask(rank * ncu, ncu)  # compute units of this rank's own
 ctx.comm_init_ipc_only(world, rank)
 handles = [None] * world
