@@ -735,7 +735,7 @@ __device__ __forceinline__ void xr_sum(const MailArgs &A, XrRegs &R, bool report
   double v0 = 0.0, v1 = 0.0;
   if (lane < A.nranks && lane != A.rank) {
     const unsigned long long t0 = wall_clock64();
-    unsigned spins = 0;
+    unsigned spins = 0, backoff = 1;
     for (;;) {
       if ((R.g[0] >> 32) == tag && (R.g[1] >> 32) == tag && (R.g[2] >> 32) == tag && (R.g[3] >> 32) == tag) break;
       if (A.timeout_ticks) {
@@ -746,7 +746,10 @@ __device__ __forceinline__ void xr_sum(const MailArgs &A, XrRegs &R, bool report
           break;
         }
       }
-      __builtin_amdgcn_s_sleep(2);
+      // back off: thousands of wavefronts polling uncached memory take bandwidth from whoever is still working (a rank that waits
+      // long is waiting for a straggler anyway) -- 128 cycles first, doubling up to ~4k
+      for (unsigned k = 0; k < backoff; ++k) __builtin_amdgcn_s_sleep(2);
+      if (backoff < 32u) backoff <<= 1;
       xr_load(A, R);
     }
     v0 = __longlong_as_double((long long)((R.g[0] & 0xffffffffull) | (R.g[1] << 32)));
