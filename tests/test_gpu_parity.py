@@ -1610,6 +1610,55 @@ def test_context_options_api(ja):
         os.environ.pop("JH_OPTIONS", None)
 
 
+def test_option_values_and_context_knobs_are_validated(ja):
+    """What goes into launch geometry or shared state unvalidated is a hang or a race waiting for a typo: ilu_factor_threads only
+    takes the shapes its kernels are written for, JH_OPTIONS only integers, a CU mask only compute units the device has, the
+    communicator knobs need a communicator; jh_host_unregister releases only what jh_host_register pinned itself."""
+    import ctypes as C
+    import os
+    from jutul_amd._lib import load, check
+    c = ja.HIPContext(0)
+    for bad in (1, 32, 96, 1000):
+        with pytest.raises(ja.JutulHIPError, match="ilu_factor_threads"):
+            c.set_option("ilu_factor_threads", bad)
+    for good in (0, 64, 128, 256, 512):
+        c.set_option("ilu_factor_threads", good)
+    os.environ["JH_OPTIONS"] = "sync_loop=on"
+    try:
+        with pytest.raises(ja.JutulHIPError, match="not an integer"):
+            ja.HIPContext(0)
+    finally:
+        os.environ.pop("JH_OPTIONS", None)
+    with pytest.raises(ja.JutulHIPError, match="compute units"):
+        c.set_cu_mask(200, 100)
+    c.set_cu_mask(64, 64)      # a masked context computes the same numbers
+    g, rng = tet_case(ja, (8, 7, 6), seed=2)
+    disc = ja.TwoPointPotentialFlowHardCoded(c, g["N"], g["nc"], reorder="blocks", block_rows=64)
+    lsys = ja.LinearizedSystem(disc)
+    nz = rng.standard_normal(disc.pattern()[1].size)
+    lsys.jac.nzval = nz
+    x = rng.standard_normal(g["nc"])
+    y_masked = ja.mul_(ja.DeviceVector(disc), lsys.jac, ja.DeviceVector(disc, x)).download()
+    c2 = ja.HIPContext(0)
+    disc2 = ja.TwoPointPotentialFlowHardCoded(c2, g["N"], g["nc"], reorder="blocks", block_rows=64)
+    l2 = ja.LinearizedSystem(disc2)
+    l2.jac.nzval = nz
+    assert np.array_equal(y_masked, ja.mul_(ja.DeviceVector(disc2), l2.jac, ja.DeviceVector(disc2, x)).download())
+    c.set_cu_mask(0, 0)        # mask removed
+    with pytest.raises(ja.JutulHIPError, match="no communicator"):
+        c.comm_set_exclusive(True)
+    # page-locking: a second registration of the same range is success and not ours; unregistering twice is harmless
+    L = load()
+    a = np.zeros(1 << 16)
+    p = a.ctypes.data_as(C.c_void_p)
+    check(L.jh_host_register(p, a.nbytes))
+    check(L.jh_host_register(p, a.nbytes))      # already page-locked: success
+    check(L.jh_host_unregister(p))
+    check(L.jh_host_unregister(p))              # not registered by the library any more: no-op
+    b = np.ones(8)
+    check(L.jh_host_unregister(b.ctypes.data_as(C.c_void_p)))   # never registered: no-op, not an error
+
+
 @pytest.mark.parametrize("nt", [0, 1])
 def test_jagged_spmv_stream_policy_same_bits(ja, oracle, nt):
     """spmv_nontemporal: the matrix stream of the jagged SpMV through plain or non-temporal loads (chosen by working set against the
