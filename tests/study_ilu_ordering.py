@@ -85,3 +85,45 @@ inblock(bfs_rim, "BFS from a pseudo-peripheral cell")
 inblock(rcm, "RCM")
 inblock(cm, "Cuthill-McKee")
 inblock(lex, "lexicographic by centroid (z, y, x)")
+
+
+# ---- round 5 addendum: the weighted blocks (jh_partition_graph with the transmissibilities) and weight-aware in-block orders ----
+W = sp.csr_matrix((np.r_[T, T], (np.r_[Nf[0], Nf[1]], np.r_[Nf[1], Nf[0]])), shape=(nc, nc)).tocsr()
+pg = dd.partition_graph(g["N"], nc, nb, face_weights=T)
+order = np.argsort(pg, kind="stable")
+bp = np.concatenate([[0], np.cumsum(np.bincount(pg[order] - 1, minlength=nb))])
+def strong_dfs(Gb, rows):
+    """greedy chain: continue with the strongest-coupled unvisited neighbour of the current row, else of the most recent rows"""
+    Wb = W[rows][:, rows].tocsr()
+    n = len(rows); seen = np.zeros(n, bool); out = []
+    ip, ix, dv = Wb.indptr, Wb.indices, Wb.data
+    for s0 in range(n):
+        if seen[s0]: continue
+        stack = [s0]; seen[s0] = True
+        while stack:
+            v = stack.pop(); out.append(v)
+            nb_ = [(dv[k], ix[k]) for k in range(ip[v], ip[v + 1]) if not seen[ix[k]]]
+            nb_.sort()                       # weakest first -> strongest is popped next
+            for w_, u in nb_:
+                seen[u] = True; stack.append(u)
+    return np.array(out)
+def strong_bfs(Gb, rows):
+    """breadth-first from the block centre, neighbours taken strongest first"""
+    base = bfs_centre(Gb, rows)
+    Wb = W[rows][:, rows].tocsr()
+    n = len(rows); seen = np.zeros(n, bool); out = []
+    ip, ix, dv = Wb.indptr, Wb.indices, Wb.data
+    for s0 in base:
+        if seen[s0]: continue
+        q = [s0]; seen[s0] = True; h = 0
+        while h < len(q):
+            v = q[h]; h += 1; out.append(v)
+            nb_ = sorted(((dv[k], ix[k]) for k in range(ip[v], ip[v + 1]) if not seen[ix[k]]), reverse=True)
+            for w_, u in nb_:
+                seen[u] = True; q.append(u)
+    return np.array(out)
+print("--- weighted blocks ---")
+inblock(bfs_centre, "weighted blocks, BFS from the centre (device today)")
+inblock(rcm, "weighted blocks, RCM")
+inblock(strong_bfs, "weighted blocks, centre BFS, strongest neighbour first")
+inblock(strong_dfs, "weighted blocks, strongest-neighbour chains (DFS)")
