@@ -281,7 +281,18 @@ def main():
             attached_all = bool(int(flag[0]))
             mailbox = attached_all and os.environ.get("JH_BENCH_NO_MAILBOX") != "1"
             ctx.comm_ipc_enable(mailbox)
-            ctx.comm_set_exclusive(exclusive and mailbox)
+            xr_ok = False
+            if exclusive and mailbox:   # collective self-test of the consumer-side all-reduce: all ranks or none (like the mailboxes)
+                try:
+                    xr_ok = ctx.comm_xrank_selftest()
+                except Exception as e:  # noqa: BLE001
+                    print(f"[bench] rank {rank}: consumer-side all-reduce self-test failed: {e}", file=sys.stderr)
+                flag = torch.tensor([1 if xr_ok else 0])
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                xr_ok = bool(int(flag[0]))
+                if not xr_ok and rank == 0:
+                    print("[bench] consumer-side all-reduce self-test failed on some rank: reduction-launch path", file=sys.stderr)
+            ctx.comm_set_exclusive(exclusive and mailbox and xr_ok)
         cells = sub["cells"] - 1
         n_owned = sub["n_owned"]
         disc = ja.TwoPointPotentialFlowHardCoded(ctx, sub["N"], sub["n_local"], block_n=N, reorder="blocks", block_rows=args.block_rows,

@@ -390,6 +390,11 @@ int32_t jh_comm_ipc_enable(jh_context ctx, int32_t enable);
  * ranks), and the push halo's signal / wait / copy (consistent!, linalg.jl:37-55) runs inside the product kernel.  Where ranks
  * share compute units a chip-filling kernel waiting for a peer would keep that peer off the chip: leave it 0 (default). */
 int32_t jh_comm_set_exclusive(jh_context ctx, int32_t exclusive);
+/* Self-test of that path, collective (every rank calls it, after jh_comm_ipc_enable(ctx, 1)): 16 launches of 256 one-wavefront
+ * workgroups in which every wavefront collects the peers' sums, waits limited to 5 s; *ok = 1 if every wavefront held the sums in
+ * rank order.  Pass the AND of all ranks' answers (and of "every rank has compute units of its own") to jh_comm_set_exclusive --
+ * the same all-or-none negotiation as for the mailboxes and the push halo; a failure leaves the reduction-launch path usable. */
+int32_t jh_comm_xrank_selftest(jh_context ctx, int32_t *ok);
 /* In-process multi-rank backend (the analogue of DebugPArrayBackend / JuliaPArrayBackend,
  * src/ext/partitionedarrays_ext.jl:37-39): ranks are host threads of one process exchanging through host memory;
  * same pack/unpack kernels, halo plans and reduction placement as the RCCL path.  For tests on one GPU. */

@@ -162,6 +162,12 @@ class HIPContext(_Handle):
         finishes its dot products over the ranks inside the consuming kernels (five launches per BiCGStab iteration)."""
         check(_L().jh_comm_set_exclusive(self.h, 1 if exclusive else 0))
 
+    def comm_xrank_selftest(self):
+        """Collective self-test of the consumer-side all-reduce (every rank calls it); True if this rank saw every sum right."""
+        ok = C.c_int32(0)
+        check(_L().jh_comm_xrank_selftest(self.h, C.byref(ok)))
+        return bool(ok.value)
+
     def comm_finalize(self):
         check(_L().jh_comm_finalize(self.h))
 

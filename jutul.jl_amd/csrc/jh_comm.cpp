@@ -503,6 +503,40 @@ extern "C" int32_t jh_comm_set_exclusive(jh_context ctx, int32_t exclusive) {
   });
 }
 
+namespace jh {
+void xr_selftest_launch(hipStream_t s, const MailArgs &A, double v0, double v1, double *out, int nblocks);
+}  // namespace jh
+// Self-test of the consumer-side all-reduce before jh_comm_set_exclusive(ctx, 1): 16 launches of 256 one-wavefront workgroups in
+// which EVERY wavefront collects the peers' sums (time limit 5 s per wait); *ok = 1 if all of them hold the sums in rank order.
+// Collective: every rank calls it; enable the consumer-side path only if all ranks report 1 (like jh_comm_ipc_attach).
+extern "C" int32_t jh_comm_xrank_selftest(jh_context ctx, int32_t *ok) {
+  return guard([&] {
+    if (!ctx || !ctx->comm || !ok) JH_THROW("jh_comm_xrank_selftest needs a communicator");
+    Comm &c = *ctx->comm;
+    *ok = 0;
+    if (!c.mail_attached || !c.mail_enabled || c.nranks < 2) return;
+    JH_HIP(hipSetDevice(ctx->device));
+    const int nb = 256;
+    DevBuf<double> out;
+    out.alloc(2 * nb);
+    std::vector<double> got(2 * nb);
+    bool good = true;
+    for (int t = 0; t < 16 && good; ++t) {
+      auto f0 = [&](int r) { return (double)((r + 1) * (t + 3)) * (((r + t) & 1) ? 0.5 : -0.25) + 1e-3 * r; };
+      auto f1 = [&](int r) { return 1.0 / (double)(r + t + 1); };
+      double w0 = f0(0), w1 = f1(0);
+      for (int r = 1; r < c.nranks; ++r) { w0 += f0(r); w1 += f1(r); }  // rank order, like the kernel
+      xr_selftest_launch(ctx->stream, next_mail_args(ctx, 500000000ull), f0(c.rank), f1(c.rank), out.p, nb);
+      jh::copy_d2h(got.data(), out.p, got.size() * sizeof(double), ctx->stream);
+      JH_HIP(hipStreamSynchronize(ctx->stream));
+      if (c.mail_err->code) good = false;
+      for (int b = 0; b < nb; ++b) good = good && got[2 * b] == w0 && got[2 * b + 1] == w1;
+    }
+    if (!good) clear_mail_error(c);  // the reduction-launch path must stay usable
+    *ok = good ? 1 : 0;
+  });
+}
+
 extern "C" int32_t jh_comm_ipc_enable(jh_context ctx, int32_t enable) {
   return guard([&] {
     if (!ctx || !ctx->comm) JH_THROW("no communicator");

@@ -29,6 +29,19 @@ void mailbox_allreduce_launch(hipStream_t s, const MailArgs &A, double *p, int n
   hipLaunchKernelGGL(mailbox_allreduce_kernel, dim3(1), dim3(64), 0, s, A, p, n, op);
 }
 
+// self-test of the consumer-side all-reduce (xr_push / xr_sum): every wavefront of a many-workgroup launch collects the peers' sums
+__global__ __launch_bounds__(64) void xr_selftest_kernel(MailArgs A, double v0, double v1, double *out) {
+  XrRegs R;
+  xr_load(A, R);
+  double s0 = v0, s1 = v1;
+  if (blockIdx.x == 0) xr_push(A, s0, s1);
+  xr_sum(A, R, blockIdx.x == 0, s0, s1);
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = s0; out[2 * blockIdx.x + 1] = s1; }
+}
+void xr_selftest_launch(hipStream_t s, const MailArgs &A, double v0, double v1, double *out, int nblocks) {
+  hipLaunchKernelGGL(xr_selftest_kernel, dim3(nblocks), dim3(64), 0, s, A, v0, v1, out);
+}
+
 // ---- push halo ------------------------------------------------------------------------------------------------------------
 // Inside the Krylov loop the ghost exchange needs no collective library call either: the producer of the vector (the fused
 // ILU(0) apply, or this pack kernel) stores every boundary row straight into the landing buffers of the ranks that hold it

@@ -574,7 +574,11 @@ function setup_distributed!(ctx::HIPContext, nranks::Integer, rank::Integer, bca
     @jh :jh_comm_ipc_attach (Handle, Ptr{UInt8}, Ref{Int32}) ctx.handle all ok
     everyone = minimum(allgather(ok[])) == 1
     @jh :jh_comm_ipc_enable (Handle, Int32) ctx.handle Int32(everyone)
-    @jh :jh_comm_set_exclusive (Handle, Int32) ctx.handle Int32(everyone && exclusive_devices)
+    xok = Ref{Int32}(0)
+    if everyone && exclusive_devices   # collective self-test of the consumer-side all-reduce: all ranks or none
+        @jh :jh_comm_xrank_selftest (Handle, Ref{Int32}) ctx.handle xok
+    end
+    @jh :jh_comm_set_exclusive (Handle, Int32) ctx.handle Int32(everyone && exclusive_devices && minimum(allgather(xok[])) == 1)
     info = zeros(Int64, 8)
     @jh :jh_comm_info (Handle, Ptr{Int64}) ctx.handle info
     info[1] == nranks && info[3] == nranks || error("communicator has $(info[1]) ranks ($(info[3]) in RCCL), expected $nranks")

@@ -55,6 +55,7 @@ ok = torch.tensor([1 if ctx.comm_ipc_attach(handles) else 0])
 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
 assert int(ok[0]) == 1
 ctx.comm_ipc_enable(True)
+assert ctx.comm_xrank_selftest()   # (collective)
 ctx.comm_set_exclusive(True)
 assert ctx.comm_info()["consumer_allreduce"]
 disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, rank, T, g["volumes"], X0, kind=kind, block_n=nblk, sources=src,
