@@ -674,7 +674,8 @@ def selftest(args, ja, np, torch, dist, ctx, disc, law, rank, world, N, n_owned,
     flat = [p for ps in allp for p in ps]
     if rank == 0:
         out = {"selftest": {"ranks": world, "rccl_ranks": cinfo["rccl_ranks"], "paths": took, "requested": want, "state_halo_ok": halo_ok,
-                            "allreduce_ok": ar, "ghost_rows": int(nloc - n_owned), "comm_timeouts": ctx.comm_info()["timeouts"],
+                            "allreduce_ok": ar, "consumer_allreduce": bool(ctx.comm_info().get("consumer_allreduce")),
+                            "ghost_rows": int(nloc - n_owned), "comm_timeouts": ctx.comm_info()["timeouts"],
                             "problems": flat},
                "ok": not flat}
         sys.stdout.flush()
