@@ -42,6 +42,13 @@ int32_t jh_last_error(char *buf, int64_t cap);
 int32_t jh_version(void);
 /* device_id: HIP device ordinal.  Mirrors SingleCUDAContext's role (contexts/cuda.jl). */
 int32_t jh_context_create(int32_t device_id, jh_context *out);
+/* A PLANNING context: no device behind it.  The set-up entry points run their host phases on it -- jh_tpfa_create(_weighted)
+ * and every jh_tpfa_get_* table getter (a-1 .. a-4: the tables setup_equation_storage builds on the host,
+ * conservation/conservation.jl:101-216), jh_csr_create / jh_csr_create_from_pattern (pattern only), jh_spmv_info (jagged layout),
+ * jh_ilu0_create + jh_ilu0_info / jh_ilu0_stats (the symbolic phase of ilu0_csr, StaticCSR/ilu0.jl:13-81) -- and allocate or upload
+ * nothing; every entry point that computes refuses it ("this context has no device").  NOT a CPU fallback: it lets a maintainer
+ * (and this repository's CPU-only tests) check the set-up tables against Jutul's own and time the set-up on a box without a GPU. */
+int32_t jh_context_create_host(jh_context *out);
 int32_t jh_context_destroy(jh_context ctx);
 int32_t jh_synchronize(jh_context ctx); /* synchronize(ctx), context.jl:72 */
 /* Named integer options of a context -- the role of the keyword arguments of the reference's contexts and solver set-up

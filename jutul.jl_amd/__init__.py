@@ -67,9 +67,13 @@ class HIPContext(_Handle):
 
     def __init__(self, device=0, **options):
         """options: named integer options of the context (jh_context_set_option, include/jutul_hip.h), e.g.
-        HIPContext(0, consumer_reduce=0, spmv_col_bits=16)."""
+        HIPContext(0, consumer_reduce=0, spmv_col_bits=16).  device="host": a planning context without a device -- the
+        discretisation tables, the pattern and the ILU(0) symbolic phase can be built and read, nothing can be computed."""
         super().__init__()
-        check(_L().jh_context_create(int(device), C.byref(self.h)))
+        if device == "host":  # planning context: set-up tables only, every compute call raises (jh_context_create_host)
+            check(_L().jh_context_create_host(C.byref(self.h)))
+        else:
+            check(_L().jh_context_create(int(device), C.byref(self.h)))
         self.device = device
         self.comm_size, self.comm_rank = 1, 0
         for k, v in options.items():
@@ -545,8 +549,8 @@ class ILUZeroPreconditioner(_Handle):
         self.left, self.right, self.partition = left, right, partition
         self.A = None
 
-    def update_preconditioner(self, A):
-        """update_preconditioner!(ilu, A, b, context, executor) (precond/ilu.jl:37-60)."""
+    def symbolic(self, A):
+        """The symbolic phase alone (ilu0_csr's pattern work, StaticCSR/ilu0.jl:13-81): what a planning context can do."""
         if self.A is not A:
             self.close()
             if isinstance(self.partition, str) and self.partition == "blocks":
@@ -558,6 +562,11 @@ class ILUZeroPreconditioner(_Handle):
             else:
                 check(_L().jh_ilu0_create(A.h, None, 1, C.byref(self.h)))
             self.A = A
+        return self
+
+    def update_preconditioner(self, A):
+        """update_preconditioner!(ilu, A, b, context, executor) (precond/ilu.jl:37-60)."""
+        self.symbolic(A)
         check(_L().jh_ilu0_factor(self.h))
         return self
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "jh_last_error": [C.c_char_p, C.c_int64],
     "jh_version": [],
     "jh_context_create": [C.c_int32, C.POINTER(H)],
+    "jh_context_create_host": [C.POINTER(H)],
     "jh_context_destroy": [H],
     "jh_synchronize": [H],
     "jh_context_set_option": [H, C.c_char_p, C.c_int64],

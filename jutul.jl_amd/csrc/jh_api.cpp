@@ -13,6 +13,8 @@
 #include "jh_internal.hpp"
 
 namespace jh {
+thread_local bool tl_plan_only = false;  // jh_internal.hpp, "PLANNING CONTEXTS"
+
 void halo_exchange(jh_tpfa d, double *v, int bs, bool packed = false, bool push = false);
 }
 using namespace jh;
@@ -223,9 +225,21 @@ extern "C" int32_t jh_context_create(int32_t device_id, jh_context *out) {
     *out = c.release();
   });
 }
+// A context without a device: plans the set-up tables (jh_internal.hpp, "PLANNING CONTEXTS"); every compute entry point refuses it.
+extern "C" int32_t jh_context_create_host(jh_context *out) {
+  return guard([&] {
+    if (!out) JH_THROW("null argument");
+    auto c = std::make_unique<jh_context_s>();
+    c->device = -1;
+    c->plan_only = true;
+    c->opt.seed_from_env();
+    *out = c.release();
+  });
+}
 extern "C" int32_t jh_context_destroy(jh_context ctx) {
   return guard([&] {
     if (!ctx) return;
+    if (ctx->plan_only) { delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     (void)jh_comm_finalize(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -267,7 +281,7 @@ hipStream_t jh_context_s::new_stream() const {
 extern "C" int32_t jh_context_set_cu_mask(jh_context ctx, int32_t first_cu, int32_t n_cus) {
   return guard([&] {
     if (!ctx) JH_THROW("null context");
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::select_device(ctx);
     JH_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->comm_stream) JH_THROW("jh_context_set_cu_mask after the context's communication stream was created: set the mask first");
     if (n_cus > 0 && (first_cu < 0 || first_cu + n_cus > ctx->ncu_total))
@@ -284,15 +298,16 @@ extern "C" int32_t jh_context_set_cu_mask(jh_context ctx, int32_t first_cu, int3
 extern "C" int32_t jh_synchronize(jh_context ctx) {
   return guard([&] {
     if (!ctx) JH_THROW("null context");
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::select_device(ctx);
     JH_HIP(hipStreamSynchronize(ctx->stream));
   });
 }
 extern "C" int32_t jh_timer_start(jh_context ctx) {
-  return guard([&] { JH_HIP(hipEventRecord(ctx->ev0, ctx->stream)); });
+  return guard([&] { jh::require_device(ctx); JH_HIP(hipEventRecord(ctx->ev0, ctx->stream)); });
 }
 extern "C" int32_t jh_timer_stop_ms(jh_context ctx, double *ms) {
   return guard([&] {
+    jh::require_device(ctx);
     JH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     JH_HIP(hipEventSynchronize(ctx->ev1));
     float f = 0;
@@ -308,7 +323,7 @@ static jh_vec make_vec(jh_context ctx, std::shared_ptr<Pattern> pat) {
   v->pat = pat;
   v->bs = pat->bs;
   v->len = pat->n * pat->bs;
-  JH_HIP(hipSetDevice(ctx->device));
+  jh::select_device(ctx);
   v->d.alloc(v->len);
   JH_HIP(hipMemsetAsync(v->d.p, 0, v->len * sizeof(double), ctx->stream));
   return v.release();
@@ -329,7 +344,7 @@ extern "C" int32_t jh_vec_destroy(jh_vec v) {
   return guard([&] { delete v; });
 }
 static void upload_cells(jh_context ctx, const Pattern &P, double *dst, const double *host, int64_t n, int bs) {
-  JH_HIP(hipSetDevice(ctx->device));
+  jh::select_device(ctx);
   if (P.perm.empty()) {
     jh::copy_h2d(dst, host, n * bs * sizeof(double), ctx->stream);
   } else {
@@ -340,7 +355,7 @@ static void upload_cells(jh_context ctx, const Pattern &P, double *dst, const do
   JH_HIP(hipStreamSynchronize(ctx->stream));
 }
 static void download_cells(jh_context ctx, const Pattern &P, double *host, const double *src, int64_t n, int bs) {
-  JH_HIP(hipSetDevice(ctx->device));
+  jh::select_device(ctx);
   if (P.perm.empty()) {
     jh::copy_d2h(host, src, n * bs * sizeof(double), ctx->stream);
   } else {
@@ -386,7 +401,7 @@ extern "C" int32_t jh_vec_negate_into(jh_vec dx, jh_vec x) {
 extern "C" int32_t jh_vec_dot(jh_vec a, jh_vec b, double *out) {
   return guard([&] {
     if (a->len != b->len) JH_THROW("dimension mismatch");
-    JH_HIP(hipSetDevice(a->ctx->device));
+    jh::select_device(a->ctx);
     k_dot(a->ctx, a->d.p, b->d.p, a->len, 10);
     *out = read_scalar(a->ctx, 10);
   });
@@ -399,14 +414,14 @@ extern "C" int32_t jh_vec_length(jh_vec v, int64_t *n) {
 extern "C" int32_t jh_csr_create(jh_tpfa d, jh_csr *out) {
   return guard([&] {
     if (!d || !out) JH_THROW("null argument");
-    JH_HIP(hipSetDevice(d->ctx->device));
+    jh::DeviceScope dev(d->ctx);  // (planning contexts: a matrix without values, for jh_ilu0_create's symbolic phase)
     auto A = std::make_unique<jh_csr_s>();
     A->ctx = d->ctx;
     A->pat = d->pat;
     A->disc = d;
     size_t cnt = (size_t)d->nnzb * d->N * d->N;
     A->val.alloc(cnt);
-    JH_HIP(hipMemsetAsync(A->val.p, 0, cnt * sizeof(double), d->ctx->stream));
+    A->val.zero(d->ctx->stream);
     *out = A.release();
   });
 }
@@ -416,7 +431,7 @@ extern "C" int32_t jh_csr_create_from_pattern(jh_context ctx, int64_t n, int32_t
     if (!ctx || !rowptr || !colidx || !out) JH_THROW("null argument");
     if (bs < 1 || bs > 3) JH_THROW("block size must be 1..3");
     if (rowptr[0] != 1) JH_THROW("rowptr must be 1-based");
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::DeviceScope dev(ctx);  // (planning contexts: the pattern only)
     auto pat = std::make_shared<Pattern>();
     pat->ctx = ctx;
     pat->n = n;
@@ -443,9 +458,9 @@ extern "C" int32_t jh_csr_create_from_pattern(jh_context ctx, int64_t n, int32_t
     A->pat = pat;
     size_t cnt = (size_t)pat->nnzb * bs * bs;
     A->val.alloc(cnt);
-    if (nz) jh::copy_h2d(A->val.p, nz, cnt * sizeof(double), ctx->stream);
-    else JH_HIP(hipMemsetAsync(A->val.p, 0, cnt * sizeof(double), ctx->stream));
-    JH_HIP(hipStreamSynchronize(ctx->stream));
+    if (nz && !jh::tl_plan_only) jh::copy_h2d(A->val.p, nz, cnt * sizeof(double), ctx->stream);
+    else A->val.zero(ctx->stream);
+    jh::stream_sync(ctx->stream);
     *out = A.release();
   });
 }
@@ -464,7 +479,7 @@ extern "C" int32_t jh_csr_set_values(jh_csr A, const double *nz) {
   return guard([&] {
     if (!A || !nz) JH_THROW("null argument");
     jh_context ctx = A->ctx;
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::select_device(ctx);
     const Pattern &P = *A->pat;
     int bb = P.bs * P.bs;
     size_t cnt = (size_t)P.nnzb_host * bb;  // the host pattern; shadow slots of a multigraph read the zeroed spare slot behind it
@@ -483,7 +498,7 @@ extern "C" int32_t jh_csr_get_values(jh_csr A, double *nz) {
   return guard([&] {
     if (!A || !nz) JH_THROW("null argument");
     jh_context ctx = A->ctx;
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::select_device(ctx);
     const Pattern &P = *A->pat;
     int bb = P.bs * P.bs;
     size_t cnt = (size_t)P.nnzb_host * bb;
@@ -503,7 +518,7 @@ extern "C" int32_t jh_spmv(jh_csr A, jh_vec x, jh_vec y, double alpha, double be
     int64_t len = A->pat->n * A->pat->bs;
     if (x->len != len || y->len != len) JH_THROW("DimensionMismatch (mat.jl:27-28)");
     if (x == y) JH_THROW("x and y must not alias");
-    JH_HIP(hipSetDevice(A->ctx->device));
+    jh::select_device(A->ctx);
     k_spmv(A->ctx, *A->pat, A->val.p, x->d.p, y->d.p, alpha, beta);
     JH_HIP(hipGetLastError());
   });
@@ -514,7 +529,7 @@ extern "C" int32_t jh_spmv_jagged(jh_csr A, jh_vec x, jh_vec y, double alpha, do
     int64_t len = A->pat->n * A->pat->bs;
     if (x->len != len || y->len != len) JH_THROW("DimensionMismatch (mat.jl:27-28)");
     if (x == y) JH_THROW("x and y must not alias");
-    JH_HIP(hipSetDevice(A->ctx->device));
+    jh::select_device(A->ctx);
     const bool keep = A->ctx->opt.jds_keep != 0;  // tools/spmv_probe.py: time the product without the refresh
     if (!(keep && A->jval_fresh) && !sell_refresh(A)) JH_THROW("matrix has no jagged-slice form (block size > 1 or more than 8 entries in a row)");
     k_spmv_sell(A, x->d.p, y->d.p, alpha, beta, nullptr, nullptr);
@@ -526,6 +541,7 @@ extern "C" int32_t jh_spmv_info(jh_csr A, int64_t *out6) {
   return guard([&] {
     if (!A || !out6) JH_THROW("null argument");
     Pattern &P = *A->pat;
+    jh::DeviceScope dev(A->ctx);  // (planning contexts: the jagged layout is built, not uploaded)
     if (!P.jag.built) P.build_jagged();
     int32_t kmax = 0;
     for (int64_t i = 0; i < P.n; ++i) kmax = std::max(kmax, P.rowptr[i + 1] - P.rowptr[i]);
@@ -543,7 +559,7 @@ extern "C" int32_t jh_scale_system(jh_csr A, jh_vec r, int32_t kind, double dt) 
     if (kind == 0) return;
     if (kind != 1 && kind != 2) JH_THROW("scaling must be 0 (:none), 1 (:diagonal) or 2 (:dt)");
     if (r->len != A->pat->n * A->pat->bs) JH_THROW("dimension mismatch");
-    JH_HIP(hipSetDevice(A->ctx->device));
+    jh::select_device(A->ctx);
     k_scale_system(A->ctx->stream, *A->pat, A->val.p, r->d.p, kind, dt);
     JH_HIP(hipGetLastError());
   });
@@ -551,6 +567,7 @@ extern "C" int32_t jh_scale_system(jh_csr A, jh_vec r, int32_t kind, double dt) 
 extern "C" int32_t jh_unit_diagonalize(jh_csr A, jh_vec r, int64_t n_owned) {
   return guard([&] {
     if (!A || !r) JH_THROW("null argument");
+    jh::require_device(A->ctx);
     k_unit_diag(A->ctx->stream, *A->pat, A->val.p, r->d.p, n_owned);
   });
 }
@@ -562,7 +579,7 @@ extern "C" int32_t jh_law_create(jh_tpfa d, int32_t kind, const double *params, 
     int N = (kind == JH_LAW_TWOPHASE) ? 2 : 1;
     if (kind < 0 || kind > 2) JH_THROW("unknown law kind");
     if (N != d->N) JH_THROW("law needs block_n = " + std::to_string(N) + " but the discretisation has " + std::to_string(d->N));
-    JH_HIP(hipSetDevice(d->ctx->device));
+    jh::select_device(d->ctx);
     auto L = std::make_unique<jh_law_s>();
     L->ctx = d->ctx;
     L->disc = d;
@@ -589,7 +606,7 @@ extern "C" int32_t jh_law_set_data(jh_law L, int32_t which, const double *host) 
     if (!L || !host) JH_THROW("null argument");
     jh_context ctx = L->ctx;
     jh_tpfa d = L->disc;
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::select_device(ctx);
     hipStream_t s = ctx->stream;
     if (which == JH_FACE_TRANS || which == JH_FACE_GDZ) {
       ctx->ensure_stage(std::max<size_t>(d->nf, 1));
@@ -637,7 +654,7 @@ extern "C" int32_t jh_law_get_variable(jh_law L, int32_t which, int32_t e, doubl
     jh_context ctx = L->ctx;
     const Pattern &P = *L->disc->pat;
     const int64_t nc = L->disc->nc;
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::select_device(ctx);
     ctx->ensure_stage(nc);
     k_component_out(ctx->stream, ctx->stage.p, which ? L->X0.p : L->X.p, P.perm.empty() ? nullptr : P.d_perm.p, nc, L->N, e);
     jh::copy_d2h(out, ctx->stage.p, nc * sizeof(double), ctx->stream);
@@ -682,7 +699,7 @@ extern "C" int32_t jh_law_set_sources(jh_law L, int64_t n, const int64_t *cells,
   return guard([&] {
     if (!L) JH_THROW("null argument");
     if (n < 0 || (n > 0 && (!cells || !values))) JH_THROW("bad source list");
-    JH_HIP(hipSetDevice(L->ctx->device));
+    jh::select_device(L->ctx);
     // forces are re-applied in every Newton iteration (update_equations_and_apply_forces!): an unchanged list costs nothing
     if (L->src_set && (int64_t)L->h_src_cells.size() == n && std::equal(cells, cells + n, L->h_src_cells.begin()) &&
         std::equal(values, values + n * L->N, L->h_src_vals.begin(), [](double a, double b) { return std::memcmp(&a, &b, sizeof(double)) == 0; }))
@@ -723,7 +740,7 @@ extern "C" int32_t jh_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
     if (A->pat != L->disc->pat) JH_THROW("matrix does not belong to the law's discretisation");
     if (r->len != L->disc->nc * L->N) JH_THROW("residual has wrong length");
     if (L->kind != JH_LAW_POISSON && !(dt > 0)) JH_THROW("dt must be positive");
-    JH_HIP(hipSetDevice(L->ctx->device));
+    jh::select_device(L->ctx);
     k_assemble(L, dt, A, r);
     JH_HIP(hipGetLastError());
   });
@@ -731,7 +748,7 @@ extern "C" int32_t jh_assemble(jh_law L, double dt, jh_csr A, jh_vec r) {
 extern "C" int32_t jh_convergence(jh_law L, jh_vec r, int64_t n_owned, double *err) {
   return guard([&] {
     if (!L || !r || !err) JH_THROW("null argument");
-    JH_HIP(hipSetDevice(L->ctx->device));
+    jh::select_device(L->ctx);
     if (n_owned <= 0) n_owned = L->disc->nc;
     k_absmax_strided(L->ctx, r->d.p, n_owned, L->N, 12);
     read_scalars(L->ctx, 12, L->N, err);
@@ -740,7 +757,7 @@ extern "C" int32_t jh_convergence(jh_law L, jh_vec r, int64_t n_owned, double *e
 extern "C" int32_t jh_update_primary(jh_law L, jh_vec dx, double w, const double *limits) {
   return guard([&] {
     if (!L || !dx) JH_THROW("null argument");
-    JH_HIP(hipSetDevice(L->ctx->device));
+    jh::select_device(L->ctx);
     const double *lim_dev = nullptr;
     if (limits) {
       jh::copy_h2d(L->ctx->scalars.p + 16, limits, 5 * L->N * sizeof(double), L->ctx->stream);
@@ -754,7 +771,7 @@ extern "C" int32_t jh_update_primary(jh_law L, jh_vec dx, double w, const double
 extern "C" int32_t jh_law_set_update_limits(jh_law L, const double *limits) {
   return guard([&] {
     if (!L) JH_THROW("null argument");
-    JH_HIP(hipSetDevice(L->ctx->device));
+    jh::select_device(L->ctx);
     JH_HIP(hipStreamSynchronize(L->ctx->stream));
     if (!limits) { L->limits.release(); return; }
     std::vector<double> h(limits, limits + 5 * L->N);
@@ -766,7 +783,7 @@ extern "C" int32_t jh_increment_norm(jh_law L, jh_vec dx, int64_t n_owned, doubl
   return guard([&] {
     if (!L || !dx || !out) JH_THROW("null argument");
     if (dx->len != L->disc->nc * L->N) JH_THROW("increment has wrong length");
-    JH_HIP(hipSetDevice(L->ctx->device));
+    jh::select_device(L->ctx);
     if (n_owned <= 0 || n_owned > L->disc->nc) n_owned = L->disc->nc;
     k_absstats(L->ctx, dx->d.p, nullptr, n_owned, L->N, S_STATS);
     double h[12];
@@ -777,7 +794,7 @@ extern "C" int32_t jh_increment_norm(jh_law L, jh_vec dx, int64_t n_owned, doubl
 extern "C" int32_t jh_law_change_report(jh_law L, int64_t n_owned, double *out) {
   return guard([&] {
     if (!L || !out) JH_THROW("null argument");
-    JH_HIP(hipSetDevice(L->ctx->device));
+    jh::select_device(L->ctx);
     if (n_owned <= 0 || n_owned > L->disc->nc) n_owned = L->disc->nc;
     k_absstats(L->ctx, L->X.p, L->X0.p, n_owned, L->N, S_STATS);
     read_scalars(L->ctx, S_STATS, 4 * L->N, out);
@@ -786,14 +803,14 @@ extern "C" int32_t jh_law_change_report(jh_law L, int64_t n_owned, double *out) 
 extern "C" int32_t jh_halo_exchange(jh_tpfa d, jh_vec v) {
   return guard([&] {
     if (!d || !v) JH_THROW("null argument");
-    JH_HIP(hipSetDevice(d->ctx->device));
+    jh::select_device(d->ctx);
     halo_exchange(d, v->d.p, v->bs);
   });
 }
 extern "C" int32_t jh_halo_exchange_state(jh_law L) {
   return guard([&] {
     if (!L) JH_THROW("null argument");
-    JH_HIP(hipSetDevice(L->ctx->device));
+    jh::select_device(L->ctx);
     halo_exchange(L->disc, L->X.p, L->N);
   });
 }

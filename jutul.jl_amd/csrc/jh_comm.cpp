@@ -325,7 +325,7 @@ extern "C" int32_t jh_comm_init(jh_context ctx, int32_t nranks, int32_t rank, co
   return guard([&] {
     if (!ctx) JH_THROW("null context");
     if (ctx->comm) JH_THROW("communicator already initialised");
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::select_device(ctx);
     auto c = std::make_unique<Comm>();
     c->nranks = nranks;
     c->rank = rank;
@@ -356,6 +356,7 @@ extern "C" int32_t jh_comm_local_group_destroy(void *group) {
 extern "C" int32_t jh_comm_init_local(jh_context ctx, void *group, int32_t rank) {
   return guard([&] {
     if (!ctx || !group) JH_THROW("null argument");
+    jh::require_device(ctx);
     if (ctx->comm) JH_THROW("communicator already initialised");
     auto *G = (LocalGroup *)group;
     if (rank < 0 || rank >= G->n) JH_THROW("rank out of range");
@@ -403,7 +404,7 @@ extern "C" int32_t jh_halo_info(jh_tpfa d, int64_t *out6) {
 // ---- mailbox all-reduce: the solver's 1-2 scalar reductions over peer-mapped device memory ------------------------------
 extern "C" int32_t jh_comm_init_ipc_only(jh_context ctx, int32_t nranks, int32_t rank) {
   return guard([&] {
-    if (!ctx) JH_THROW("null context");
+    jh::require_device(ctx);
     if (ctx->comm) JH_THROW("communicator already initialised");
     if (nranks < 1 || rank < 0 || rank >= nranks) JH_THROW("bad rank / size");
     auto c = std::make_unique<Comm>();
@@ -429,7 +430,7 @@ extern "C" int32_t jh_comm_ipc_export(jh_context ctx, char *handle64) {
     Comm &c = *ctx->comm;
     if (c.local) JH_THROW("the in-process backend has no mailboxes");
     if (c.nranks > MAIL_MAX_RANKS) JH_THROW("mailbox all-reduce supports at most 16 ranks");
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::select_device(ctx);
     if (!c.mail_self) {
       // uncached (fine-grained) device memory: peer stores over xGMI become visible without cache maintenance
       JH_HIP(hipExtMallocWithFlags((void **)&c.mail_self, mailbox_bytes(), hipDeviceMallocUncached));
@@ -452,7 +453,7 @@ extern "C" int32_t jh_comm_ipc_attach(jh_context ctx, const char *handles, int32
     if (!ctx || !ctx->comm || !handles || !ok) JH_THROW("null argument");
     Comm &c = *ctx->comm;
     if (!c.mail_self) JH_THROW("jh_comm_ipc_export first");
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::select_device(ctx);
     *ok = 0;
     c.mail_peer.assign(c.nranks, nullptr);
     for (int r = 0; r < c.nranks; ++r) {
@@ -515,7 +516,7 @@ extern "C" int32_t jh_comm_xrank_selftest(jh_context ctx, int32_t *ok) {
     Comm &c = *ctx->comm;
     *ok = 0;
     if (!c.mail_attached || !c.mail_enabled || c.nranks < 2) return;
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::select_device(ctx);
     const int nb = 256;
     DevBuf<double> out;
     out.alloc(2 * nb);
@@ -552,7 +553,7 @@ extern "C" int32_t jh_halo_ipc_export(jh_tpfa d, char *handle64) {
     auto &H = d->halo;
     if (!H.active) JH_THROW("jh_halo_create first");
     if (!d->ctx->comm || !d->ctx->comm->mail_attached) JH_THROW("the push halo needs attached mailboxes (jh_comm_ipc_attach)");
-    JH_HIP(hipSetDevice(d->ctx->device));
+    jh::select_device(d->ctx);
     if (!H.landing) {
       H.landing_stride = std::max<int64_t>(1, H.n_recv * d->N);
       JH_HIP(hipExtMallocWithFlags((void **)&H.landing, sizeof(double) * HALO_S * H.landing_stride, hipDeviceMallocUncached));
@@ -573,7 +574,7 @@ extern "C" int32_t jh_halo_ipc_attach(jh_tpfa d, const char *nbr_handles, const 
     auto &H = d->halo;
     if (!H.landing) JH_THROW("jh_halo_ipc_export first");
     Comm &c = *d->ctx->comm;
-    JH_HIP(hipSetDevice(d->ctx->device));
+    jh::select_device(d->ctx);
     *ok = 0;
     const int nn = (int)H.nbr.size();
     H.peer_landing.assign(nn, nullptr);
@@ -654,7 +655,7 @@ extern "C" int32_t jh_allreduce(jh_context ctx, double *values, int32_t n, int32
     if (!ctx) JH_THROW("null context");
     if (!ctx->comm || ctx->comm->nranks == 1) return;
     if (n > 16) JH_THROW("jh_allreduce handles at most 16 scalars");
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::select_device(ctx);
     double *dev = ctx->scalars.p + 16;
     jh::copy_h2d(dev, values, sizeof(double) * n, ctx->stream);
     comm_allreduce_dev(ctx, dev, n, op);
@@ -670,6 +671,7 @@ extern "C" int32_t jh_halo_create(jh_tpfa d, int64_t n_owned, int32_t n_nbr, con
                                   const int64_t *send_cells, const int64_t *recv_ptr, const int64_t *recv_cells) {
   return guard([&] {
     if (!d) JH_THROW("null handle");
+    jh::require_device(d->ctx);
     const Pattern &P = *d->pat;
     auto &H = d->halo;
     H.n_owned = n_owned;

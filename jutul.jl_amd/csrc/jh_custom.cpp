@@ -214,7 +214,7 @@ extern "C" int32_t jh_law_create_custom(jh_tpfa d, const char *source, const dou
     if (!d || !source || !out) JH_THROW("null argument");
     if (d->N < 1 || d->N > 3) JH_THROW("custom laws support 1..3 equations per cell");
     if (n_params < 0 || (n_params > 0 && !params)) JH_THROW("bad parameter array");
-    JH_HIP(hipSetDevice(d->ctx->device));
+    jh::select_device(d->ctx);
     auto L = std::make_unique<jh_law_s>();
     L->ctx = d->ctx;
     L->disc = d;

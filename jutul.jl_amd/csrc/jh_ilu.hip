@@ -1996,7 +1996,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       if (P.diag[i] < 0) JH_THROW("Diagonal must be present in sparsity pattern.");
     auto M = std::make_unique<jh_ilu_s>();
     M->ctx = A->ctx; M->A = A; M->pat = A->pat; M->bs = P.bs; M->n = n;
-    JH_HIP(hipSetDevice(M->ctx->device));
+    jh::DeviceScope dev(M->ctx);  // (planning contexts: the symbolic phase and the layouts, nothing allocated or uploaded)
     const bool timing = M->ctx->opt.setup_timing != 0;
     auto tlast = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -2515,8 +2515,8 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
                 M->d_e_row.upload(e_row, su); M->d_e_ptr.upload(e_ptr, su); M->d_e_col.upload(e_col, su); M->d_e_slot.upload(e_slot, su);
                 M->jkap.alloc((size_t)M->j_nslots * P.bs * P.bs);
                 M->jdinv_f.alloc((size_t)M->j_nslots * P.bs * P.bs);
-                JH_HIP(hipMemsetAsync(M->jkap.p, 0, M->jkap.n * sizeof(double), su));
-                JH_HIP(hipMemsetAsync(M->jdinv_f.p, 0, M->jdinv_f.n * sizeof(double), su));
+                M->jkap.zero(su);
+                M->jdinv_f.zero(su);
               }
             }
             if (timing) fprintf(stderr, "[jutul_hip setup] ilu0: pivot-only factorisation %s (largest block: %d chunks), fused product %s (%lld rows with %lld out-of-block entries)\n",
@@ -2552,9 +2552,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         M->d_jl_of_old.upload(M->jl_of_old, sj); M->d_ju_of_old.upload(M->ju_of_old, sj); M->d_jd_of_old.upload(M->jd_of_old, sj);
         const size_t bbj = (size_t)P.bs * P.bs;
         M->jl_val.alloc((size_t)(M->jl_nent + 64) * bbj); M->ju_val.alloc((size_t)(M->ju_nent + 64) * bbj); M->jdinv.alloc((size_t)M->j_nslots * bbj);
-        JH_HIP(hipMemsetAsync(M->jl_val.p, 0, M->jl_val.n * sizeof(double), sj));
-        JH_HIP(hipMemsetAsync(M->ju_val.p, 0, M->ju_val.n * sizeof(double), sj));
-        JH_HIP(hipMemsetAsync(M->jdinv.p, 0, M->jdinv.n * sizeof(double), sj));
+        M->jl_val.zero(sj);
+        M->ju_val.zero(sj);
+        M->jdinv.zero(sj);
         // chains of lanes need the unit pivots the program kernel writes: without a program (a block beyond its 16-bit indices or
         // the LDS) long rows keep the row-major sweeps
         if (VR && !M->prog) { M->jag = false; M->jag_vr = false; jag_ok = false; }
@@ -2680,7 +2680,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     }
     if (!lds) M->xg.alloc((size_t)n * P.bs);
     M->lds_bytes = lds ? (size_t)maxrows * P.bs * sizeof(double) : 0;
-    JH_HIP(hipStreamSynchronize(s));
+    jh::stream_sync(s);
     lap("upload");
     *out = M.release();
   });
@@ -2722,7 +2722,7 @@ extern "C" int32_t jh_diag_precond_create(jh_csr A, int32_t kind, double w, jh_i
     M->ctx = A->ctx; M->A = A; M->pat = A->pat; M->bs = A->pat->bs; M->n = A->pat->n;
     M->kind = kind;
     M->jacobi_w = w;
-    JH_HIP(hipSetDevice(M->ctx->device));
+    jh::select_device(M->ctx);
     M->dinv.alloc((size_t)M->n * M->bs * M->bs);
     *out = M.release();
   });
@@ -3075,7 +3075,7 @@ int ilu_eprod(jh_ilu M, const double *x, double *q, const SpmvDot *dot, const do
 extern "C" int32_t jh_ilu0_factor(jh_ilu M) {
   return guard([&] {
     if (!M) JH_THROW("null handle");
-    JH_HIP(hipSetDevice(M->ctx->device));
+    jh::select_device(M->ctx);
     jh::ilu_factor(M);
     JH_HIP(hipGetLastError());
   });
@@ -3085,7 +3085,7 @@ extern "C" int32_t jh_ilu0_apply(jh_ilu M, jh_vec b, jh_vec x) {
   return guard([&] {
     if (!M || !b || !x) JH_THROW("null handle");
     if (b->len != M->n * M->bs || x->len != b->len) JH_THROW("dimension mismatch in ilu apply");
-    JH_HIP(hipSetDevice(M->ctx->device));
+    jh::select_device(M->ctx);
     if (b == x && !M->lds_mode) { /* in-place is fine: gather copies first */ }
     jh::ilu_apply(M, b->d.p, x->d.p);
     JH_HIP(hipGetLastError());
@@ -3098,7 +3098,7 @@ extern "C" int32_t jh_ilu0_apply_mul(jh_ilu M, jh_vec b, jh_vec x, jh_vec q) {
     if (b->len != M->n * M->bs || x->len != b->len || q->len != b->len) JH_THROW("dimension mismatch in ilu apply + product");
     if (b == x || x == q || b == q) JH_THROW("b, x and q must not alias");
     if (!M->factored) JH_THROW("ILU(0) applied before jh_ilu0_factor");
-    JH_HIP(hipSetDevice(M->ctx->device));
+    jh::select_device(M->ctx);
     if (jh::ilu_can_fuse_product(M)) {
       jh::ilu_eprod_refresh(M);
       jh::ilu_apply_mul(M, jh::IluGather(), b->d.p, x->d.p, q->d.p, nullptr, nullptr, false);

@@ -146,6 +146,15 @@ constexpr int S_STATS = 32;       // [32, 44): k_absstats results (4 per variabl
 void copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s);
 void copy_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s);
 
+// PLANNING CONTEXTS (jh_context_create_host): a context without a device.  The set-up entry points -- jh_tpfa_create*, the table
+// getters, jh_csr_create, jh_ilu0_create and its info getters -- run their host phases (connectivity, device ordering, pattern,
+// tiles, ILU(0) symbolic phase and layouts) and skip every allocation, upload and memset; everything that computes on the device
+// refuses such a context (require_device).  tl_plan_only is raised by DeviceScope for the duration of one entry point on the
+// calling thread: all device work of the set-up is issued from that thread (the worker threads of parallel_ranges only fill host
+// arrays).  There is no CPU compute path behind this: it exists so that the set-up tables can be checked and timed on a box
+// without a GPU (tests -m "not gpu", tools/setup_probe.py).
+extern thread_local bool tl_plan_only;
+
 template <class T>
 struct DevBuf {
   T *p = nullptr;
@@ -162,15 +171,19 @@ struct DevBuf {
   void alloc(size_t count) {
     release();
     n = count;
-    if (count) JH_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+    if (count && !tl_plan_only) JH_HIP(hipMalloc((void **)&p, count * sizeof(T)));
   }
   void upload(const T *h, size_t count, hipStream_t s) {
     if (count > n) alloc(count);
-    if (count) jh::copy_h2d(p, h, count * sizeof(T), s);
+    if (count && !tl_plan_only) jh::copy_h2d(p, h, count * sizeof(T), s);
   }
   void upload(const std::vector<T> &h, hipStream_t s) {
     alloc(h.size());
-    if (!h.empty()) jh::copy_h2d(p, h.data(), h.size() * sizeof(T), s);
+    if (!h.empty() && !tl_plan_only) jh::copy_h2d(p, h.data(), h.size() * sizeof(T), s);
+  }
+  // zero-fill on the stream (nothing to do for a planning context)
+  void zero(hipStream_t s) {
+    if (p && n && !tl_plan_only) JH_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
   }
 };
 
@@ -308,7 +321,36 @@ struct jh_context_s {
   void ensure_stage(size_t n) {
     if (stage.n < n) stage.alloc(n);
   }
+  bool plan_only = false;  // jh_context_create_host: no device behind this context (device == -1, no stream)
 };
+
+namespace jh {
+// First statement of a set-up entry point that also serves planning contexts: selects the context's device, or raises
+// tl_plan_only until the entry point returns.
+struct DeviceScope {
+  bool prev;
+  explicit DeviceScope(jh_context c) : prev(tl_plan_only) {
+    if (c->plan_only) tl_plan_only = true;
+    else JH_HIP(hipSetDevice(c->device));
+  }
+  ~DeviceScope() { tl_plan_only = prev; }
+  DeviceScope(const DeviceScope &) = delete;
+  DeviceScope &operator=(const DeviceScope &) = delete;
+};
+// every entry point that computes on the device
+static inline void require_device(jh_context c) {
+  if (!c) JH_THROW("null context");
+  if (c->plan_only) JH_THROW("this context has no device (jh_context_create_host): it only plans the set-up tables");
+}
+// first statement of every entry point that works on the device
+static inline void select_device(jh_context c) {
+  require_device(c);
+  JH_HIP(hipSetDevice(c->device));
+}
+static inline void stream_sync(hipStream_t s) {
+  if (!tl_plan_only) JH_HIP(hipStreamSynchronize(s));
+}
+}  // namespace jh
 
 namespace jh {
 

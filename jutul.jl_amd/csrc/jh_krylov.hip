@@ -266,7 +266,7 @@ inline dim3 vgrid(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::m
 extern "C" int32_t jh_krylov_create(jh_csr A, jh_krylov *out) {
   return guard([&] {
     if (!A || !out) JH_THROW("null argument");
-    JH_HIP(hipSetDevice(A->ctx->device));
+    jh::select_device(A->ctx);
     auto K = std::make_unique<jh_krylov_s>();
     K->ctx = A->ctx;
     K->A = A;
@@ -778,7 +778,7 @@ extern "C" int32_t jh_gmres(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh_ve
   return guard([&] {
     if (!K || !b || !x || !iters || !status) JH_THROW("null argument");
     if (b->len != K->len || x->len != K->len) JH_THROW("dimension mismatch in gmres");
-    JH_HIP(hipSetDevice(K->ctx->device));
+    jh::select_device(K->ctx);
     *status = jh::gmres(K, M, side, b->d.p, x->d.p, rtol, atol, itmax, iters, hist, hist_cap);
   });
 }
@@ -817,7 +817,7 @@ extern "C" int32_t jh_bicgstab(jh_krylov K, jh_ilu M, int32_t side, jh_vec b, jh
   return guard([&] {
     if (!K || !b || !x || !iters || !status) JH_THROW("null argument");
     if (b->len != K->len || x->len != K->len) JH_THROW("dimension mismatch in bicgstab");
-    JH_HIP(hipSetDevice(K->ctx->device));
+    jh::select_device(K->ctx);
     *status = jh::bicgstab(K, M, side, b->d.p, x->d.p, rtol, atol, itmax, iters, hist, hist_cap);
   });
 }
@@ -828,7 +828,7 @@ extern "C" int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_
   return guard([&] {
     if (!L || !A || !K || !r || !dx || !rep) JH_THROW("null argument");
     jh_context ctx = L->ctx;
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::select_device(ctx);
     hipStream_t st = ctx->stream;
     std::memset(rep, 0, sizeof(*rep));
     hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;

@@ -104,7 +104,7 @@ void Pattern::build_jagged() {
   // from 2M; the rank-local matrix of an 8-rank 10M-cell run, ghost rows included, counts 211 MB)
   const int64_t nt = ctx->opt.spmv_nontemporal;
   jag.nontemporal = nt >= 0 ? nt != 0 : 12.0 * (double)nnzb + 100.0 * (double)n > 235e6;
-  JH_HIP(hipStreamSynchronize(st));
+  stream_sync(st);
   jag.usable = true;
 }
 

@@ -60,7 +60,7 @@ void Pattern::upload() {
   d_tile_desc.upload(tile_desc, s);
   if (!perm.empty()) d_perm.upload(perm, s);
   if (!nz_hslot.empty()) d_nz_hslot.upload(nz_hslot, s);
-  JH_HIP(hipStreamSynchronize(s));
+  stream_sync(s);
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -445,7 +445,7 @@ extern "C" int32_t jh_tpfa_create_weighted(jh_context ctx, int64_t nc, int64_t n
     if (nc + 2 * nf > (int64_t)INT32_MAX / ((int64_t)block_n * block_n))
       JH_THROW("discretisation too large for 32-bit device indices: partition it across more ranks");
     if (nc > 2000000000LL || 2 * nf + nc > 2000000000LL) JH_THROW("problem too large for 32-bit device indices");
-    JH_HIP(hipSetDevice(ctx->device));
+    jh::DeviceScope dev(ctx);  // (planning contexts: host phases only)
     auto d = std::make_unique<jh_tpfa_s>();
     d->ctx = ctx;
     d->nc = nc;
@@ -591,7 +591,7 @@ extern "C" int32_t jh_tpfa_create_weighted(jh_context ctx, int64_t nc, int64_t n
     pat->upload();
     pt.lap("tiles + upload");
     d->d_nz_face.upload(d->nz_face, ctx->stream);
-    JH_HIP(hipStreamSynchronize(ctx->stream));
+    jh::stream_sync(ctx->stream);
     d->pat = pat;
     *out = d.release();
   });

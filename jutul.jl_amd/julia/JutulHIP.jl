@@ -62,7 +62,11 @@ mutable struct HIPContext <: GPUJutulContext
     # (contexts/csr.jl:3-23)
     function HIPContext(device = 0; matrix_layout = BlockMajorLayout(), block_rows = 0, n_owned = 0, options...)
         h = Ref{Handle}(C_NULL)
-        @jh :jh_context_create (Int32, Ref{Handle}) Int32(device) h
+        if device < 0   # planning context: set-up tables only (jh_context_create_host), every compute call throws
+            @jh :jh_context_create_host (Ref{Handle},) h
+        else
+            @jh :jh_context_create (Int32, Ref{Handle}) Int32(device) h
+        end
         ctx = new(h[], device, matrix_layout, block_rows, n_owned)
         finalizer(c -> ccall((:jh_context_destroy, libjutul_hip), Int32, (Handle,), c.handle), ctx)
         for (k, v) in options

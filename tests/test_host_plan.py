@@ -1,0 +1,176 @@
+"""CPU-only: the PRODUCT library's set-up tables (SURVEY 8 rows a-1 .. a-4, a-13's partition, a-11's symbolic phase) through a
+planning context (jh_context_create_host) -- the same C++ that runs in front of the GPU kernels, checked bit for bit against the
+oracle without a device.  Every compute entry point must refuse such a context (there is no CPU fallback)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ja():
+    import __graft_entry__ as g
+    g.build()
+    import jutul_amd
+    return jutul_amd
+
+
+@pytest.fixture(scope="module")
+def hctx(ja):
+    return ja.HIPContext("host")
+
+
+def check_tables(ja, hctx, oracle, N, nc, nblk, reorder, block_rows=64, weights=None):
+    disc = ja.TwoPointPotentialFlowHardCoded(hctx, N, nc, block_n=nblk, reorder=reorder, block_rows=block_rows, face_weights=weights)
+    h = oracle.half_face_map(N, nc)
+    c = disc.conn
+    assert np.array_equal(c["face_pos"], h["face_pos"])
+    assert np.array_equal(c["self"], h["self"]) and np.array_equal(c["other"], h["other"])
+    assert np.array_equal(c["face"], h["faces"]) and np.array_equal(c["face_sign"], h["face_sign"])
+    rowptr, colidx = disc.pattern()
+    orp, oci = oracle.csr_pattern(nc, h)
+    assert np.array_equal(rowptr, orp) and np.array_equal(colidx, oci)
+    pa, pf = disc.jacobian_positions()
+    opa, opf = oracle.align(nc, nblk, 2, orp, oci, h)
+    assert np.array_equal(pa, opa) and np.array_equal(pf, opf)
+    perm, bp = disc.ordering()
+    assert np.array_equal(np.sort(perm), np.arange(1, nc + 1))
+    return disc, h, (orp, oci), (perm, bp)
+
+
+@pytest.mark.parametrize("reorder", ["none", "blocks"])
+@pytest.mark.parametrize("nblk", [1, 2])
+def test_tables_bit_exact_on_a_tet_lattice(ja, hctx, oracle, reorder, nblk):
+    g = ja.tet_lattice_mesh(5, 4, 3)
+    disc, _, _, (perm, bp) = check_tables(ja, hctx, oracle, g["N"], g["nc"], nblk, reorder)
+    if reorder == "blocks":
+        assert bp[0] == 0 and bp[-1] == g["nc"] and np.all(np.diff(bp) > 0) and np.diff(bp).max() <= 80
+
+
+@pytest.mark.parametrize("layout", ["equation_major", "entity_major"])
+def test_scalar_layout_tables_bit_exact(ja, hctx, oracle, layout):
+    g = ja.tet_lattice_mesh(5, 4, 3)
+    nc, N = g["nc"], 2
+    disc, h, (orp, oci), _ = check_tables(ja, hctx, oracle, g["N"], nc, N, "blocks")
+    lay = oracle.LAYOUT[layout]
+    srp, sci = oracle.csr_pattern_scalar(nc, N, lay, orp, oci)
+    rp, ci = disc.pattern_layout(layout)
+    assert np.array_equal(rp, srp) and np.array_equal(ci, sci)
+    opa, opf = oracle.align(nc, N, lay, orp, oci, h, srp, sci)
+    pa, pf = disc.jacobian_positions_layout(layout)
+    assert np.array_equal(pa, opa) and np.array_equal(pf, opf)
+
+
+def test_pico_fixture_random_graphs_and_multigraphs(ja, hctx, oracle, golden):
+    N = golden["pico"]["N"]
+    check_tables(ja, hctx, oracle, N, 9, 1, "none")
+    rng = np.random.default_rng(5)
+    for nc, nf in [(40, 90), (200, 700), (17, 16)]:
+        a = rng.integers(1, nc + 1, size=3 * nf)
+        b = rng.integers(1, nc + 1, size=3 * nf)
+        keep = a != b
+        key = np.minimum(a, b) * (nc + 1) + np.maximum(a, b)
+        _, first = np.unique(key[keep], return_index=True)
+        N = np.stack([a[keep][np.sort(first)], b[keep][np.sort(first)]])[:, :nf]
+        for reorder in ("none", "blocks"):
+            check_tables(ja, hctx, oracle, N, nc, 1, reorder, block_rows=16)
+    d = ja.TwoPointPotentialFlowHardCoded(hctx, np.array([[1, 1], [2, 2]]), 2)  # duplicate pair: a multigraph, accepted like the reference does
+    assert d.nnzb == 4 and d.nhf == 4
+    with pytest.raises(ja.JutulHIPError):
+        ja.TwoPointPotentialFlowHardCoded(hctx, np.array([[1], [5]]), 3)
+    with pytest.raises(ja.JutulHIPError):
+        ja.TwoPointPotentialFlowHardCoded(hctx, np.array([[1], [1]]), 2)
+
+
+@pytest.mark.parametrize("family", ["delaunay", "polyhedral", "cartesian"])
+def test_unstructured_families_tables_and_block_partition(ja, hctx, oracle, family):
+    g = {"delaunay": lambda: ja.delaunay_tet_mesh(1500, grading=2.0),
+         "polyhedral": lambda: ja.polyhedral_dual_mesh(1500, grading=1.5),
+         "cartesian": lambda: ja.cartesian_mesh(14, 13, 12)}[family]()
+    nc = g["nc"]
+    disc, h, (orp, oci), (perm, bp) = check_tables(ja, hctx, oracle, g["N"], nc, 1, "blocks", block_rows=128, weights=g["T"])
+    sizes = np.diff(bp)
+    assert sizes.min() >= 1 and sizes.max() <= 144          # the bisection's size cap: block_rows * 9 / 8
+    # ILU(0) symbolic phase on the device blocks: the entries it keeps are exactly the in-block couplings of the oracle's pattern
+    A = ja.StaticSparsityMatrixCSR(disc)
+    prec = ja.ILUZeroPreconditioner(partition="blocks").symbolic(A)
+    fi = prec.info()
+    blk_of_host = np.empty(nc, dtype=np.int64)
+    blk_of_host[perm - 1] = np.repeat(np.arange(sizes.size), sizes)
+    rows = np.repeat(np.arange(nc), np.diff(orp))
+    cols = oci - 1
+    same = blk_of_host[rows] == blk_of_host[cols]
+    assert fi["nblocks"] == sizes.size and fi["max_block_rows"] == sizes.max()
+    assert fi["l_entries"] + fi["u_entries"] == int(np.count_nonzero(same & (rows != cols)))
+    assert fi["l_entries"] == fi["u_entries"]               # structurally symmetric pattern
+
+
+def test_weighted_blocks_cut_less_coupling_weight(ja, hctx):
+    """jh_tpfa_create_weighted (partitioning.jl:64-78: Metis on the |A|-weighted graph): the blocks cut less coupling WEIGHT than
+    the unweighted ones on a grid whose transmissibilities vary."""
+    g = ja.tet_lattice_mesh(16, 15, 14)
+    nc, N, T = g["nc"], g["N"], g["T"]
+
+    def cut_weight(weights):
+        d = ja.TwoPointPotentialFlowHardCoded(hctx, N, nc, reorder="blocks", block_rows=128, face_weights=weights)
+        perm, bp = d.ordering()
+        blk = np.empty(nc, dtype=np.int64)
+        blk[perm - 1] = np.repeat(np.arange(bp.size - 1), np.diff(bp))
+        cut = blk[N[0] - 1] != blk[N[1] - 1]
+        return T[cut].sum() / T.sum()
+
+    assert cut_weight(T) < 0.9 * cut_weight(None)
+
+
+def test_set_up_does_not_depend_on_the_thread_count(ja):
+    """The set-up runs on all host cores; nothing it produces may depend on the thread timing or count."""
+    code = r"""
+import sys, zlib, numpy as np
+sys.path.insert(0, %r)
+import jutul_amd as ja
+ctx = ja.HIPContext("host")
+g = ja.tet_lattice_mesh(22, 21, 20, scramble=True)
+d = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], g["nc"], reorder="blocks", block_rows=256, face_weights=g["T"])
+perm, bp = d.ordering()
+rp, ci = d.pattern()
+pa, pf = d.jacobian_positions()
+A = ja.StaticSparsityMatrixCSR(d)
+fi = ja.ILUZeroPreconditioner(partition="blocks").symbolic(A).info()
+h = 0
+for a in (perm, bp, rp, ci, pa, pf):
+    h = zlib.crc32(np.ascontiguousarray(a).tobytes(), h)
+print(h, fi["nblocks"], fi["max_levels"], fi["l_entries"], A.spmv_info()["slices"])
+""" % ROOT
+    outs = []
+    for threads in ("1", "3", "8"):
+        env = dict(os.environ, JH_SETUP_THREADS=threads)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip())
+    assert outs[0] and outs[0] == outs[1] == outs[2], outs
+
+
+def test_planning_context_refuses_every_compute_path(ja, hctx):
+    g = ja.tet_lattice_mesh(3, 3, 2)
+    disc = ja.TwoPointPotentialFlowHardCoded(hctx, g["N"], g["nc"], reorder="blocks", block_rows=32)
+    A = ja.StaticSparsityMatrixCSR(disc)
+    prec = ja.ILUZeroPreconditioner(partition="blocks").symbolic(A)
+    for call in (lambda: ja.ConservationLaw(disc, "poisson"),
+                 lambda: ja.DeviceVector(disc),
+                 lambda: A.new_vector(),
+                 lambda: ja.LinearizedSystem(disc),
+                 lambda: prec.update_preconditioner(A),
+                 lambda: prec.factor_values(),
+                 lambda: setattr(A, "nzval", np.ones(disc.nnzb)),
+                 lambda: A.set_nzval_layout(np.ones(disc.nnzb), "block_major"),
+                 lambda: ja.mul_(None, A, None) if False else ja.StaticSparsityMatrixCSR(context=hctx, n=2, bs=1, rowptr=[1, 2, 3], colidx=[1, 2], nzval=[1.0, 1.0]).nzval,
+                 lambda: A.nzval,
+                 lambda: hctx.synchronize(),
+                 lambda: hctx.timer_start(),
+                 lambda: hctx.set_cu_mask(0, 8),
+                 lambda: hctx.comm_init_ipc_only(1, 0),
+                 lambda: ja.GenericKrylov("bicgstab", preconditioner=prec)._workspace(A)):
+        with pytest.raises(ja.JutulHIPError, match="no device|not factored"):
+            call()

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Times the host set-up of the library on a box WITHOUT a GPU, through a planning context (jh_context_create_host): device
+ordering (weighted bisection), CSR pattern, tiles, jagged-slice layout, ILU(0) symbolic phase and layouts -- everything
+`bench.py` reports as setup_s except the uploads.  Phases are printed by the library itself (option setup_timing = 1).
+
+    python tools/setup_probe.py --cells 10000000 [--law twophase] [--mesh lattice|cartesian|delaunay|polyhedral] [--threads 16]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cells", type=int, default=10_000_000)
+    ap.add_argument("--mesh", default="lattice")
+    ap.add_argument("--law", default="poisson")
+    ap.add_argument("--grading", type=float, default=3.0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--no-timing", action="store_true")
+    args = ap.parse_args()
+    if args.threads:
+        os.environ["JH_SETUP_THREADS"] = str(args.threads)
+    import bench
+    import jutul_amd as ja
+    t0 = time.time()
+    mesh, desc = bench.make_mesh(ja, args, args.cells)
+    print(f"mesh: {desc}, nc={mesh['nc']} nf={mesh['nf']} in {time.time() - t0:.2f} s", flush=True)
+    N = 2 if args.law == "twophase" else 1
+    for rep in range(args.repeat):
+        ctx = ja.HIPContext("host", setup_timing=0 if args.no_timing else 1)
+        t0 = time.time()
+        disc = ja.TwoPointPotentialFlowHardCoded(ctx, mesh["N"], mesh["nc"], block_n=N, reorder="blocks", face_weights=mesh["T"])
+        t1 = time.time()
+        A = ja.StaticSparsityMatrixCSR(disc)
+        info = A.spmv_info()
+        t2 = time.time()
+        prec = ja.ILUZeroPreconditioner(partition="blocks")
+        prec.symbolic(A)
+        t3 = time.time()
+        print(f"[probe] discretisation {t1 - t0:.3f} s   jagged layout {t2 - t1:.3f} s   ilu symbolic {t3 - t2:.3f} s   total {t3 - t0:.3f} s"
+              f"   (spmv_info {info}, ilu {prec.info()})", flush=True)
+        del prec, A, disc, ctx
+
+
+if __name__ == "__main__":
+    main()
