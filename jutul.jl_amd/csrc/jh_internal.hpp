@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <exception>
 #include <memory>
+#include <atomic>
 #include <thread>
 #include <stdexcept>
 #include <string>
@@ -81,6 +82,104 @@ static inline void parallel_ranges(int64_t n, int64_t min_per_thread, F &&fn) {
     });
   for (auto &x : th) x.join();
   for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+
+// fn(t, nt) on exactly nt threads (the caller is thread 0); exceptions are rethrown on the caller
+template <class F>
+static inline void parallel_team(int nt, F &&fn) {
+  if (nt <= 1) { fn(0, 1); return; }
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err((size_t)nt);
+  for (int t = 1; t < nt; ++t)
+    th.emplace_back([&, t] {
+      try { fn(t, nt); } catch (...) { err[(size_t)t] = std::current_exception(); }
+    });
+  try { fn(0, nt); } catch (...) { err[0] = std::current_exception(); }
+  for (auto &x : th) x.join();
+  for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+// Barrier of a parallel_team: spins briefly, then yields (the team may share cores with other set-up threads)
+struct TeamBarrier {
+  const int nt;
+  std::atomic<int> count{0};
+  std::atomic<int> phase{0};
+  explicit TeamBarrier(int n) : nt(n) {}
+  void wait() {
+    const int ph = phase.load(std::memory_order_acquire);
+    if (count.fetch_add(1, std::memory_order_acq_rel) == nt - 1) {
+      count.store(0, std::memory_order_relaxed);
+      phase.store(ph + 1, std::memory_order_release);
+      return;
+    }
+    for (int spins = 0; phase.load(std::memory_order_acquire) == ph; ++spins) {
+      if (spins < 2000) __builtin_ia32_pause();
+      else std::this_thread::yield();
+    }
+  }
+};
+
+// ---- level-synchronous breadth-first search on a team of host threads, in the SERIAL queue order -------------------------------
+// Continues the search whose queue is o[head, tail) (one complete level) until it dies out and returns the new tail.  The order
+// written to o[] is exactly what the serial loop
+//     for (; head < tail; ++head) for (k over the neighbours w of o[head]) if (accept(w) && mark[w] != st) { mark[w] = st; o[tail++] = w; }
+// produces, for any thread count: while a level is expanded, mark[w] = -(i + 1) is the claim of frontier position i on the
+// unvisited w and the smallest position wins -- the vertex the serial search discovers w from -- then every thread emits the
+// claims it placed that still hold, in position and neighbour order, and the threads' lists are concatenated in thread order.
+// mark[w] == st means visited; stamps are positive, claims negative, any other value counts as unvisited.  levels (optional):
+// the queue position where every level starts is appended.  Nothing else may write mark[] of accepted vertices meanwhile.
+template <class Accept>
+static inline int64_t bfs_parallel(const int64_t *ptr, const int32_t *nbr, int32_t *mark, int32_t st, int32_t *o, int64_t head, int64_t tail,
+                                   int nt, Accept accept, std::vector<int64_t> *levels) {
+  nt = std::max(1, std::min(nt, 64));
+  TeamBarrier bar(nt);
+  std::vector<int64_t> cnt((size_t)nt * 8, 0);  // (one cache line per thread)
+  int64_t head_out = head, tail_out = tail;
+  parallel_team(nt, [&](int t, int) {
+    std::vector<int32_t> buf;
+    std::vector<std::pair<int32_t, int32_t>> claimed;  // (claim, vertex) of every claim this thread placed, in serial order
+    int64_t h = head, tl = tail;
+    while (h < tl) {
+      if (t == 0 && levels) levels->push_back(h);
+      const int64_t F = tl - h, i0 = h + F * t / nt, i1 = h + F * (t + 1) / nt;
+      claimed.clear();
+      for (int64_t i = i0; i < i1; ++i) {  // claims
+        // the queue runs ahead of the random accesses (input numberings may be arbitrary: every access a cache miss)
+        if (i + 8 < i1) __builtin_prefetch(&ptr[o[i + 8]]);
+        if (i + 4 < i1) __builtin_prefetch(&nbr[ptr[o[i + 4]]]);
+        if (i + 2 < i1) { const int32_t v2 = o[i + 2]; for (int64_t k = ptr[v2]; k < ptr[v2 + 1]; ++k) __builtin_prefetch(&mark[nbr[k]]); }
+        const int32_t v = o[i], mine = -(int32_t)(i - h) - 1;
+        for (int64_t k = ptr[v]; k < ptr[v + 1]; ++k) {
+          const int32_t w = nbr[k];
+          if (!accept(w)) continue;
+          int32_t m = __atomic_load_n(&mark[w], __ATOMIC_RELAXED);
+          while (m != st && !(m < 0 && m >= mine)) {
+            if (__atomic_compare_exchange_n(&mark[w], &m, mine, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+              claimed.emplace_back(mine, w);
+              break;
+            }
+          }
+        }
+      }
+      bar.wait();
+      buf.clear();
+      for (const auto &cw : claimed)  // the claims that held: discovered from this position, in position and neighbour order
+        if (__atomic_load_n(&mark[cw.second], __ATOMIC_RELAXED) == cw.first) {
+          __atomic_store_n(&mark[cw.second], st, __ATOMIC_RELAXED);
+          buf.push_back(cw.second);
+        }
+      cnt[(size_t)t * 8] = (int64_t)buf.size();
+      bar.wait();
+      int64_t off = 0, total = 0;
+      for (int u = 0; u < nt; ++u) { if (u == t) off = total; total += cnt[(size_t)u * 8]; }
+      std::copy(buf.begin(), buf.end(), o + tl + off);
+      bar.wait();  // (cnt[] is written again only behind the next level's first barrier)
+      h = tl;
+      tl += total;
+    }
+    if (t == 0) { head_out = h; tail_out = tl; }
+  });
+  (void)head_out;
+  return tail_out;
 }
 
 // Pacing of the health checks inside a host spin on pinned memory: due() is true once every `period_ms` of waiting.  The check

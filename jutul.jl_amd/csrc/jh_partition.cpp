@@ -27,6 +27,7 @@ struct Job {
   int64_t k = 1;
   int64_t off = 0, n = 0;  // the job's cells: cells[off .. off + n) of the shared list (children split their parent's segment)
   int32_t start = -1;      // a cell on the job's rim if one is known (an end of the parent's sweep), else -1
+  int par = 1;             // host threads this job may use for its own sweeps (the top of the tree has fewer jobs than threads)
 };
 
 struct Bisector {
@@ -39,6 +40,7 @@ struct Bisector {
   double imbalance;
   int64_t max_part;
   static constexpr int64_t hint_min = 65536;  // jobs above this size are shared between the threads, see partition_bisect
+  static constexpr int64_t par_min = 1 << 17;  // sweeps over at least this many cells run on the job's own team of threads
   Bisector(const PGraph &g, std::vector<int32_t> &lab, std::vector<int32_t> &&c, double imb, int64_t mp)
       : G(g), label(lab), cells(std::move(c)), imbalance(imb), max_part(mp) {
     resize_parallel(order, cells.size());
@@ -58,8 +60,9 @@ struct Bisector {
   // last cell reached from the first start (a far end of that piece).  levels (optional): the positions in o[] where a
   // breadth-first level begins.
   // dmode 1: dkey[v] = level of v; 2: dkey[v] -= level of v (after a mode-1 sweep from the other end: distance difference).
+  // par > 1 (large jobs, dmode 0): the first piece is swept by a team of threads -- same order (bfs_parallel).
   int32_t bfs_order(int32_t lab, const int32_t *c, int64_t n, int32_t start, int32_t *o, std::vector<int64_t> *levels = nullptr,
-                    int dmode = 0) {
+                    int dmode = 0, int par = 1) {
     const int32_t st = ++stamp;
     if (levels) levels->clear();
     int32_t far = start, s = start;
@@ -75,6 +78,11 @@ struct Bisector {
       int64_t head = tail, level_end = head;
       mark[s] = st;
       o[tail++] = s;
+      if (first && par > 1 && dmode == 0 && n >= par_min) {
+        tail = bfs_parallel(G.ptr, G.nbr, mark.data(), st, o, head, tail, par,
+                            [&](int32_t w) { return w < G.n && lab_of(w) == lab; }, levels);
+        head = tail;
+      }
       while (head < tail) {
         if (head == level_end) {
           if (levels) levels->push_back(head);
@@ -195,7 +203,8 @@ struct Bisector {
     // take the first sweep)
     std::vector<int64_t> levels;
     int32_t far = job.start;
-    if (far < 0 || n <= hint_min || lab_of(far) != la) far = bfs_order(la, c, n, c[0], o);
+    const int par = n >= par_min ? job.par : 1;
+    if (far < 0 || n <= hint_min || lab_of(far) != la) far = bfs_order(la, c, n, c[0], o, nullptr, 0, par);
     int64_t na, nb, lo, hi;
     // Small jobs only: they make the final shapes (the cut area doubles with every level) and cost nothing extra in wall
     // time, the large jobs at the top are the serial part of the run.  Cut on the 2M-cell lattice 13.6 % -> 13.1 %; BiCGStab
@@ -222,14 +231,16 @@ struct Bisector {
       lo = levels[std::max<int64_t>(0, lv - 2)];
       hi = lv + 3 < (int64_t)levels.size() ? levels[lv + 3] : n;
     } else {
-      bfs_order(la, c, n, far, o, &levels);
+      bfs_order(la, c, n, far, o, &levels, 0, par);
       // neighbours are at most one breadth-first level apart: the cut lies inside the level of position target_a and its two
       // neighbours
       const int64_t lv = (int64_t)(std::upper_bound(levels.begin(), levels.end(), target_a) - levels.begin()) - 1;  // level of o[target_a]
       lo = levels[std::max<int64_t>(0, lv - 1)];
       hi = lv + 2 < (int64_t)levels.size() ? levels[lv + 2] : n;
     }
-    for (int64_t i = target_a; i < n; ++i) set_lab(o[i], lb);
+    parallel_team(par, [&](int t, int nt) {
+      for (int64_t i = target_a + (n - target_a) * t / nt, e = target_a + (n - target_a) * (t + 1) / nt; i < e; ++i) set_lab(o[i], lb);
+    });
     na = target_a;
     nb = n - target_a;
     const int64_t max_a = std::min(cap_a, target_a + (int64_t)std::floor(imbalance * (double)target_a));
@@ -238,15 +249,87 @@ struct Bisector {
     if (na < k1 || nb < k2) JH_THROW("partitioner lost a part (internal error)");
     // the children split the segment and keep the breadth-first order
     int64_t wa = 0, wb = na;
-    for (int64_t i = 0; i < n; ++i) {
-      const int32_t v = o[i];
-      if (lab_of(v) == la) c[wa++] = v; else c[wb++] = v;
+    if (par > 1) {  // stable two-way split on the job's team: count per range, then fill
+      std::vector<int64_t> cnt_a((size_t)par + 1, 0);
+      TeamBarrier bar(par);
+      parallel_team(par, [&](int t, int nt) {
+        const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
+        int64_t a = 0;
+        for (int64_t i = i0; i < i1; ++i) a += lab_of(o[i]) == la;
+        cnt_a[(size_t)t + 1] = a;
+        bar.wait();
+        int64_t pa = 0;
+        for (int u = 0; u < t; ++u) pa += cnt_a[(size_t)u + 1];
+        int64_t pb = na + (i0 - pa);
+        for (int64_t i = i0; i < i1; ++i) {
+          const int32_t v = o[i];
+          if (lab_of(v) == la) c[pa++] = v; else c[pb++] = v;
+        }
+      });
+      for (int u = 0; u < par; ++u) wa += cnt_a[(size_t)u + 1];
+      wb = n - wa + na;
+    } else {
+      for (int64_t i = 0; i < n; ++i) {
+        const int32_t v = o[i];
+        if (lab_of(v) == la) c[wa++] = v; else c[wb++] = v;
+      }
     }
     if (wa != na || wb != n) JH_THROW("partitioner: side counts are inconsistent (internal error)");
     A.lab = la; A.k = k1; A.off = job.off; A.n = na;
     B.lab = lb; B.k = k2; B.off = job.off + na; B.n = nb;
+    A.par = B.par = std::max(1, job.par / 2);
     A.start = lab_of(o[0]) == la ? o[0] : -1;  // where this sweep began / ended, unless the refinement moved the cell across
     B.start = lab_of(o[n - 1]) == lb ? o[n - 1] : -1;
+  }
+
+  // A job of at most hint_min cells is finished on a private copy of its subgraph: local ids 0 .. n-1 in the order of the global
+  // ids (every comparison between cells -- the priority queue's tie-break -- comes out the same), the cell list, the neighbour
+  // order and the label values as they are, so the parts are those the shared arrays would give; but label / mark / locked / dkey
+  // and the adjacency of 64k cells stay in the thread's cache instead of being scattered over the arrays of the whole graph
+  // (10M cells, 19 582 parts, one thread of the build box: 14.1-15.2 -> 13.5 s; the parts are bit-identical).
+  void finish_locally(const Job &job) {
+    const int64_t n = job.n;
+    const int32_t *c = cells.data() + job.off;
+    std::vector<int32_t> ids(c, c + n);
+    std::sort(ids.begin(), ids.end());
+    for (int64_t i = 0; i < n; ++i) dkey[ids[i]] = (int32_t)i;  // (dkey of the job's own cells: nobody else reads or writes it)
+    std::vector<int64_t> lptr((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t v = ids[i];
+      int64_t d = 0;
+      for (int64_t k = G.ptr[v]; k < G.ptr[v + 1]; ++k) { const int32_t w = G.nbr[k]; d += w < G.n && lab_of(w) == job.lab; }
+      lptr[i + 1] = lptr[i] + d;
+    }
+    std::vector<int32_t> lnbr((size_t)lptr[n]);
+    std::vector<double> lw(G.w ? (size_t)lptr[n] : 0);
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t v = ids[i];
+      int64_t p = lptr[i];
+      for (int64_t k = G.ptr[v]; k < G.ptr[v + 1]; ++k) {
+        const int32_t w = G.nbr[k];
+        if (w < G.n && lab_of(w) == job.lab) { if (G.w) lw[p] = G.w[k]; lnbr[p++] = dkey[w]; }
+      }
+    }
+    std::vector<int32_t> llab((size_t)n, job.lab), lcells((size_t)n);
+    for (int64_t i = 0; i < n; ++i) lcells[i] = dkey[c[i]];
+    const PGraph L{n, lptr.data(), lnbr.data(), G.w ? lw.data() : nullptr};
+    Bisector sub(L, llab, std::move(lcells), imbalance, max_part);
+    std::vector<Job> todo;
+    Job root = job;
+    root.off = 0;
+    root.start = -1;  // (jobs of this size look for their far end themselves)
+    root.par = 1;
+    todo.push_back(root);
+    while (!todo.empty()) {
+      const Job cur = todo.back();
+      todo.pop_back();
+      if (cur.k <= 1) continue;
+      Job A, B;
+      sub.split(cur, A, B);
+      todo.push_back(A);
+      todo.push_back(B);
+    }
+    for (int64_t i = 0; i < n; ++i) set_lab(ids[i], llab[i]);
   }
 };
 
@@ -277,6 +360,7 @@ void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t npa
   int nt = (int)setup_cores();  // hardware threads, capped by the cgroup CPU quota
   if (const char *e = getenv("JH_SETUP_THREADS")) nt = atoi(e);
   nt = std::max(1, std::min(nt, 64));
+  queue[0].par = nt;  // the root job sweeps on all threads, its children on half of them each, ...
   auto worker = [&] {
     for (;;) {
       Job job;
@@ -298,6 +382,7 @@ void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t npa
           const Job cur = local.back();
           local.pop_back();
           if (cur.k <= 1) continue;
+          if (cur.n <= Bisector::hint_min) { bis.finish_locally(cur); continue; }
           Job A, B;
           bis.split(cur, A, B);
           if (cur.n > Bisector::hint_min && nt > 1) {

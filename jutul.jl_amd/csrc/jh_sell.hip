@@ -39,44 +39,61 @@ void Pattern::build_jagged() {
   // the few outside go to a per-slice list
   std::vector<uint16_t> jc16(nnzb + 64, 0);
   std::vector<int32_t> win((size_t)ns * 2, 0), far;
-  int64_t pos = 0;
-  int lanes[64];
-  for (int32_t s = 0; s < ns; ++s) {
-    const int64_t r0 = (int64_t)s * 64;
-    const int64_t cb = r0 - JDS_BACK;
-    const size_t far0 = far.size();
-    win[(size_t)s * 2] = (int32_t)cb;
-    win[(size_t)s * 2 + 1] = (int32_t)far0;
-    const int nr = (int)std::min<int64_t>(64, n - r0);
-    std::iota(lanes, lanes + nr, 0);
-    std::stable_sort(lanes, lanes + nr, [&](int a, int b) {
-      return rowptr[r0 + a + 1] - rowptr[r0 + a] > rowptr[r0 + b + 1] - rowptr[r0 + b];
-    });
-    base[s] = (int32_t)pos;
-    for (int l = 0; l < nr; ++l) perm[(size_t)s * 64 + l] = (uint8_t)lanes[l];
-    for (int j = 0; j < kmax; ++j) {
-      int c = 0;
-      for (int l = 0; l < nr; ++l) {
-        const int64_t row = r0 + lanes[l];
-        if (rowptr[row + 1] - rowptr[row] > j) {
-          const int32_t cj = col[rowptr[row] + j];
-          jc[pos] = cj;
-          if (cj >= cb && cj - cb < JDS_FAR) {
-            jc16[pos] = (uint16_t)(cj - cb);
+  // Slices are independent (no padding: slice s starts at entry rowptr[64 s]); only the lists of far columns are appended in slice
+  // order -- every range of slices collects its own and the ranges are concatenated in order afterwards.  All host cores.
+  struct FarPart { int64_t s0, s1; std::vector<int32_t> far; };
+  std::vector<FarPart> parts;
+  std::mutex parts_m;
+  parallel_ranges(ns, 2048, [&](int64_t s_begin, int64_t s_end) {
+    FarPart P{s_begin, s_end, {}};
+    int lanes[64];
+    for (int64_t s = s_begin; s < s_end; ++s) {
+      const int64_t r0 = s * 64;
+      const int64_t cb = r0 - JDS_BACK;
+      const size_t far0 = P.far.size();
+      win[(size_t)s * 2] = (int32_t)cb;
+      win[(size_t)s * 2 + 1] = (int32_t)far0;  // (relative to the range's list until the lists are joined)
+      const int nr = (int)std::min<int64_t>(64, n - r0);
+      std::iota(lanes, lanes + nr, 0);
+      std::stable_sort(lanes, lanes + nr, [&](int a, int b) {
+        return rowptr[r0 + a + 1] - rowptr[r0 + a] > rowptr[r0 + b + 1] - rowptr[r0 + b];
+      });
+      int64_t pos = rowptr[r0];
+      base[s] = (int32_t)pos;
+      for (int l = 0; l < nr; ++l) perm[(size_t)s * 64 + l] = (uint8_t)lanes[l];
+      for (int j = 0; j < kmax; ++j) {
+        int c = 0;
+        for (int l = 0; l < nr; ++l) {
+          const int64_t row = r0 + lanes[l];
+          if (rowptr[row + 1] - rowptr[row] > j) {
+            const int32_t cj = col[rowptr[row] + j];
+            jc[pos] = cj;
+            if (cj >= cb && cj - cb < JDS_FAR) {
+              jc16[pos] = (uint16_t)(cj - cb);
+            } else {
+              jc16[pos] = (uint16_t)(JDS_FAR + (P.far.size() - far0));  // (a slice has at most 512 entries)
+              P.far.push_back(cj);
+            }
+            src[pos] = (uint16_t)(rowptr[row] + j - rowptr[r0]);
+            ++pos;
+            ++c;
           } else {
-            jc16[pos] = (uint16_t)(JDS_FAR + (far.size() - far0));  // (a slice has at most 512 entries)
-            far.push_back(cj);
+            break;  // sorted by length: no later lane has a j-th entry either
           }
-          src[pos] = (uint16_t)(rowptr[row] + j - rowptr[r0]);
-          ++pos;
-          ++c;
-        } else {
-          break;  // sorted by length: no later lane has a j-th entry either
         }
+        cnt[(size_t)s * 16 + j] = (uint8_t)c;
       }
-      cnt[(size_t)s * 16 + j] = (uint8_t)c;
     }
+    std::lock_guard<std::mutex> lk(parts_m);
+    parts.push_back(std::move(P));
+  });
+  std::sort(parts.begin(), parts.end(), [](const FarPart &a, const FarPart &b) { return a.s0 < b.s0; });
+  for (const FarPart &P : parts) {
+    const int32_t off = (int32_t)far.size();
+    if (off) for (int64_t s = P.s0; s < P.s1; ++s) win[(size_t)s * 2 + 1] += off;
+    far.insert(far.end(), P.far.begin(), P.far.end());
   }
+  const int64_t pos = rowptr[n];
   base[ns] = (int32_t)pos;
   jag.nslices = ns;
   jag.kmax = kmax;

@@ -192,27 +192,40 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
     // The input numbering may be arbitrary (the bench grid's is scrambled): every sweep of the partitioner would miss the
     // cache on every cell.  One breadth-first renumbering first (neighbours end up close in memory), the bisections run on the
     // renumbered graph of the owned cells, the labels are mapped back.
-    std::vector<int32_t> ord, newid;
-    resize_parallel(ord, (size_t)nc);  // (touches the pages)
-    ord.clear();
+    std::vector<int32_t> ord, newid, seen;
+    resize_parallel(ord, (size_t)nc);
     resize_parallel(newid, (size_t)nc);
-    parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { std::fill(newid.begin() + b, newid.begin() + e, -1); });
+    resize_parallel(seen, (size_t)nc);  // 0: not reached yet, 1: reached (negative while a level is expanded: bfs_parallel)
+    int nt_bfs = (int)setup_cores();
+    if (const char *e = getenv("JH_SETUP_THREADS")) nt_bfs = atoi(e);
+    if (nc < (1 << 17)) nt_bfs = 1;
     int64_t first_piece = 0;  // cells of the first connected piece: its last cell is a far end of the graph
-    for (int64_t s0 = 0; s0 < nc; ++s0) {
-      if (newid[s0] >= 0) continue;
-      newid[s0] = (int32_t)ord.size();
-      ord.push_back((int32_t)s0);
-      for (size_t h = ord.size() - 1; h < ord.size(); ++h) {
-        if (h + 8 < ord.size()) __builtin_prefetch(&A.ptr[ord[h + 8]]);  // the queue runs ahead of the random accesses
-        if (h + 4 < ord.size()) __builtin_prefetch(&A.nbr[A.ptr[ord[h + 4]]]);
-        const int32_t c = ord[h];
-        for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k) {
-          const int32_t o = A.nbr[k];
-          if (o < nc && newid[o] < 0) { newid[o] = (int32_t)ord.size(); ord.push_back(o); }
+    int64_t tail = 0;
+    for (int64_t s0 = 0; s0 < nc && tail < nc; ++s0) {
+      if (seen[s0] != 0) continue;
+      seen[s0] = 1;
+      ord[tail] = (int32_t)s0;
+      // the serial queue order on all host cores (pieces past the first one are usually small: bfs_parallel costs them a team
+      // start, so they take the plain loop)
+      if (nt_bfs > 1 && tail == 0) {
+        tail = bfs_parallel(A.ptr.data(), A.nbr.data(), seen.data(), 1, ord.data(), tail, tail + 1, nt_bfs,
+                            [&](int32_t o) { return o < nc; }, nullptr);
+      } else {
+        int64_t h = tail++;
+        for (; h < tail; ++h) {
+          if (h + 8 < tail) __builtin_prefetch(&A.ptr[ord[h + 8]]);  // the queue runs ahead of the random accesses
+          if (h + 4 < tail) __builtin_prefetch(&A.nbr[A.ptr[ord[h + 4]]]);
+          const int32_t c = ord[h];
+          for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k) {
+            const int32_t o = A.nbr[k];
+            if (o < nc && seen[o] == 0) { seen[o] = 1; ord[tail++] = o; }
+          }
         }
       }
-      if (s0 == 0) first_piece = (int64_t)ord.size();
+      if (s0 == 0) first_piece = tail;
     }
+    parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) newid[ord[i]] = (int32_t)i; });
+    { std::vector<int32_t>().swap(seen); }
     pt.lap("  blocks: renumber");
     std::vector<int64_t> ptr2;
     resize_parallel(ptr2, (size_t)nc + 1);

@@ -174,3 +174,16 @@ def test_planning_context_refuses_every_compute_path(ja, hctx):
                  lambda: ja.GenericKrylov("bicgstab", preconditioner=prec)._workspace(A)):
         with pytest.raises(ja.JutulHIPError, match="no device|not factored"):
             call()
+
+
+def test_device_ordering_is_the_pinned_one(ja, hctx):
+    """tests/golden/ordering_crc.json (make_ordering_crc.py): the set-up code may be re-threaded or restructured, the blocks it cuts
+    -- hence every iteration count measured on the GPU -- stay what they were."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("make_ordering_crc", os.path.join(ROOT, "tests", "golden", "make_ordering_crc.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pinned = json.load(open(os.path.join(ROOT, "tests", "golden", "ordering_crc.json")))
+    for name, case in mod.cases(ja).items():
+        assert mod.figures(ja, hctx, *case) == pinned[name], name

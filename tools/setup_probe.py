@@ -22,13 +22,22 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--no-timing", action="store_true")
+    ap.add_argument("--cache", default="", help="npz file the generated mesh is kept in between runs (N, T, nc, nf)")
     args = ap.parse_args()
     if args.threads:
         os.environ["JH_SETUP_THREADS"] = str(args.threads)
     import bench
     import jutul_amd as ja
     t0 = time.time()
-    mesh, desc = bench.make_mesh(ja, args, args.cells)
+    if args.cache and os.path.exists(args.cache):
+        import numpy as np
+        z = np.load(args.cache)
+        mesh, desc = dict(N=z["N"], T=z["T"], nc=int(z["nc"]), nf=int(z["nf"])), f"cached {args.cache}"
+    else:
+        mesh, desc = bench.make_mesh(ja, args, args.cells)
+        if args.cache:
+            import numpy as np
+            np.savez(args.cache, N=mesh["N"], T=mesh["T"], nc=mesh["nc"], nf=mesh["nf"])
     print(f"mesh: {desc}, nc={mesh['nc']} nf={mesh['nf']} in {time.time() - t0:.2f} s", flush=True)
     N = 2 if args.law == "twophase" else 1
     for rep in range(args.repeat):
