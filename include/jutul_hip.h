@@ -49,6 +49,10 @@ int32_t jh_context_create(int32_t device_id, jh_context *out);
  * nothing; every entry point that computes refuses it ("this context has no device").  NOT a CPU fallback: it lets a maintainer
  * (and this repository's CPU-only tests) check the set-up tables against Jutul's own and time the set-up on a box without a GPU. */
 int32_t jh_context_create_host(jh_context *out);
+/* Planning contexts with option plan_checksum = 1: a running checksum of every table a real context would have uploaded so far
+ * (pattern, tiles, jagged layouts, ILU(0) levels / maps / programs; in upload order).  Equal checksums = the device would see the
+ * same tables: how this repository shows that work on the set-up code leaves them bit for bit as they were. */
+int32_t jh_context_plan_checksum(jh_context ctx, int64_t *out);
 int32_t jh_context_destroy(jh_context ctx);
 int32_t jh_synchronize(jh_context ctx); /* synchronize(ctx), context.jl:72 */
 /* Named integer options of a context -- the role of the keyword arguments of the reference's contexts and solver set-up
@@ -70,7 +74,7 @@ int32_t jh_synchronize(jh_context ctx); /* synchronize(ctx), context.jl:72 */
  *                            programs, wavefront per row | 0 = thread per row)
  *   asm_pipe (1), asm_pipe2_wgs (0), block_order (0 bisection | 1 onion), block_weights (1: use the face weights of
  *   jh_tpfa_create_weighted | 0: ignore them)
- *   read_sync (0), setup_timing (0), jds_keep (0), upload_bounce (1; process-wide: 0 copies caller arrays straight from their
+ *   read_sync (0), setup_timing (0), plan_checksum (0; planning contexts), jds_keep (0), upload_bounce (1; process-wide: 0 copies caller arrays straight from their
  *   pageable memory instead of through the page-locked bounce buffer)
  *   xrank_consumer (-1 = when jh_comm_set_exclusive declared it | 0 | 1)  several ranks: the dot products of the Krylov loop are
  *                         summed over the ranks inside the consuming kernels and the push-halo hand-shake runs inside the product

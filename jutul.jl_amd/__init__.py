@@ -87,6 +87,12 @@ class HIPContext(_Handle):
         check(_L().jh_context_get_option(self.h, str(key).encode(), C.byref(v)))
         return v.value
 
+    def plan_checksum(self):
+        """Planning contexts with plan_checksum=1: checksum of every table a real context would have uploaded so far."""
+        v = C.c_int64()
+        check(_L().jh_context_plan_checksum(self.h, C.byref(v)))
+        return v.value
+
     def set_cu_mask(self, first_cu, n_cus):
         """Every kernel of the context runs on the compute units [first_cu, first_cu + n_cus) only (several ranks on one GPU with
         compute units of their own); n_cus <= 0 removes the mask.  Before any other object of the context is created."""

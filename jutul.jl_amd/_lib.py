@@ -32,6 +32,7 @@ SIGNATURES = {
     "jh_version": [],
     "jh_context_create": [C.c_int32, C.POINTER(H)],
     "jh_context_create_host": [C.POINTER(H)],
+    "jh_context_plan_checksum": [H, C.POINTER(C.c_int64)],
     "jh_context_destroy": [H],
     "jh_synchronize": [H],
     "jh_context_set_option": [H, C.c_char_p, C.c_int64],

@@ -14,6 +14,7 @@
 
 namespace jh {
 thread_local bool tl_plan_only = false;  // jh_internal.hpp, "PLANNING CONTEXTS"
+thread_local uint64_t *tl_plan_crc = nullptr;
 
 void halo_exchange(jh_tpfa d, double *v, int bs, bool packed = false, bool push = false);
 }
@@ -234,6 +235,13 @@ extern "C" int32_t jh_context_create_host(jh_context *out) {
     c->plan_only = true;
     c->opt.seed_from_env();
     *out = c.release();
+  });
+}
+extern "C" int32_t jh_context_plan_checksum(jh_context ctx, int64_t *out) {
+  return guard([&] {
+    if (!ctx || !out) JH_THROW("null argument");
+    if (!ctx->plan_only) JH_THROW("jh_context_plan_checksum is for planning contexts (jh_context_create_host)");
+    *out = (int64_t)ctx->plan_crc;
   });
 }
 extern "C" int32_t jh_context_destroy(jh_context ctx) {

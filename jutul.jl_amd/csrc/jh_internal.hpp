@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <exception>
 #include <memory>
 #include <atomic>
@@ -253,6 +254,24 @@ void copy_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s);
 // arrays).  There is no CPU compute path behind this: it exists so that the set-up tables can be checked and timed on a box
 // without a GPU (tests -m "not gpu", tools/setup_probe.py).
 extern thread_local bool tl_plan_only;
+// Option plan_checksum = 1: every table a real context would upload is folded into a running 64-bit checksum of the planning
+// context instead (jh_context_plan_checksum) -- in upload order, lengths included -- so that ALL device tables of a set-up
+// (pattern, tiles, jagged layouts, ILU(0) levels / maps / factorisation programs) can be compared between two builds, thread
+// counts or machines without a GPU.
+extern thread_local uint64_t *tl_plan_crc;
+static inline void plan_crc_update(const void *data, size_t bytes) {
+  uint64_t h = *tl_plan_crc ^ (0x9e3779b97f4a7c15ull * (uint64_t)(bytes + 1));
+  const unsigned char *b = (const unsigned char *)data;
+  size_t i = 0;
+  for (; i + 8 <= bytes; i += 8) {
+    uint64_t w;
+    memcpy(&w, b + i, 8);
+    h = (h ^ w) * 0x100000001b3ull;
+    h ^= h >> 29;
+  }
+  for (; i < bytes; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+  *tl_plan_crc = h;
+}
 
 template <class T>
 struct DevBuf {
@@ -274,11 +293,13 @@ struct DevBuf {
   }
   void upload(const T *h, size_t count, hipStream_t s) {
     if (count > n) alloc(count);
-    if (count && !tl_plan_only) jh::copy_h2d(p, h, count * sizeof(T), s);
+    if (tl_plan_only) { if (tl_plan_crc) plan_crc_update(h, count * sizeof(T)); return; }
+    if (count) jh::copy_h2d(p, h, count * sizeof(T), s);
   }
   void upload(const std::vector<T> &h, hipStream_t s) {
     alloc(h.size());
-    if (!h.empty() && !tl_plan_only) jh::copy_h2d(p, h.data(), h.size() * sizeof(T), s);
+    if (tl_plan_only) { if (tl_plan_crc) plan_crc_update(h.data(), h.size() * sizeof(T)); return; }
+    if (!h.empty()) jh::copy_h2d(p, h.data(), h.size() * sizeof(T), s);
   }
   // zero-fill on the stream (nothing to do for a planning context)
   void zero(hipStream_t s) {
@@ -322,6 +343,7 @@ struct Comm;  // RCCL state (jh_comm.cpp)
   X(comm_timeout_ms, 600000)  /* limit of the mailbox / push-halo waits inside kernels, 0 = wait like a collective */          \
   X(upload_bounce, 1)         /* PROCESS-WIDE: caller arrays cross PCIe through the library's page-locked bounce buffer; 0 = straight from the caller's (pageable) memory */ \
   X(setup_timing, 0)          /* print the set-up phases */                                                                    \
+  X(plan_checksum, 0)         /* planning contexts: checksum every table that would be uploaded (jh_context_plan_checksum) */  \
   X(xrank_consumer, -1)       /* several ranks: dots all-reduced inside the consuming kernels + push-halo hand-shake inside the product; -1 = when the host declared exclusive compute units (jh_comm_set_exclusive) */ \
   X(jds_keep, 0)              /* jh_spmv_jagged: do not refresh the jagged copy (timing probe) */
 struct Options {
@@ -421,6 +443,7 @@ struct jh_context_s {
     if (stage.n < n) stage.alloc(n);
   }
   bool plan_only = false;  // jh_context_create_host: no device behind this context (device == -1, no stream)
+  uint64_t plan_crc = 0;   // option plan_checksum: running checksum of everything a real context would have uploaded
 };
 
 namespace jh {
@@ -428,11 +451,12 @@ namespace jh {
 // tl_plan_only until the entry point returns.
 struct DeviceScope {
   bool prev;
-  explicit DeviceScope(jh_context c) : prev(tl_plan_only) {
-    if (c->plan_only) tl_plan_only = true;
+  uint64_t *prev_crc;
+  explicit DeviceScope(jh_context c) : prev(tl_plan_only), prev_crc(tl_plan_crc) {
+    if (c->plan_only) { tl_plan_only = true; tl_plan_crc = c->opt.plan_checksum ? &c->plan_crc : nullptr; }
     else JH_HIP(hipSetDevice(c->device));
   }
-  ~DeviceScope() { tl_plan_only = prev; }
+  ~DeviceScope() { tl_plan_only = prev; tl_plan_crc = prev_crc; }
   DeviceScope(const DeviceScope &) = delete;
   DeviceScope &operator=(const DeviceScope &) = delete;
 };

@@ -81,6 +81,11 @@ function get_option(c::HIPContext, key)
     @jh :jh_context_get_option (Handle, Cstring, Ref{Int64}) c.handle String(key) v
     return v[]
 end
+function plan_checksum(c::HIPContext)   # planning contexts (device < 0) with plan_checksum = 1: checksum of the tables a device would get
+    v = Ref{Int64}(0)
+    @jh :jh_context_plan_checksum (Handle, Ref{Int64}) c.handle v
+    return v[]
+end
 matrix_layout(c::HIPContext) = c.matrix_layout
 float_type(::HIPContext) = Float64          # context.jl:76
 index_type(::HIPContext) = Int64            # context.jl:77 (host side; the device uses 0-based Int32)

@@ -127,12 +127,13 @@ def test_weighted_blocks_cut_less_coupling_weight(ja, hctx):
 
 
 def test_set_up_does_not_depend_on_the_thread_count(ja):
-    """The set-up runs on all host cores; nothing it produces may depend on the thread timing or count."""
+    """The set-up runs on all host cores; nothing it produces may depend on the thread timing or count -- the getters' tables and
+    (plan_checksum) every table the device would be handed: pattern, tiles, jagged layouts, ILU(0) levels, maps and programs."""
     code = r"""
 import sys, zlib, numpy as np
 sys.path.insert(0, %r)
 import jutul_amd as ja
-ctx = ja.HIPContext("host")
+ctx = ja.HIPContext("host", plan_checksum=1)
 g = ja.tet_lattice_mesh(22, 21, 20, scramble=True)
 d = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], g["nc"], reorder="blocks", block_rows=256, face_weights=g["T"])
 perm, bp = d.ordering()
@@ -143,7 +144,13 @@ fi = ja.ILUZeroPreconditioner(partition="blocks").symbolic(A).info()
 h = 0
 for a in (perm, bp, rp, ci, pa, pf):
     h = zlib.crc32(np.ascontiguousarray(a).tobytes(), h)
-print(h, fi["nblocks"], fi["max_levels"], fi["l_entries"], A.spmv_info()["slices"])
+print(h, fi["nblocks"], fi["max_levels"], fi["l_entries"], A.spmv_info()["slices"], ctx.plan_checksum())
+g = ja.polyhedral_dual_mesh(6000, grading=1.5)      # long rows: virtual rows, rows-form factorisation programs
+for bn in (1, 2):
+    d = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], g["nc"], block_n=bn, reorder="blocks", face_weights=g["T"])
+    A = ja.StaticSparsityMatrixCSR(d)
+    ja.ILUZeroPreconditioner(partition="blocks").symbolic(A)
+    print(A.spmv_info()["longest_row"], ctx.plan_checksum())
 """ % ROOT
     outs = []
     for threads in ("1", "3", "8"):
