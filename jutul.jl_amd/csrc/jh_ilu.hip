@@ -2295,6 +2295,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         M->jl_of_old.assign(nlent, -1); M->ju_of_old.assign(nuent, -1); M->jd_of_old.assign(n, -1);
         M->blk_lbase.assign(nb + 1, 0); M->blk_ubase.assign(nb + 1, 0); M->blk_prog.assign(nb + 1, 0);
         for (int64_t b = 0; b <= nb; ++b) { M->blk_lbase[b] = M->l_ptr[M->blk_ptr[b]]; M->blk_ubase[b] = M->u_ptr[M->blk_ptr[b]]; }
+        lap("  jagged: arrays");
         std::vector<std::vector<uint16_t>> progs(nb);  // factorisation program of every block (ilu_factor_prog_kernel)
         // long rows: the rows form of the programs (ilu_factor_rows_kernel; ilu_factor_wave_per_row = 2 keeps the instruction form).
         // Scalar matrices only: the entries of a block of 2x2 cells take 80 KB of LDS, two blocks per CU either way, and the
@@ -2421,6 +2422,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
                                           M->flev_off[b + 1] - M->flev_off[b] - 1, b0, P.bs == 1 ? 8 : (P.bs == 2 ? 4 : 2), progs_rows[b]);
           }
         });
+        lap("  jagged: blocks (layout + programs)");
         {
           bool ok = true;
           int max_vals = 0, max_words = 0;
@@ -2542,6 +2544,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
             M->d_prog.upload(prog, sp);
           }
         }
+        lap("  jagged: program concat");
         M->jl_nent = (int64_t)nlent; M->ju_nent = (int64_t)nuent;
         hipStream_t sj = M->ctx->stream;
         M->d_chunk_ptr.upload(M->chunk_ptr, sj);
