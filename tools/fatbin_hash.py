@@ -5,7 +5,10 @@ compilation unit carries a `__hip_cuid_<hash>` symbol derived from its source pa
 tables.)  Two trees with the same hash run the same kernels -- host-side changes (set-up, bindings, options) do not move it -- so
 measurements committed under profiles/ for one of them hold for the other.
 
-    python tools/fatbin_hash.py [path/to/libjutul_hip.so]
+    python tools/fatbin_hash.py [path/to/libjutul_hip.so]            one hash for the whole library
+    python tools/fatbin_hash.py --kernels [path/to/libjutul_hip.so]  one hash per kernel (mangled names) -- NOT a per-kernel
+        identity test across different trees: kernels address device globals and each other PC-relatively, so a change anywhere in a
+        code object moves the literals of kernels whose source did not change (tried on 3b0db32 vs d92f7eb: 171 of 317 differ)
 """
 import hashlib
 import os
@@ -62,6 +65,36 @@ def code_objects(fatbin):
         pos += 24
 
 
+def kernel_hashes(path):
+    """{mangled kernel name: sha256[:16] of its machine code + kernel descriptor} over all code objects"""
+    out = {}
+    for name, blob in fatbin_sections(path):
+        if name != ".hip_fatbin":
+            continue
+        for _triple, obj in code_objects(blob):
+            shoff = struct.unpack_from("<Q", obj, 0x28)[0]
+            shentsize, shnum, _ = struct.unpack_from("<HHH", obj, 0x3A)
+            secs = [struct.unpack_from("<IIQQQQIIQQ", obj, shoff + i * shentsize) for i in range(shnum)]
+            for _n, stype, _f, _a, off, size, link, _i, _al, entsize in secs:
+                if stype != 2:  # SHT_SYMTAB
+                    continue
+                stroff = secs[link][4]
+                syms = {}
+                for k in range(size // entsize):
+                    st_name, st_info, _o, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", obj, off + k * entsize)
+                    if st_shndx == 0 or st_shndx >= len(secs) or st_size == 0:
+                        continue
+                    end = obj.index(b"\0", stroff + st_name)
+                    nm = obj[stroff + st_name:end].decode()
+                    sec = secs[st_shndx]
+                    syms[nm] = obj[sec[4] + st_value - sec[3]:sec[4] + st_value - sec[3] + st_size]
+                for nm, code in syms.items():
+                    if nm.endswith(".kd") or nm + ".kd" not in syms:
+                        continue  # kernels only: functions that have a kernel descriptor
+                    out[nm] = hashlib.sha256(code + syms[nm + ".kd"]).hexdigest()[:16]
+    return out
+
+
 def device_code_hash(path):
     h = hashlib.sha256()
     n_obj = n_text = 0
@@ -80,7 +113,14 @@ def device_code_hash(path):
 
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "jutul.jl_amd", "libjutul_hip.so")
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    path = args[0] if args else os.path.join(root, "jutul.jl_amd", "libjutul_hip.so")
+    if "--kernels" in sys.argv:
+        path = [a for a in sys.argv[1:] if not a.startswith("--")]
+        path = path[0] if path else os.path.join(root, "jutul.jl_amd", "libjutul_hip.so")
+        for nm, hh in sorted(kernel_hashes(path).items()):
+            print(hh, nm)
+        return
     digest, n_obj, n_text = device_code_hash(path)
     print(f"{digest}  {n_obj} gfx950 code objects, {n_text} bytes of machine code  {path}")
 
