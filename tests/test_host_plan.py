@@ -134,7 +134,7 @@ import sys, zlib, numpy as np
 sys.path.insert(0, %r)
 import jutul_amd as ja
 ctx = ja.HIPContext("host", plan_checksum=1)
-g = ja.tet_lattice_mesh(22, 21, 20, scramble=True)
+g = ja.tet_lattice_mesh(30, 29, 28, scramble=True)   # 146k cells: above the size from which the sweeps run on thread teams
 d = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], g["nc"], reorder="blocks", block_rows=256, face_weights=g["T"])
 perm, bp = d.ordering()
 rp, ci = d.pattern()
