@@ -145,6 +145,12 @@ h = 0
 for a in (perm, bp, rp, ci, pa, pf):
     h = zlib.crc32(np.ascontiguousarray(a).tobytes(), h)
 print(h, fi["nblocks"], fi["max_levels"], fi["l_entries"], A.spmv_info()["slices"], ctx.plan_checksum())
+a, b = ja.tet_lattice_mesh(30, 29, 28, scramble=True), ja.tet_lattice_mesh(19, 18, 17)   # two pieces, no face between them
+N2 = np.concatenate([a["N"], b["N"] + a["nc"], a["N"][:, :500]], axis=1)                  # ... and 500 duplicated faces (multigraph)
+d = ja.TwoPointPotentialFlowHardCoded(ctx, N2, a["nc"] + b["nc"], reorder="blocks", face_weights=np.concatenate([a["T"], b["T"], a["T"][:500]]))
+A = ja.StaticSparsityMatrixCSR(d)
+ja.ILUZeroPreconditioner(partition="blocks").symbolic(A)
+print("two pieces", zlib.crc32(np.ascontiguousarray(d.ordering()[0]).tobytes()), ctx.plan_checksum())
 g = ja.polyhedral_dual_mesh(6000, grading=1.5)      # long rows: virtual rows, rows-form factorisation programs
 for bn in (1, 2):
     d = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], g["nc"], block_n=bn, reorder="blocks", face_weights=g["T"])
