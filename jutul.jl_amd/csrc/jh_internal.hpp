@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <memory>
 #include <atomic>
 #include <thread>
@@ -215,6 +216,9 @@ struct PGraph {
 };
 void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t nparts, double imbalance, int64_t max_part,
                       std::vector<int32_t> &label, int32_t rim_cell);
+void partition_on_bfs_numbering(int64_t nc, const int64_t *ptr, const int32_t *nbr, const double *wk, const int32_t *sface, const double *fw,
+                                int64_t nparts, double imbalance, int64_t max_part, int32_t *label_out,
+                                const std::function<void(const char *)> &lap);
 
 // ---- tiling constants for the CSR row-segment kernels ------------------------------------------------
 // Value of a vector entry that lives either in an LDS window or in global memory.  Two loads -- an LDS read every lane issues and

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <exception>
+#include <functional>
 #include <mutex>
 #include <numeric>
 #include <queue>
@@ -413,6 +414,89 @@ void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t npa
   if (err) std::rethrow_exception(err);
 }
 
+
+// Partition of the vertices 0 .. nc-1 of the graph (ptr, nbr; neighbours >= nc are ignored) into nparts, label_out[v] in 0 .. nparts-1.
+// Weight of adjacency entry k: wk[k], or fw[|sface[k]| - 1] (a weight per face, sface = signed 1-based face id of the entry), or 1.
+// lap(name): called after each phase (set-up timing).
+void partition_on_bfs_numbering(int64_t nc, const int64_t *ptr, const int32_t *nbr, const double *wk, const int32_t *sface, const double *fw,
+                                int64_t nparts, double imbalance, int64_t max_part, int32_t *label_out,
+                                const std::function<void(const char *)> &lap) {
+  const bool weighted = wk || (fw && sface);
+  // The input numbering may be arbitrary (the bench grid's is scrambled): every sweep of the partitioner would miss the
+  // cache on every cell.  One breadth-first renumbering first (neighbours end up close in memory), the bisections run on the
+  // renumbered graph of the owned cells, the labels are mapped back.
+  std::vector<int32_t> ord, newid, seen;
+  resize_parallel(ord, (size_t)nc);
+  resize_parallel(newid, (size_t)nc);
+  resize_parallel(seen, (size_t)nc);  // 0: not reached yet, 1: reached (negative while a level is expanded: bfs_parallel)
+  int nt_bfs = (int)setup_cores();
+  if (const char *e = getenv("JH_SETUP_THREADS")) nt_bfs = atoi(e);
+  if (nc < (1 << 17)) nt_bfs = 1;
+  int64_t first_piece = 0;  // cells of the first connected piece: its last cell is a far end of the graph
+  int64_t tail = 0;
+  for (int64_t s0 = 0; s0 < nc && tail < nc; ++s0) {
+    if (seen[s0] != 0) continue;
+    seen[s0] = 1;
+    ord[tail] = (int32_t)s0;
+    // the serial queue order on all host cores (pieces past the first one are usually small: bfs_parallel costs them a team
+    // start, so they take the plain loop)
+    if (nt_bfs > 1 && tail == 0) {
+      tail = bfs_parallel(ptr, nbr, seen.data(), 1, ord.data(), tail, tail + 1, nt_bfs,
+                          [&](int32_t o) { return o < nc; }, nullptr);
+    } else {
+      int64_t h = tail++;
+      for (; h < tail; ++h) {
+        if (h + 8 < tail) __builtin_prefetch(&ptr[ord[h + 8]]);  // the queue runs ahead of the random accesses
+        if (h + 4 < tail) __builtin_prefetch(&nbr[ptr[ord[h + 4]]]);
+        const int32_t c = ord[h];
+        for (int64_t k = ptr[c]; k < ptr[c + 1]; ++k) {
+          const int32_t o = nbr[k];
+          if (o < nc && seen[o] == 0) { seen[o] = 1; ord[tail++] = o; }
+        }
+      }
+    }
+    if (s0 == 0) first_piece = tail;
+  }
+  parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) newid[ord[i]] = (int32_t)i; });
+  { std::vector<int32_t>().swap(seen); }
+  lap("  blocks: renumber");
+  std::vector<int64_t> ptr2;
+  resize_parallel(ptr2, (size_t)nc + 1);
+  parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
+    for (int64_t i = b; i < e; ++i) {
+      const int32_t c = ord[i];
+      int64_t deg = 0;
+      for (int64_t k = ptr[c]; k < ptr[c + 1]; ++k) deg += nbr[k] < nc;
+      ptr2[i + 1] = deg;
+    }
+  });
+  for (int64_t i = 0; i < nc; ++i) ptr2[i + 1] += ptr2[i];
+  std::vector<int32_t> nbr2;
+  resize_parallel(nbr2, (size_t)ptr2[nc]);
+  std::vector<double> w2;
+  if (weighted) resize_parallel(w2, (size_t)ptr2[nc]);
+  parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
+    for (int64_t i = b; i < e; ++i) {
+      const int32_t c = ord[i];
+      int64_t w = ptr2[i];
+      for (int64_t k = ptr[c]; k < ptr[c + 1]; ++k)
+        if (nbr[k] < nc) {
+          if (weighted) w2[w] = wk ? wk[k] : fw[std::abs(sface[k]) - 1];
+          nbr2[w++] = newid[nbr[k]];
+        }
+    }
+  });
+  std::vector<int32_t> lab2, cells;
+  resize_parallel(lab2, (size_t)nc);
+  resize_parallel(cells, (size_t)nc);
+  parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { std::iota(cells.begin() + b, cells.begin() + e, (int32_t)b); });
+  PGraph G{nc, ptr2.data(), nbr2.data(), weighted ? w2.data() : nullptr};
+  lap("  blocks: graph");
+  partition_bisect(G, std::move(cells), nparts, imbalance, max_part, lab2, (int32_t)(first_piece - 1));
+  lap("  blocks: bisection");
+  parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) label_out[ord[i]] = lab2[i]; });
+}
+
 }  // namespace jh
 
 using namespace jh;
@@ -426,29 +510,60 @@ extern "C" int32_t jh_partition_graph(int64_t nc, int64_t nf, const int64_t *N, 
     if (nparts < 1 || nparts > nc) JH_THROW("nparts must be in 1..nc");
     if (nc > 2000000000LL) JH_THROW("graph too large");
     if (!(imbalance >= 0.0)) imbalance = 0.03;
-    std::vector<int64_t> ptr(nc + 1, 0);
-    for (int64_t f = 0; f < nf; ++f) {
-      const int64_t l = N[2 * f], r = N[2 * f + 1];
-      if (l < 1 || l > nc || r < 1 || r > nc) JH_THROW("neighborship entry out of range (utils.jl:822: max(N) <= nc)");
-      if (l == r) continue;
-      ptr[l]++;
-      ptr[r]++;
-    }
+    // adjacency on all host cores: counts and cursors are bumped atomically, then every row is put back into ascending face order
+    // (what a serial fill produces), so that nothing depends on the thread timing; faces connecting a cell to itself are skipped
+    std::vector<int64_t> ptr;
+    resize_parallel(ptr, (size_t)nc + 1);
+    int64_t *pp = ptr.data();
+    parallel_ranges(nf, 1 << 18, [&](int64_t f0, int64_t f1) {
+      for (int64_t f = f0; f < f1; ++f) {
+        const int64_t l = N[2 * f], r = N[2 * f + 1];
+        if (l < 1 || l > nc || r < 1 || r > nc) JH_THROW("neighborship entry out of range (utils.jl:822: max(N) <= nc)");
+        if (l == r) continue;
+        __atomic_fetch_add(&pp[l], 1, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&pp[r], 1, __ATOMIC_RELAXED);
+      }
+    });
     for (int64_t c = 0; c < nc; ++c) ptr[c + 1] += ptr[c];
-    std::vector<int32_t> nbr(ptr[nc]);
-    std::vector<double> w(face_weights ? ptr[nc] : 0);
-    std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
-    for (int64_t f = 0; f < nf; ++f) {
-      const int64_t l = N[2 * f] - 1, r = N[2 * f + 1] - 1;
-      if (l == r) continue;
-      if (face_weights) { w[cur[l]] = std::fabs(face_weights[f]); w[cur[r]] = std::fabs(face_weights[f]); }
-      nbr[cur[l]++] = (int32_t)r;
-      nbr[cur[r]++] = (int32_t)l;
+    std::vector<int32_t> nbr, face;
+    resize_parallel(nbr, (size_t)ptr[nc]);
+    resize_parallel(face, (size_t)ptr[nc]);
+    std::vector<int64_t> cur;
+    resize_parallel(cur, (size_t)nc);
+    parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { std::copy(ptr.begin() + b, ptr.begin() + e, cur.begin() + b); });
+    int64_t *cu = cur.data();
+    parallel_ranges(nf, 1 << 18, [&](int64_t f0, int64_t f1) {
+      for (int64_t f = f0; f < f1; ++f) {
+        const int64_t l = N[2 * f] - 1, r = N[2 * f + 1] - 1;
+        if (l == r) continue;
+        const int64_t pl = __atomic_fetch_add(&cu[l], 1, __ATOMIC_RELAXED), pr = __atomic_fetch_add(&cu[r], 1, __ATOMIC_RELAXED);
+        nbr[pl] = (int32_t)r; face[pl] = (int32_t)(f + 1);
+        nbr[pr] = (int32_t)l; face[pr] = (int32_t)(f + 1);
+      }
+    });
+    parallel_ranges(nc, 1 << 16, [&](int64_t c0, int64_t c1) {
+      for (int64_t c = c0; c < c1; ++c)
+        for (int64_t i = ptr[c] + 1; i < ptr[c + 1]; ++i) {  // insertion sort by face (rows are short)
+          const int32_t sf = face[i], nb = nbr[i];
+          int64_t j = i;
+          for (; j > ptr[c] && face[j - 1] > sf; --j) { face[j] = face[j - 1]; nbr[j] = nbr[j - 1]; }
+          face[j] = sf;
+          nbr[j] = nb;
+        }
+    });
+    { std::vector<int64_t>().swap(cur); }
+    // |weight| per face; the bisections run on a breadth-first renumbering of the cells (an arbitrary input numbering would miss the
+    // cache on every access of every sweep; build box, 3M scrambled cells, weighted: 8 parts 4.1 -> 2.4 s, 64 parts 4.7 -> 2.4 s, the cut
+    // weight unchanged to four digits)
+    std::vector<double> fw;
+    if (face_weights) {
+      resize_parallel(fw, (size_t)nf);
+      parallel_ranges(nf, 1 << 18, [&](int64_t b, int64_t e) { for (int64_t f = b; f < e; ++f) fw[f] = std::fabs(face_weights[f]); });
     }
-    PGraph G{nc, ptr.data(), nbr.data(), face_weights ? w.data() : nullptr};
-    std::vector<int32_t> label(nc, 0), cells(nc);
-    std::iota(cells.begin(), cells.end(), 0);
-    partition_bisect(G, std::move(cells), nparts, imbalance, 0, label, -1);
+    std::vector<int32_t> label;
+    resize_parallel(label, (size_t)nc);
+    partition_on_bfs_numbering(nc, ptr.data(), nbr.data(), nullptr, face_weights ? face.data() : nullptr, face_weights ? fw.data() : nullptr, nparts,
+                               imbalance, 0, label.data(), [](const char *) {});
     for (int64_t c = 0; c < nc; ++c) out[c] = (int64_t)label[c] + 1;
   });
 }

@@ -188,81 +188,9 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
   resize_parallel(label, A.ptr.size() - 1);
   parallel_ranges((int64_t)label.size(), 1 << 18, [&](int64_t b, int64_t e) { std::fill(label.begin() + b, label.begin() + e, -1); });
   PhaseTimer pt(timing);
-  {
-    // The input numbering may be arbitrary (the bench grid's is scrambled): every sweep of the partitioner would miss the
-    // cache on every cell.  One breadth-first renumbering first (neighbours end up close in memory), the bisections run on the
-    // renumbered graph of the owned cells, the labels are mapped back.
-    std::vector<int32_t> ord, newid, seen;
-    resize_parallel(ord, (size_t)nc);
-    resize_parallel(newid, (size_t)nc);
-    resize_parallel(seen, (size_t)nc);  // 0: not reached yet, 1: reached (negative while a level is expanded: bfs_parallel)
-    int nt_bfs = (int)setup_cores();
-    if (const char *e = getenv("JH_SETUP_THREADS")) nt_bfs = atoi(e);
-    if (nc < (1 << 17)) nt_bfs = 1;
-    int64_t first_piece = 0;  // cells of the first connected piece: its last cell is a far end of the graph
-    int64_t tail = 0;
-    for (int64_t s0 = 0; s0 < nc && tail < nc; ++s0) {
-      if (seen[s0] != 0) continue;
-      seen[s0] = 1;
-      ord[tail] = (int32_t)s0;
-      // the serial queue order on all host cores (pieces past the first one are usually small: bfs_parallel costs them a team
-      // start, so they take the plain loop)
-      if (nt_bfs > 1 && tail == 0) {
-        tail = bfs_parallel(A.ptr.data(), A.nbr.data(), seen.data(), 1, ord.data(), tail, tail + 1, nt_bfs,
-                            [&](int32_t o) { return o < nc; }, nullptr);
-      } else {
-        int64_t h = tail++;
-        for (; h < tail; ++h) {
-          if (h + 8 < tail) __builtin_prefetch(&A.ptr[ord[h + 8]]);  // the queue runs ahead of the random accesses
-          if (h + 4 < tail) __builtin_prefetch(&A.nbr[A.ptr[ord[h + 4]]]);
-          const int32_t c = ord[h];
-          for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k) {
-            const int32_t o = A.nbr[k];
-            if (o < nc && seen[o] == 0) { seen[o] = 1; ord[tail++] = o; }
-          }
-        }
-      }
-      if (s0 == 0) first_piece = tail;
-    }
-    parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) newid[ord[i]] = (int32_t)i; });
-    { std::vector<int32_t>().swap(seen); }
-    pt.lap("  blocks: renumber");
-    std::vector<int64_t> ptr2;
-    resize_parallel(ptr2, (size_t)nc + 1);
-    parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
-      for (int64_t i = b; i < e; ++i) {
-        const int32_t c = ord[i];
-        int64_t deg = 0;
-        for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k) deg += A.nbr[k] < nc;
-        ptr2[i + 1] = deg;
-      }
-    });
-    for (int64_t i = 0; i < nc; ++i) ptr2[i + 1] += ptr2[i];
-    std::vector<int32_t> nbr2;
-    resize_parallel(nbr2, (size_t)ptr2[nc]);
-    std::vector<double> w2;
-    if (fw) resize_parallel(w2, (size_t)ptr2[nc]);
-    parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
-      for (int64_t i = b; i < e; ++i) {
-        const int32_t c = ord[i];
-        int64_t w = ptr2[i];
-        for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k)
-          if (A.nbr[k] < nc) {
-            if (fw) w2[w] = fw[std::abs(A.sface[k]) - 1];
-            nbr2[w++] = newid[A.nbr[k]];
-          }
-      }
-    });
-    std::vector<int32_t> lab2, cells;
-    resize_parallel(lab2, (size_t)nc);
-    resize_parallel(cells, (size_t)nc);
-    parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { std::iota(cells.begin() + b, cells.begin() + e, (int32_t)b); });
-    PGraph G{nc, ptr2.data(), nbr2.data(), fw ? w2.data() : nullptr};
-    pt.lap("  blocks: graph");
-    partition_bisect(G, std::move(cells), nparts, 0.04, max_part, lab2, (int32_t)(first_piece - 1));
-    pt.lap("  blocks: bisection");
-    parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) label[ord[i]] = lab2[i]; });
-  }
+  // (on a breadth-first renumbering of the owned cells: jh_partition.cpp)
+  partition_on_bfs_numbering(nc, A.ptr.data(), A.nbr.data(), nullptr, fw ? A.sface.data() : nullptr, fw, nparts, 0.04, max_part, label.data(),
+                             [&](const char *what) { pt.lap(what); });
   std::vector<int32_t> cnt(nparts + 1, 0);
   for (int64_t c = 0; c < nc; ++c) cnt[label[c] + 1]++;
   block_ptr.assign(nparts + 1, 0);
