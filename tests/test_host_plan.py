@@ -107,6 +107,22 @@ def test_unstructured_families_tables_and_block_partition(ja, hctx, oracle, fami
     assert fi["nblocks"] == sizes.size and fi["max_block_rows"] == sizes.max()
     assert fi["l_entries"] + fi["u_entries"] == int(np.count_nonzero(same & (rows != cols)))
     assert fi["l_entries"] == fi["u_entries"]               # structurally symmetric pattern
+    # dependency levels of the triangular sweeps (ilu0.jl:156-187 in the device's elimination order): the longest chain of in-block
+    # lower (forward) / upper (backward) couplings, restated here from the ordering alone
+    dev_of_host = np.empty(nc, dtype=np.int64)
+    dev_of_host[perm - 1] = np.arange(nc)
+    nbrs = [[] for _ in range(nc)]
+    for r, c, keep in zip(dev_of_host[rows], dev_of_host[cols], same & (rows != cols)):
+        if keep:
+            nbrs[r].append(c)
+    flev, blev = np.zeros(nc, dtype=np.int64), np.zeros(nc, dtype=np.int64)
+    for i in range(nc):
+        lower = [flev[j] for j in nbrs[i] if j < i]
+        flev[i] = 1 + max(lower) if lower else 0
+    for i in range(nc - 1, -1, -1):
+        upper = [blev[j] for j in nbrs[i] if j > i]
+        blev[i] = 1 + max(upper) if upper else 0
+    assert fi["max_levels"] == 1 + max(flev.max(), blev.max())
 
 
 def test_weighted_blocks_cut_less_coupling_weight(ja, hctx):
