@@ -45,7 +45,8 @@ int32_t jh_context_create(int32_t device_id, jh_context *out);
 /* A PLANNING context: no device behind it.  The set-up entry points run their host phases on it -- jh_tpfa_create(_weighted)
  * and every jh_tpfa_get_* table getter (a-1 .. a-4: the tables setup_equation_storage builds on the host,
  * conservation/conservation.jl:101-216), jh_csr_create / jh_csr_create_from_pattern (pattern only), jh_spmv_info (jagged layout),
- * jh_ilu0_create + jh_ilu0_info / jh_ilu0_stats (the symbolic phase of ilu0_csr, StaticCSR/ilu0.jl:13-81) -- and allocate or upload
+ * jh_ilu0_create + jh_ilu0_info / jh_ilu0_stats (the symbolic phase of ilu0_csr, StaticCSR/ilu0.jl:13-81), jh_halo_create + jh_halo_info
+ * (a rank's halo plan: index tables and their validation, ext/JutulPartitionedArraysExt/utils.jl:91-148) -- and allocate or upload
  * nothing; every entry point that computes refuses it ("this context has no device").  NOT a CPU fallback: it lets a maintainer
  * (and this repository's CPU-only tests) check the set-up tables against Jutul's own and time the set-up on a box without a GPU. */
 int32_t jh_context_create_host(jh_context *out);

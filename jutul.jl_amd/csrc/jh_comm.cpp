@@ -671,7 +671,7 @@ extern "C" int32_t jh_halo_create(jh_tpfa d, int64_t n_owned, int32_t n_nbr, con
                                   const int64_t *send_cells, const int64_t *recv_ptr, const int64_t *recv_cells) {
   return guard([&] {
     if (!d) JH_THROW("null handle");
-    jh::require_device(d->ctx);
+    jh::DeviceScope dev(d->ctx);  // (planning contexts: the plan's index tables are built and checked, nothing is allocated)
     const Pattern &P = *d->pat;
     auto &H = d->halo;
     H.n_owned = n_owned;
@@ -712,7 +712,7 @@ extern "C" int32_t jh_halo_create(jh_tpfa d, int64_t n_owned, int32_t n_nbr, con
     H.d_recv_idx.upload(ri, s);
     H.d_send_buf.alloc(std::max<size_t>(1, (size_t)H.n_send * d->N));
     H.d_recv_buf.alloc(std::max<size_t>(1, (size_t)H.n_recv * d->N));
-    JH_HIP(hipStreamSynchronize(s));
+    jh::stream_sync(s);
     H.active = true;
   });
 }

@@ -216,3 +216,47 @@ def test_device_ordering_is_the_pinned_one(ja, hctx):
     pinned = json.load(open(os.path.join(ROOT, "tests", "golden", "ordering_crc.json")))
     for name, case in mod.cases(ja).items():
         assert mod.figures(ja, hctx, *case) == pinned[name], name
+
+
+def test_rank_local_set_up_and_halo_plan_without_a_device(ja, hctx):
+    """a-16 / a-17, host part, in the product library: every rank's discretisation (ghosts last, owned-first numbering), its halo
+    plan and the ILU(0) symbolic phase with the fused halo pack, for a 3-rank decomposition -- the plans of neighbouring ranks
+    mirror each other, ghosts grouped by owner are received without an unpack pass, and a wrong plan is refused."""
+    from jutul_amd import dd
+    g = ja.tet_lattice_mesh(12, 11, 10)
+    N, nc = g["N"], g["nc"]
+    part = dd.partition_graph(N, nc, 3, face_weights=g["T"])
+    subs = [dd.local_subdomain(N, part, r + 1, ghost_order="owner") for r in range(3)]
+    discs = []
+    for r, sub in enumerate(subs):
+        d = ja.TwoPointPotentialFlowHardCoded(hctx, sub["N"], sub["n_local"], reorder="blocks", block_rows=64, n_owned=sub["n_owned"],
+                                              face_weights=g["T"][sub["faces"] - 1])
+        d.set_halo(sub["n_owned"], sub["neighbors"], sub["send"], sub["recv"])
+        hi = d.halo_info()
+        assert hi["n_owned"] == sub["n_owned"] and hi["n_nbr"] == len(sub["neighbors"]) and hi["direct_recv"]
+        assert hi["n_send"] == sum(len(x) for x in sub["send"]) and hi["n_recv"] == sub["n_local"] - sub["n_owned"]
+        perm, bp = d.ordering()
+        assert np.array_equal(np.sort(perm[:sub["n_owned"]]), np.arange(1, sub["n_owned"] + 1))      # ghosts stay the last device rows
+        interior_rows, interior_blocks, _ = d.split()      # [interior blocks | boundary blocks | ghosts]
+        assert 0 <= interior_rows <= sub["n_owned"] and (interior_rows == 0 or bp[interior_blocks] == interior_rows)
+        A = ja.StaticSparsityMatrixCSR(d)
+        fi = ja.ILUZeroPreconditioner(partition="blocks").symbolic(A).info()
+        assert fi["nblocks"] == bp.size - 1 and fi["jagged"]
+        discs.append(d)
+    # what rank a sends to rank b is, cell for cell in global numbering, what b receives from a
+    for a, sa in enumerate(subs):
+        for i, b in enumerate(sa["neighbors"]):
+            sb = subs[int(b)]
+            j = list(sb["neighbors"]).index(a)
+            assert np.array_equal(sa["cells"][np.asarray(sa["send"][i]) - 1], sb["cells"][np.asarray(sb["recv"][j]) - 1])
+    sub = subs[0]
+    d = ja.TwoPointPotentialFlowHardCoded(hctx, sub["N"], sub["n_local"], reorder="blocks", block_rows=64, n_owned=sub["n_owned"])
+    with pytest.raises(ja.JutulHIPError, match="not an owned cell"):
+        d.set_halo(sub["n_owned"], sub["neighbors"], [np.asarray(s) * 0 + sub["n_local"] for s in sub["send"]], sub["recv"])
+    with pytest.raises(ja.JutulHIPError, match="not a ghost cell"):
+        d.set_halo(sub["n_owned"], sub["neighbors"], sub["send"], [np.asarray(r_) * 0 + 1 for r_ in sub["recv"]])
+    d2 = ja.TwoPointPotentialFlowHardCoded(hctx, sub["N"], sub["n_local"], reorder="blocks", block_rows=64)   # n_owned forgotten
+    with pytest.raises(ja.JutulHIPError, match="disagree on n_owned"):
+        d2.set_halo(sub["n_owned"], sub["neighbors"], sub["send"], sub["recv"])
+    with pytest.raises(ja.JutulHIPError, match="no device"):
+        ja.DeviceVector(discs[0])
