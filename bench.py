@@ -758,6 +758,17 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def device_code_hash():
+    """Hash of the machine code of every kernel in libjutul_hip.so (tools/fatbin_hash.py): unlike the source hash it does not move
+    when only host code changes (set-up, bindings, options)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from fatbin_hash import device_code_hash as dch
+        return dch(os.path.join(ROOT, "jutul.jl_amd", "libjutul_hip.so"))[0]
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def traffic_tag(args, cells):
     """name of the workload in profiles/r*_traffic_<tag>_1gpu.json (the default workload keeps its historic name)"""
     if args.law == "poisson" and args.mesh == "lattice" and cells == 10_025_988:
@@ -785,6 +796,7 @@ def measured_traffic(kernel, args, cells, world):
         return None, "PMC passes are committed for 1-GPU workloads only"
     tag = traffic_tag(args, cells)
     want = kernel_source_hash()
+    want_dev = device_code_hash()
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{tag}_1gpu.json")), reverse=True)
     if not cands:
         return None, f"no PMC pass is committed for this workload (profiles/r*_traffic_{tag}_1gpu.json; tools/pmc_passes.sh)"
@@ -792,7 +804,9 @@ def measured_traffic(kernel, args, cells, world):
         try:
             with open(path) as f:
                 d = json.load(f)
-            if d.get("_meta", {}).get("kernel_source_hash") != want:
+            meta = d.get("_meta", {})
+            same_dev = want_dev is not None and meta.get("device_code_hash") == want_dev
+            if meta.get("kernel_source_hash") != want and not same_dev:
                 continue
             for family in names[kernel]:
                 vals = []
@@ -801,10 +815,11 @@ def measured_traffic(kernel, args, cells, world):
                     if len(hit) == 1:
                         vals.append(hit[0])
                 if vals:
-                    return int(sum(vals) / len(vals)), f"{os.path.basename(path)} (same kernel sources, hash {want})"
+                    how = f"same kernel sources, hash {want}" if meta.get("kernel_source_hash") == want else f"same device code, hash {want_dev}"
+                    return int(sum(vals) / len(vals)), f"{os.path.basename(path)} ({how})"
         except Exception:  # noqa: BLE001
             continue
-    return None, f"no committed PMC pass of this workload matches the current kernel sources (hash {want}): re-run tools/pmc_passes.sh"
+    return None, f"no committed PMC pass of this workload matches the current kernel sources (hash {want}) or device code (hash {want_dev}): re-run tools/pmc_passes.sh"
 
 
 def usable_cores():

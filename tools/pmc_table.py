@@ -50,7 +50,13 @@ def finish(out, out_path):
     for fn in sorted(os.listdir(d)):
         if fn.endswith((".hip", ".hpp", ".cpp")):
             h.update(open(os.path.join(d, fn), "rb").read())
-    out["_meta"] = {"kernel_source_hash": h.hexdigest()[:16], "units": "FETCH_SIZE/WRITE_SIZE in KB per launch; SQ_* cycles are quad-cycles summed over waves"}
+    try:  # the machine code of the library the passes ran on: host-side changes leave it (and the validity of this table) alone
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from fatbin_hash import device_code_hash
+        dev_hash = device_code_hash(os.path.join(os.path.dirname(d), "libjutul_hip.so"))[0]
+    except Exception:  # noqa: BLE001
+        dev_hash = None
+    out["_meta"] = {"kernel_source_hash": h.hexdigest()[:16], "device_code_hash": dev_hash, "units": "FETCH_SIZE/WRITE_SIZE in KB per launch; SQ_* cycles are quad-cycles summed over waves"}
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
     for k, row in out.items():
         if k == "_meta":
