@@ -26,3 +26,33 @@ def test_committed_pmc_passes_are_found_for_every_bench_kernel(monkeypatch):
     monkeypatch.setattr(bench, "kernel_source_hash", lambda: "0" * 16)
     traffic, note = bench.measured_traffic("spmv", args, 10_025_988, 1)
     assert traffic is None and "no committed PMC pass" in note
+
+
+def test_a_table_taken_on_the_same_device_code_is_quoted_after_host_side_changes(monkeypatch, tmp_path):
+    """Host-side changes move the source hash but not the machine code of the kernels (tools/fatbin_hash.py): a PMC table that
+    records the device-code hash of its library stays valid for them."""
+    import bench
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_10M_1gpu.json")))[-1]
+    d = json.load(open(newest))
+    d["_meta"]["device_code_hash"] = "feedfacefeedface"
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r99_traffic_10M_1gpu.json").write_text(json.dumps(d))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "0" * 16)          # the sources have changed ...
+    args = types.SimpleNamespace(law="poisson", mesh="lattice")
+    monkeypatch.setattr(bench, "device_code_hash", lambda: "feedfacefeedface")   # ... the kernels have not
+    traffic, note = bench.measured_traffic("ilu0_apply", args, 10_025_988, 1)
+    assert traffic is not None and "same device code" in note
+    monkeypatch.setattr(bench, "device_code_hash", lambda: "0123456789abcdef")   # ... or they have
+    assert bench.measured_traffic("ilu0_apply", args, 10_025_988, 1)[0] is None
+    monkeypatch.setattr(bench, "device_code_hash", lambda: None)                 # (no library to hash)
+    assert bench.measured_traffic("ilu0_apply", args, 10_025_988, 1)[0] is None
+
+
+def test_device_code_hash_reads_the_built_library():
+    import __graft_entry__ as g
+    g.build()
+    import bench
+    h = bench.device_code_hash()
+    assert isinstance(h, str) and len(h) == 16 and h == bench.device_code_hash()
