@@ -1,10 +1,16 @@
 # the round's evidence on the final tree -> gpurun_out/r05/ (copied into profiles/r05_final_* afterwards)
-# usage: tools/r5_final_profiles.sh [part]   part = tests | pmc | bench | xrank | all (default)
+# usage: tools/r5_final_profiles.sh [part]   part = tests | setup | pmc | bench | xrank | all (default)
 PART=${1:-all}
 R=${GRAFT_REPO_ROOT:-$(dirname "$0")/..}; cd $R; O=$R/gpurun_out/r05; mkdir -p $O
 if [ $PART = tests ] || [ $PART = all ]; then
 timeout 3000 python -m pytest tests -m gpu -x -q > $O/gpu_pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/gpu_pytest.log | tail -1
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
+fi
+if [ $PART = setup ] || [ $PART = all ]; then
+# the set-up phases of the default workload as the library prints them (threaded bisection of session 4: never timed on this box)
+nproc > $O/setup_phases.txt; grep -m1 "model name" /proc/cpuinfo >> $O/setup_phases.txt; cat /sys/fs/cgroup/cpu.max >> $O/setup_phases.txt 2>/dev/null
+python bench.py --no-cpu --steps 10 --warmup 3 --option setup_timing=1 > $O/bench_setup_timing.json 2>> $O/setup_phases.txt; grep -c "jutul_hip setup" $O/setup_phases.txt
+JH_SETUP_THREADS=1 python bench.py --no-cpu --steps 10 --warmup 3 --option setup_timing=1 > $O/bench_setup_timing_1thread.json 2> $O/setup_phases_1thread.txt
 fi
 if [ $PART = pmc ] || [ $PART = all ]; then
 bash tools/collect_profiles.sh r05_final > $O/collect.log 2>&1
