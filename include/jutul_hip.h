@@ -75,6 +75,8 @@ int32_t jh_synchronize(jh_context ctx); /* synchronize(ctx), context.jl:72 */
  *                            programs, wavefront per row | 0 = thread per row)
  *   asm_pipe (1), asm_pipe2_wgs (0), block_order (0 bisection | 1 onion), block_weights (1: use the face weights of
  *   jh_tpfa_create_weighted | 0: ignore them)
+ *   setup_heap (0; process-wide, glibc: while 1, large blocks come from the heap and freed heap memory is kept, so the set-up's later
+ *   tables reuse mapped pages -- half the page faults of a first set-up, none in a second one; 0 restores the thresholds and trims)
  *   read_sync (0), setup_timing (0), plan_checksum (0; planning contexts), jds_keep (0), upload_bounce (1; process-wide: 0 copies caller arrays straight from their
  *   pageable memory instead of through the page-locked bounce buffer)
  *   xrank_consumer (-1 = when jh_comm_set_exclusive declared it | 0 | 1)  several ranks: the dot products of the Krylov loop are

@@ -10,6 +10,8 @@
 #include <map>
 #include <mutex>
 
+#include <malloc.h>
+
 #include "jh_internal.hpp"
 
 namespace jh {
@@ -144,8 +146,31 @@ inline void check(int32_t rc) {  // nested C-ABI call failed: the message is alr
 
 // ---- options ----------------------------------------------------------------------------------------------------
 namespace jh {
+// Option setup_heap (PROCESS-WIDE, glibc): the set-up allocates and frees ~5 GB of tables and temporaries per 10M cells, and every
+// vector of more than the allocator's mmap threshold is a fresh mapping whose pages are faulted in one by one, zeroed by the kernel
+// and handed back on free -- 1.2M page faults per set-up, on the thread that fills the vector.  1: such blocks come from the heap
+// and freed heap memory is kept, so later tables reuse pages that are already mapped (10M cells: 5.1 -> 2.6 GB faulted during a
+// first set-up, ~0 during a second one in the same process); 0 (the default state of the process): thresholds back to glibc's
+// steady-state values and the free heap memory returned to the system (malloc_trim).  A HOST decision -- it changes how every
+// malloc of the process behaves while it is on -- hence an option, off unless asked for: bench.py switches it on around its set-up.
+static void apply_setup_heap(bool on) {
+#if defined(__GLIBC__)
+  if (on) {
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, INT32_MAX);
+  } else {
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);  // what the dynamic thresholds converge to once a program has freed large blocks
+    mallopt(M_TRIM_THRESHOLD, 64 << 20);
+    malloc_trim(0);
+  }
+#else
+  (void)on;
+#endif
+}
+static std::atomic<int> g_setup_heap{0};
 bool Options::set(const char *key, int64_t v) {
   if (std::strcmp(key, "upload_bounce") == 0) g_upload_bounce.store(v != 0, std::memory_order_relaxed);
+  if (std::strcmp(key, "setup_heap") == 0 && g_setup_heap.exchange(v != 0) != (v != 0)) apply_setup_heap(v != 0);
   // launch geometries that go into kernels unchanged: only the shapes the kernels are written for (a factor workgroup of fewer
   // than 64 threads has no wavefront to walk its rows; a partial wavefront would share rows with another one)
   if (std::strcmp(key, "ilu_factor_threads") == 0 && v != 0 && v != 64 && v != 128 && v != 256 && v != 512)

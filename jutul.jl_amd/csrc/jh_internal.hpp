@@ -346,6 +346,7 @@ struct Comm;  // RCCL state (jh_comm.cpp)
   X(read_sync, 0)             /* device scalars through copy + stream synchronise instead of the pinned record */              \
   X(comm_timeout_ms, 600000)  /* limit of the mailbox / push-halo waits inside kernels, 0 = wait like a collective */          \
   X(upload_bounce, 1)         /* PROCESS-WIDE: caller arrays cross PCIe through the library's page-locked bounce buffer; 0 = straight from the caller's (pageable) memory */ \
+  X(setup_heap, 0)            /* PROCESS-WIDE (glibc): large blocks from the heap, freed heap memory kept -> later set-up tables reuse mapped pages; 0 restores and trims */ \
   X(setup_timing, 0)          /* print the set-up phases */                                                                    \
   X(plan_checksum, 0)         /* planning contexts: checksum every table that would be uploaded (jh_context_plan_checksum) */  \
   X(xrank_consumer, -1)       /* several ranks: dots all-reduced inside the consuming kernels + push-halo hand-shake inside the product; -1 = when the host declared exclusive compute units (jh_comm_set_exclusive) */ \

@@ -260,3 +260,21 @@ def test_rank_local_set_up_and_halo_plan_without_a_device(ja, hctx):
         d2.set_halo(sub["n_owned"], sub["neighbors"], sub["send"], sub["recv"])
     with pytest.raises(ja.JutulHIPError, match="no device"):
         ja.DeviceVector(discs[0])
+
+
+def test_setup_heap_option_changes_no_table(ja):
+    """setup_heap (process-wide malloc policy of the host during the set-up) is about page faults only: same tables, and the option
+    can be switched on and off around a set-up."""
+    g = ja.tet_lattice_mesh(20, 19, 18, scramble=True)
+    sums = []
+    for heap in (0, 1):
+        ctx = ja.HIPContext("host", plan_checksum=1, setup_heap=heap)
+        assert ctx.get_option("setup_heap") == heap
+        d = ja.TwoPointPotentialFlowHardCoded(ctx, g["N"], g["nc"], reorder="blocks", face_weights=g["T"])
+        A = ja.StaticSparsityMatrixCSR(d)
+        A.spmv_info()
+        ja.ILUZeroPreconditioner(partition="blocks").symbolic(A)
+        ctx.set_option("setup_heap", 0)
+        assert ctx.get_option("setup_heap") == 0
+        sums.append(ctx.plan_checksum())
+    assert sums[0] == sums[1] != 0
