@@ -2307,12 +2307,25 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         std::vector<char> blk_ok(nb, 1), blk_diag(nb, 1);  // blk_diag: every update of the block targets a pivot
         std::vector<int32_t> jt_map(nlent, -1), jf_diag(M->j_nslots, -1);
         std::vector<uint16_t> jf_bslot(M->j_nslots, 0);
-        parallel_ranges(nb, 16, [&](int64_t bb0, int64_t bb1) {
+        // The programs are what the program-driven kernels read; the pivot-only kernels (every update of every block lands on a
+        // pivot: triangle-free block patterns -- the lattice, Cartesian and most TPFA grids) never do.  Where the static conditions of
+        // those kernels hold, a block's program is therefore generated (its size and whether it is pivot-only are needed) but not
+        // kept -- 98M words = 200 MB at 10M cells, twice with the concatenated copy, plus the upload and the HBM -- until a block turns
+        // out not to be pivot-only; the few blocks that were processed before that are generated again afterwards.
+        int mxc_pre = 0;
+        for (int64_t b = 0; b < nb; ++b) mxc_pre = std::max(mxc_pre, M->chunk_ptr[b + 1] - M->chunk_ptr[b]);
+        const bool expect_diag = !VR && mxc_pre * 64 <= 1024 && sizeof(double) * (size_t)M->max_block_rows * M->bs * M->bs <= 64 * 1024 &&
+                                 M->ctx->opt.ilu_diag_factor != 0;
+        std::atomic<bool> keep_programs{!expect_diag};
+        std::vector<size_t> prog_words(nb, 0);   // length of every block's (instruction-form) program, kept or not
+        auto run_blocks = [&](const std::vector<int64_t> *list) {
+        parallel_ranges(list ? (int64_t)list->size() : nb, 16, [&](int64_t bb0, int64_t bb1) {
           int lanes[64];
-          std::vector<uint16_t> code;
+          std::vector<uint16_t> code, tprog;
           std::vector<VRow> vrows[2];
           std::vector<int32_t> done;
-          for (int64_t b = bb0; b < bb1; ++b) {
+          for (int64_t bi = bb0; bi < bb1; ++bi) {
+            const int64_t b = list ? (*list)[(size_t)bi] : bi;
             const int32_t b0 = M->blk_ptr[b], b1 = M->blk_ptr[b + 1], nrb = b1 - b0;
             int32_t wpos[2] = {M->blk_lbase[b], M->blk_ubase[b]};  // running jagged position of the forward / backward sweep
             for (int sweep = 0; sweep < 2; ++sweep) build_vrows(b, sweep, vrows[sweep], done);
@@ -2370,7 +2383,7 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
             const int32_t dslot0 = M->chunk_ptr[b] * 64, nd = (M->chunk_ptr[b + 1] - M->chunk_ptr[b]) * 64;
             blk_vals[b] = nl + nu + nd;
             if (nl + nu + nd >= 65536) { blk_ok[b] = 0; continue; }
-            std::vector<uint16_t> &prog = progs[b];
+            std::vector<uint16_t> &prog = tprog;
             prog.assign(2 * (size_t)nrb + 1, 0);  // row offsets (nrb + 1), pivot indices (nrb)
             code.clear();
             auto didx = [&](int32_t t) { return (uint16_t)(nl + nu + (M->jd_of_old[M->upos_of[t]] - dslot0)); };  // t: ilu row
@@ -2417,11 +2430,16 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
             }
             prog[nrb] = (uint16_t)code.size();
             prog.insert(prog.end(), code.begin(), code.end());
+            prog_words[b] = prog.size();
+            if (!blk_ok[b] || !blk_diag[b]) keep_programs.store(true, std::memory_order_relaxed);
+            if (list || keep_programs.load(std::memory_order_relaxed)) progs[b] = prog;
             if (want_rows && blk_ok[b])
               rows_ok[b] = prog_rows_form(prog, nrb, nl + nu + nd, M->flev_ptr.data() + M->flev_off[b],
                                           M->flev_off[b + 1] - M->flev_off[b] - 1, b0, P.bs == 1 ? 8 : (P.bs == 2 ? 4 : 2), progs_rows[b]);
           }
         });
+        };
+        run_blocks(nullptr);
         lap("  jagged: blocks (layout + programs)");
         {
           bool ok = true;
@@ -2438,9 +2456,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
             max_vals = std::max(max_vals, blk_vals[b]);
             // LDS words: the whole program, or (rows form: the rows are read from global memory) its head
             max_words = std::max<int>(max_words, rows ? 2 + (M->flev_off[b + 1] - M->flev_off[b] - 1) + 4 * (M->blk_ptr[b + 1] - M->blk_ptr[b])
-                                                      : (int)progs[b].size());
+                                                      : (int)prog_words[b]);
             M->blk_prog[b] = (int32_t)total;
-            total += progs[b].size();
+            total += rows ? progs[b].size() : prog_words[b];
           }
           M->blk_prog[nb] = (int32_t)total;
           {
@@ -2527,21 +2545,28 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
           size_t bytes = sizeof(double) * P.bs * P.bs * (size_t)max_vals + sizeof(uint16_t) * (size_t)max_words;
           bytes = (bytes + 15) & ~(size_t)15;
           if (ok && total < (size_t)INT32_MAX && bytes <= 160 * 1024 - 512 && M->ctx->opt.ilu_prog) {
-            std::vector<uint16_t> prog(std::max<size_t>(total, 1), 0);
-            parallel_ranges(nb, 64, [&](int64_t bb0, int64_t bb1) {
-              for (int64_t b = bb0; b < bb1; ++b)
-                if (!progs[b].empty()) std::copy(progs[b].begin(), progs[b].end(), prog.begin() + M->blk_prog[b]);
-            });
             M->prog = true;
             M->prog_lds_bytes = bytes; M->prog_max_vals = max_vals; M->prog_max_words = max_words;
-            if (timing) fprintf(stderr, "[jutul_hip setup] ilu0: factor programs: LDS %zu B per block (values %d, words %d), %zu words total, %lld rows in the largest block\n",
-                                bytes, max_vals, max_words, total, (long long)maxrows);
-            hipStream_t sp = M->ctx->stream;
-            M->d_blk_lbase.upload(M->blk_lbase, sp); M->d_blk_ubase.upload(M->blk_ubase, sp); M->d_blk_prog.upload(M->blk_prog, sp);
-            M->blk_dbase.assign(nb + 1, 0);
-            for (int64_t b = 0; b <= nb; ++b) M->blk_dbase[b] = M->chunk_ptr[b] * 64;
-            M->d_blk_dbase.upload(M->blk_dbase, sp);
-            M->d_prog.upload(prog, sp);
+            if (timing) fprintf(stderr, "[jutul_hip setup] ilu0: factor programs: LDS %zu B per block (values %d, words %d), %zu words total, %lld rows in the largest block%s\n",
+                                bytes, max_vals, max_words, total, (long long)maxrows, M->diag_only ? " (pivot-only kernels: not kept, not uploaded)" : "");
+            if (!M->diag_only) {  // (jh_ilu0_factor takes the pivot-only kernels whenever diag_only holds: nothing reads the programs then)
+              if (!rows) {  // blocks whose program was not kept while every block so far had been pivot-only
+                std::vector<int64_t> again;
+                for (int64_t b = 0; b < nb; ++b) if (prog_words[b] > 0 && progs[b].empty()) again.push_back(b);
+                if (!again.empty()) run_blocks(&again);
+              }
+              std::vector<uint16_t> prog(std::max<size_t>(total, 1), 0);
+              parallel_ranges(nb, 64, [&](int64_t bb0, int64_t bb1) {
+                for (int64_t b = bb0; b < bb1; ++b)
+                  if (!progs[b].empty()) std::copy(progs[b].begin(), progs[b].end(), prog.begin() + M->blk_prog[b]);
+              });
+              hipStream_t sp = M->ctx->stream;
+              M->d_blk_lbase.upload(M->blk_lbase, sp); M->d_blk_ubase.upload(M->blk_ubase, sp); M->d_blk_prog.upload(M->blk_prog, sp);
+              M->blk_dbase.assign(nb + 1, 0);
+              for (int64_t b = 0; b <= nb; ++b) M->blk_dbase[b] = M->chunk_ptr[b] * 64;
+              M->d_blk_dbase.upload(M->blk_dbase, sp);
+              M->d_prog.upload(prog, sp);
+            }
           }
         }
         lap("  jagged: program concat");
