@@ -217,7 +217,7 @@ struct PGraph {
 void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t nparts, double imbalance, int64_t max_part,
                       std::vector<int32_t> &label, int32_t rim_cell);
 void partition_on_bfs_numbering(int64_t nc, const int64_t *ptr, const int32_t *nbr, const double *wk, const int32_t *sface, const double *fw,
-                                int64_t nparts, double imbalance, int64_t max_part, int32_t *label_out,
+                                double fw_scale, int64_t nparts, double imbalance, int64_t max_part, int32_t *label_out,
                                 const std::function<void(const char *)> &lap);
 
 // ---- tiling constants for the CSR row-segment kernels ------------------------------------------------
@@ -547,7 +547,7 @@ struct jh_tpfa_s {
   jh_context ctx = nullptr;
   int64_t nc = 0, nf = 0, nhf = 0, nnzb = 0;  // nnzb: device slots (== pat->nnzb); the host pattern has pat->nnzb_host
   int N = 1;
-  std::vector<int64_t> Nhost;  // 2*nf, 1-based, as given
+  std::vector<int32_t> Nhost;  // 2*nf, 1-based, as given (cells are < 2^31: jh_tpfa_create checks)
   std::shared_ptr<jh::Pattern> pat;
   // per device nnz: signed face id (+(f+1) if row cell == N[1,f], -(f+1) if == N[2,f], 0 on the diagonal)
   std::vector<int32_t> nz_face;

@@ -416,10 +416,11 @@ void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t npa
 
 
 // Partition of the vertices 0 .. nc-1 of the graph (ptr, nbr; neighbours >= nc are ignored) into nparts, label_out[v] in 0 .. nparts-1.
-// Weight of adjacency entry k: wk[k], or fw[|sface[k]| - 1] (a weight per face, sface = signed 1-based face id of the entry), or 1.
+// Weight of adjacency entry k: wk[k], or |fw[|sface[k]| - 1]| x fw_scale (a weight per face, sface = signed 1-based face id of the
+// entry; non-finite weights count as 0), or 1.
 // lap(name): called after each phase (set-up timing).
 void partition_on_bfs_numbering(int64_t nc, const int64_t *ptr, const int32_t *nbr, const double *wk, const int32_t *sface, const double *fw,
-                                int64_t nparts, double imbalance, int64_t max_part, int32_t *label_out,
+                                double fw_scale, int64_t nparts, double imbalance, int64_t max_part, int32_t *label_out,
                                 const std::function<void(const char *)> &lap) {
   const bool weighted = wk || (fw && sface);
   // The input numbering may be arbitrary (the bench grid's is scrambled): every sweep of the partitioner would miss the
@@ -481,7 +482,14 @@ void partition_on_bfs_numbering(int64_t nc, const int64_t *ptr, const int32_t *n
       int64_t w = ptr2[i];
       for (int64_t k = ptr[c]; k < ptr[c + 1]; ++k)
         if (nbr[k] < nc) {
-          if (weighted) w2[w] = wk ? wk[k] : fw[std::abs(sface[k]) - 1];
+          if (weighted) {
+            if (wk) {
+              w2[w] = wk[k];
+            } else {
+              const double v = std::fabs(fw[std::abs(sface[k]) - 1]);
+              w2[w] = (std::isfinite(v) ? v : 0.0) * fw_scale;
+            }
+          }
           nbr2[w++] = newid[nbr[k]];
         }
     }
@@ -552,18 +560,13 @@ extern "C" int32_t jh_partition_graph(int64_t nc, int64_t nf, const int64_t *N, 
         }
     });
     { std::vector<int64_t>().swap(cur); }
-    // |weight| per face; the bisections run on a breadth-first renumbering of the cells (an arbitrary input numbering would miss the
+    // the bisections run on a breadth-first renumbering of the cells (an arbitrary input numbering would miss the
     // cache on every access of every sweep; build box, 3M scrambled cells, weighted: 8 parts 4.1 -> 2.4 s, 64 parts 4.7 -> 2.4 s, the cut
     // weight unchanged to four digits)
-    std::vector<double> fw;
-    if (face_weights) {
-      resize_parallel(fw, (size_t)nf);
-      parallel_ranges(nf, 1 << 18, [&](int64_t b, int64_t e) { for (int64_t f = b; f < e; ++f) fw[f] = std::fabs(face_weights[f]); });
-    }
     std::vector<int32_t> label;
     resize_parallel(label, (size_t)nc);
-    partition_on_bfs_numbering(nc, ptr.data(), nbr.data(), nullptr, face_weights ? face.data() : nullptr, face_weights ? fw.data() : nullptr, nparts,
-                               imbalance, 0, label.data(), [](const char *) {});
+    partition_on_bfs_numbering(nc, ptr.data(), nbr.data(), nullptr, face_weights ? face.data() : nullptr, face_weights, 1.0, nparts, imbalance, 0,
+                               label.data(), [](const char *) {});
     for (int64_t c = 0; c < nc; ++c) out[c] = (int64_t)label[c] + 1;
   });
 }

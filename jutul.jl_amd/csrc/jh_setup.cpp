@@ -177,11 +177,11 @@ struct PhaseTimer {
 // half-faces at 512 cells per block on the tet lattice = 24.0 instead of 26.6 BiCGStab iterations at 2M cells, and a
 // dependency depth of the radius, not the diameter.  Block ids follow the bisection tree (neighbouring blocks are close in
 // memory); inside a block the cells are ordered breadth-first from a centre.
-// fw: |coupling| per face (nf doubles, scaled so that their mean is 1) or nullptr -- the cuts then prefer weak couplings (the
+// fw, fw_scale: coupling per face (nf doubles; |.| x fw_scale has mean 1, non-finite values count as 0) or nullptr -- the cuts then prefer weak couplings (the
 // reference partitions the |A|-weighted graph of the matrix for its block-Jacobi ILU(0), precond/ilu.jl:37-60 ->
 // generate_metis_graph, partitioning.jl:64-78)
 static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, std::vector<int32_t> &perm, std::vector<int32_t> &block_ptr, bool timing,
-                                const double *fw) {
+                                const double *fw, double fw_scale) {
   const int64_t nparts = std::max<int64_t>(1, (nc + block_rows / 2) / block_rows);
   const int64_t max_part = std::max<int64_t>(block_rows + block_rows / 8, (nc + nparts - 1) / nparts);
   std::vector<int32_t> label;
@@ -189,7 +189,7 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
   parallel_ranges((int64_t)label.size(), 1 << 18, [&](int64_t b, int64_t e) { std::fill(label.begin() + b, label.begin() + e, -1); });
   PhaseTimer pt(timing);
   // (on a breadth-first renumbering of the owned cells: jh_partition.cpp)
-  partition_on_bfs_numbering(nc, A.ptr.data(), A.nbr.data(), nullptr, fw ? A.sface.data() : nullptr, fw, nparts, 0.04, max_part, label.data(),
+  partition_on_bfs_numbering(nc, A.ptr.data(), A.nbr.data(), nullptr, fw ? A.sface.data() : nullptr, fw, fw_scale, nparts, 0.04, max_part, label.data(),
                              [&](const char *what) { pt.lap(what); });
   std::vector<int32_t> cnt(nparts + 1, 0);
   for (int64_t c = 0; c < nc; ++c) cnt[label[c] + 1]++;
@@ -211,13 +211,13 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
 
 static void order_blocks(const Adj &A, int64_t nc_all, int64_t nc, int64_t block_rows, std::vector<int32_t> &perm,
                          std::vector<int32_t> &block_ptr, int64_t &interior_rows, int32_t &interior_blocks, bool onion, bool timing,
-                         const double *fw) {
+                         const double *fw, double fw_scale) {
   // cells >= nc (ghosts of a rank-local subdomain) are never absorbed; they form the last block
   perm.clear();
   perm.reserve(nc_all);
   block_ptr.assign(1, 0);
   // onion (option block_order = 1): round 1's blocks grown along the rim of the assigned region; default: graph bisection (above)
-  if (!onion) blocks_by_bisection(A, nc, block_rows, perm, block_ptr, timing, fw);
+  if (!onion) blocks_by_bisection(A, nc, block_rows, perm, block_ptr, timing, fw, fw_scale);
   std::vector<int32_t> blk(nc_all, -1);
   for (int64_t c = nc; c < nc_all; ++c) blk[c] = INT32_MAX;
   std::vector<int32_t> cand;  // frontier candidates for the next seed (FIFO)
@@ -395,7 +395,7 @@ extern "C" int32_t jh_tpfa_create_weighted(jh_context ctx, int64_t nc, int64_t n
     d->N = block_n;
     PhaseTimer pt(ctx->opt.setup_timing != 0);
     resize_parallel(d->Nhost, (size_t)(2 * nf));
-    parallel_ranges(2 * nf, 1 << 18, [&](int64_t b, int64_t e) { std::copy(N + b, N + e, d->Nhost.begin() + b); });
+    parallel_ranges(2 * nf, 1 << 18, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) d->Nhost[i] = (int32_t)N[i]; });  // (validated by build_adjacency)
     Adj A = build_adjacency(nc, nf, N);
     pt.lap("adjacency");
     if (n_owned <= 0 || n_owned > nc) n_owned = nc;
@@ -420,20 +420,16 @@ extern "C" int32_t jh_tpfa_create_weighted(jh_context ctx, int64_t nc, int64_t n
         if (deg > 7.0) block_rows = std::max<int64_t>(64, (int64_t)(block_rows * 5.0 / deg) / 32 * 32);
       }
       // |coupling| per face for the bisection, mean 1 (the refinement's give-up thresholds are absolute); non-finite -> 0
-      std::vector<double> fw;
+      // (no scaled copy of the weights: the factor goes with the pointer and is applied where the partitioner's graph is built)
+      const double *fw = nullptr;
+      double fw_scale = 1.0;
       if (face_weights && nf > 0 && ctx->opt.block_weights != 0) {
-        resize_parallel(fw, (size_t)nf);
         double sum = 0.0;
-        for (int64_t f = 0; f < nf; ++f) { const double v = std::fabs(face_weights[f]); fw[f] = std::isfinite(v) ? v : 0.0; sum += fw[f]; }
-        if (sum > 0.0) {
-          const double sc = (double)nf / sum;
-          parallel_ranges(nf, 1 << 18, [&](int64_t b, int64_t e) { for (int64_t f = b; f < e; ++f) fw[f] *= sc; });
-        } else {
-          fw.clear();
-        }
+        for (int64_t f = 0; f < nf; ++f) { const double v = std::fabs(face_weights[f]); sum += std::isfinite(v) ? v : 0.0; }
+        if (sum > 0.0) { fw = face_weights; fw_scale = (double)nf / sum; }
       }
       order_blocks(A, nc, n_owned, block_rows, pat->perm, pat->block_ptr, pat->interior_rows, pat->interior_blocks,
-                   ctx->opt.block_order == 1, ctx->opt.setup_timing != 0, fw.empty() ? nullptr : fw.data());
+                   ctx->opt.block_order == 1, ctx->opt.setup_timing != 0, fw, fw_scale);
     } else if (reorder != JH_REORDER_NONE) {
       JH_THROW("unknown reorder mode");
     }
@@ -567,7 +563,7 @@ extern "C" int32_t jh_tpfa_sizes(jh_tpfa d, int64_t *nc, int64_t *nf, int64_t *n
 // --------------------------------------------------------------------------------------------------------------
 void jh_tpfa_s::build_tables() {
   if (tables_built) return;
-  const int64_t *Nn = Nhost.data();
+  const int32_t *Nn = Nhost.data();
   face_pos.assign(nc + 1, 0);
   for (int i = 0; i < 2; ++i)
     for (int64_t j = 0; j < nf; ++j) face_pos[Nn[2 * j + i]]++;
