@@ -32,12 +32,17 @@ void Pattern::build_jagged() {
   for (int64_t i = 0; i < n; ++i) kmax = std::max(kmax, rowptr[i + 1] - rowptr[i]);
   if (kmax > JDS_KMAX) return;
   const int32_t ns = (int32_t)((n + 63) / 64);
-  std::vector<int32_t> base(ns + 1, 0), jc(nnzb + 64, 0);  // + 64: lanes past a diagonal's count load too
+  // 16-bit codes pay where the product streams from HBM for long (10M rows: 0.177 instead of 0.181-0.188 ms); on a small matrix
+  // the extra pipeline stage costs more than the bytes save (1.25M rows: 28.5 instead of 27.1 us)
+  const int64_t force = ctx->opt.spmv_col_bits;  // 16 / 32: test switch (read when the layout is built)
+  const bool col16 = force ? force == 16 : n >= 3000000;
+  // (only the column array of the chosen width is built: the other one is 100 / 200 MB at 10M rows)
+  std::vector<int32_t> base(ns + 1, 0), jc(col16 ? 0 : nnzb + 64, 0);  // + 64: lanes past a diagonal's count load too
   std::vector<uint16_t> src(nnzb + 64, 0);                // CSR slot of a jagged entry, relative to the first slot of its slice (< 512)
   std::vector<uint8_t> cnt((size_t)ns * 16, 0), perm((size_t)ns * 64, 0);
   // 16-bit column codes: a slice's columns lie almost all in a window around its rows (the device order keeps neighbours close);
   // the few outside go to a per-slice list
-  std::vector<uint16_t> jc16(nnzb + 64, 0);
+  std::vector<uint16_t> jc16(col16 ? nnzb + 64 : 0, 0);
   std::vector<int32_t> win((size_t)ns * 2, 0), far;
   // Slices are independent (no padding: slice s starts at entry rowptr[64 s]); only the lists of far columns are appended in slice
   // order -- every range of slices collects its own and the ranges are concatenated in order afterwards.  All host cores.
@@ -67,8 +72,9 @@ void Pattern::build_jagged() {
           const int64_t row = r0 + lanes[l];
           if (rowptr[row + 1] - rowptr[row] > j) {
             const int32_t cj = col[rowptr[row] + j];
-            jc[pos] = cj;
-            if (cj >= cb && cj - cb < JDS_FAR) {
+            if (!col16) {
+              jc[pos] = cj;
+            } else if (cj >= cb && cj - cb < JDS_FAR) {
               jc16[pos] = (uint16_t)(cj - cb);
             } else {
               jc16[pos] = (uint16_t)(JDS_FAR + (P.far.size() - far0));  // (a slice has at most 512 entries)
@@ -102,10 +108,6 @@ void Pattern::build_jagged() {
   jag.d_base.upload(base, st);
   jag.d_cnt.upload(cnt, st);
   jag.d_perm.upload(perm, st);
-  // 16-bit codes pay where the product streams from HBM for long (10M rows: 0.177 instead of 0.181-0.188 ms); on a small matrix
-  // the extra pipeline stage costs more than the bytes save (1.25M rows: 28.5 instead of 27.1 us)
-  const int64_t force = ctx->opt.spmv_col_bits;  // 16 / 32: test switch (read when the layout is built)
-  const bool col16 = force ? force == 16 : n >= 3000000;
   if (col16) {
     far.resize(far.size() + (0x10000 - JDS_FAR), 0);  // any code of any slice decodes to a valid position
     jag.d_col16.upload(jc16, st);
