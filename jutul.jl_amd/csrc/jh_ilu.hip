@@ -2577,7 +2577,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         M->d_jf_row.upload(frow, sj); M->d_jb_row.upload(brow, sj);
         M->d_jl_col.upload(jlc, sj); M->d_ju_col.upload(juc, sj);
         M->d_jl_map.upload(M->jl_map, sj); M->d_ju_map.upload(M->ju_map, sj); M->d_jd_map.upload(M->jd_map, sj);
-        M->d_jl_of_old.upload(M->jl_of_old, sj); M->d_ju_of_old.upload(M->ju_of_old, sj); M->d_jd_of_old.upload(M->jd_of_old, sj);
+        // (old position -> jagged position: what ilu_to_jagged permutes by after a row-major factorisation; the program-driven and
+        // pivot-only kernels write the jagged arrays themselves)
+        if (!M->prog) { M->d_jl_of_old.upload(M->jl_of_old, sj); M->d_ju_of_old.upload(M->ju_of_old, sj); M->d_jd_of_old.upload(M->jd_of_old, sj); }
         const size_t bbj = (size_t)P.bs * P.bs;
         M->jl_val.alloc((size_t)(M->jl_nent + 64) * bbj); M->ju_val.alloc((size_t)(M->ju_nent + 64) * bbj); M->jdinv.alloc((size_t)M->j_nslots * bbj);
         M->jl_val.zero(sj);
@@ -2759,6 +2761,7 @@ extern "C" int32_t jh_diag_precond_create(jh_csr A, int32_t kind, double w, jh_i
 namespace jh {
 // row-major factor arrays -> chunk-jagged ones (factor kernels that still produce the row-major order)
 static void ilu_to_jagged(jh_ilu M) {
+  if (M->prog) JH_THROW("internal error: ilu_to_jagged on a preconditioner whose kernels write the jagged arrays themselves");
   hipStream_t s = M->ctx->stream;
   const int bb = M->bs * M->bs;
   auto g = [](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096))); };
