@@ -136,11 +136,37 @@ static inline int64_t bfs_parallel(const int64_t *ptr, const int32_t *nbr, int32
   TeamBarrier bar(nt);
   std::vector<int64_t> cnt((size_t)nt * 8, 0);  // (one cache line per thread)
   int64_t head_out = head, tail_out = tail;
+  // Levels of fewer than `small` vertices (the first steps of any search; every level of a long thin graph -- a 1-D column has as
+  // many levels as cells) are not worth three barriers: thread 0 runs them alone, as the plain serial loop, while the team waits once.
+  constexpr int64_t small = 512;
+  int64_t sh_h = head, sh_tl = tail;  // (written by thread 0 in front of a barrier, read by the team behind it)
   parallel_team(nt, [&](int t, int) {
     std::vector<int32_t> buf;
     std::vector<std::pair<int32_t, int32_t>> claimed;  // (claim, vertex) of every claim this thread placed, in serial order
     int64_t h = head, tl = tail;
     while (h < tl) {
+      if (tl - h < small) {
+        if (t == 0) {
+          while (h < tl && tl - h < small) {
+            if (levels) levels->push_back(h);
+            const int64_t level_end = tl;
+            for (; h < level_end; ++h) {
+              const int32_t v = o[h];
+              for (int64_t k = ptr[v]; k < ptr[v + 1]; ++k) {
+                const int32_t w = nbr[k];
+                if (accept(w) && mark[w] != st) { mark[w] = st; o[tl++] = w; }
+              }
+            }
+          }
+          sh_h = h;
+          sh_tl = tl;
+        }
+        bar.wait();
+        h = sh_h;
+        tl = sh_tl;
+        bar.wait();  // (thread 0 may write sh_* again only after everybody has read them)
+        continue;
+      }
       if (t == 0 && levels) levels->push_back(h);
       const int64_t F = tl - h, i0 = h + F * t / nt, i1 = h + F * (t + 1) / nt;
       claimed.clear();

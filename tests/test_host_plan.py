@@ -278,3 +278,27 @@ def test_setup_heap_option_changes_no_table(ja):
         assert ctx.get_option("setup_heap") == 0
         sums.append(ctx.plan_checksum())
     assert sums[0] == sums[1] != 0
+
+
+def test_long_thin_graphs_do_not_pay_for_the_thread_teams(ja, monkeypatch):
+    """A 1-D column has as many breadth-first levels as cells: the level-synchronous sweeps of the set-up (bfs_parallel) must fall
+    back to the plain loop for small levels -- same blocks for any thread count, and no barrier per cell."""
+    import time
+    n = 300_000
+    chain = np.stack([np.arange(1, n), np.arange(2, n + 1)])
+    w, h = 6, 40_000                                                    # a 6 x 40000 strip: 40k levels of 6 cells
+    idx = np.arange(w * h).reshape(h, w) + 1
+    strip = np.concatenate([np.stack([idx[:, :-1].ravel(), idx[:, 1:].ravel()]), np.stack([idx[:-1].ravel(), idx[1:].ravel()])], axis=1)
+    for name, N, nc in (("chain", chain, n), ("strip", strip, w * h)):
+        sums = []
+        for threads in ("1", "8"):
+            monkeypatch.setenv("JH_SETUP_THREADS", threads)
+            ctx = ja.HIPContext("host", plan_checksum=1)
+            t0 = time.time()
+            d = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, reorder="blocks")
+            dt = time.time() - t0
+            perm, bp = d.ordering()
+            assert np.array_equal(np.sort(perm), np.arange(1, nc + 1)) and np.diff(bp).max() <= 576
+            sums.append(ctx.plan_checksum())
+            assert dt < 30.0, (name, threads, dt)
+        assert sums[0] == sums[1], name
