@@ -149,8 +149,8 @@ namespace jh {
 // Option setup_heap (PROCESS-WIDE, glibc): the set-up allocates and frees ~5 GB of tables and temporaries per 10M cells, and every
 // vector of more than the allocator's mmap threshold is a fresh mapping whose pages are faulted in one by one, zeroed by the kernel
 // and handed back on free -- 1.2M page faults per set-up, on the thread that fills the vector.  1: such blocks come from the heap
-// and freed heap memory is kept, so later tables reuse pages that are already mapped (10M cells: 5.1 -> 2.6 GB faulted during a
-// first set-up, ~0 during a second one in the same process); 0 (the default state of the process): thresholds back to glibc's
+// and freed heap memory is kept, so later tables reuse pages that are already mapped (10M cells: 4.2 -> 2.1 GB faulted during a
+// first set-up, ~0 during a second one while the option stays on); 0 (the default state of the process): thresholds back to glibc's
 // steady-state values and the free heap memory returned to the system (malloc_trim).  A HOST decision -- it changes how every
 // malloc of the process behaves while it is on -- hence an option, off unless asked for: bench.py switches it on around its set-up.
 static void apply_setup_heap(bool on) {
