@@ -2019,14 +2019,18 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     } else if (nparts == -1) {
       if (P.block_ptr.size() < 2) JH_THROW("discretisation has no device blocks (use JH_REORDER_BLOCKS or a partition)");
       np = (int64_t)P.block_ptr.size() - 1;
-      for (int64_t b = 0; b < np; ++b)
-        for (int32_t i = P.block_ptr[b]; i < P.block_ptr[b + 1]; ++i) part[i] = (int32_t)b;
+      parallel_ranges(np, 64, [&](int64_t p0, int64_t p1) {
+        for (int64_t b = p0; b < p1; ++b)
+          for (int32_t i = P.block_ptr[b]; i < P.block_ptr[b + 1]; ++i) part[i] = (int32_t)b;
+      });
     } else if (nparts > 1) {
       JH_THROW("nparts > 1 requires an explicit partition vector (generate_lookup, partitioning.jl:25-27)");
     }
     M->nparts = np;
+    const bool device_blocks = !partition && nparts == -1;  // the parts are the device blocks: consecutive device rows, in order
     std::vector<int64_t> psize(np, 0);
-    for (int64_t i = 0; i < n; ++i) psize[part[i]]++;
+    if (device_blocks) for (int64_t b = 0; b < np; ++b) psize[b] = P.block_ptr[b + 1] - P.block_ptr[b];
+    else for (int64_t i = 0; i < n; ++i) psize[part[i]]++;
     int64_t maxrows = 0;
     for (auto s : psize) { if (s == 0) JH_THROW("empty block in partition (partitioning.jl:47)"); maxrows = std::max(maxrows, s); }
     M->max_block_rows = maxrows;
@@ -2037,7 +2041,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     std::vector<int64_t> pstart(np + 1, 0);
     for (int64_t b = 0; b < np; ++b) pstart[b + 1] = pstart[b] + psize[b];
     std::vector<int32_t> prow(n);
-    {
+    if (device_blocks) {  // (the counting sort below is the identity here)
+      parallel_ranges(n, 1 << 18, [&](int64_t b, int64_t e) { std::iota(prow.begin() + b, prow.begin() + e, (int32_t)b); });
+    } else {
       std::vector<int64_t> cur(pstart.begin(), pstart.end() - 1);
       for (int64_t i = 0; i < n; ++i) prow[cur[part[i]]++] = (int32_t)i;
     }
@@ -2198,8 +2204,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     M->l_lev.resize(n);
     M->u_lev.resize(n);
     if (maxlev >= 65536) JH_THROW("more than 65535 dependency levels");
-    for (int64_t t = 0; t < n; ++t) M->l_lev[t] = (uint16_t)flev[order[t]];
-    for (int64_t pos = 0; pos < n; ++pos) M->u_lev[pos] = (uint16_t)blev[order[uord[pos]]];
+    parallel_ranges(n, 1 << 16, [&](int64_t b, int64_t e) {
+      for (int64_t t = b; t < e; ++t) { M->l_lev[t] = (uint16_t)flev[order[t]]; M->u_lev[t] = (uint16_t)blev[order[uord[t]]]; }
+    });
     // fused halo pack: (block, local row) of every send row of the discretisation's halo plan
     if (lds && A->disc && A->disc->halo.active && A->disc->halo.n_send > 0) {
       const auto &H = A->disc->halo;

@@ -70,11 +70,16 @@ static inline int64_t setup_cores() {
   }();
   return cached;
 }
-template <class F>
-static inline void parallel_ranges(int64_t n, int64_t min_per_thread, F &&fn) {
+// host threads of the set-up: setup_cores(), or JH_SETUP_THREADS; at most 64
+static inline int setup_threads() {
   int64_t nt = setup_cores();
   if (const char *e = getenv("JH_SETUP_THREADS")) nt = atoi(e);
-  nt = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nt, 64), n / std::max<int64_t>(1, min_per_thread)));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(nt, 64));
+}
+template <class F>
+static inline void parallel_ranges(int64_t n, int64_t min_per_thread, F &&fn) {
+  int64_t nt = setup_threads();
+  nt = std::max<int64_t>(1, std::min<int64_t>(nt, n / std::max<int64_t>(1, min_per_thread)));
   if (nt <= 1) { fn((int64_t)0, n); return; }
   std::vector<std::thread> th;
   std::vector<std::exception_ptr> err((size_t)nt);
@@ -100,6 +105,36 @@ static inline void parallel_team(int nt, F &&fn) {
   for (auto &x : th) x.join();
   for (auto &e : err) if (e) std::rethrow_exception(e);
 }
+// Stable counting sort on the set-up's threads: out[start[key[i]] ...] = i for i = 0 .. n-1 in ascending i per key; start has nkeys + 1
+// entries (filled here).  The same result as the serial two-pass loop, for any thread count.
+static inline void counting_sort_indices(const int32_t *key, int64_t n, int64_t nkeys, std::vector<int32_t> &start, int32_t *out) {
+  int nt = setup_threads();
+  if (n < (1 << 18) || (int64_t)nt * nkeys > n) nt = 1;
+  start.assign((size_t)nkeys + 1, 0);
+  if (nt == 1) {
+    for (int64_t i = 0; i < n; ++i) start[(size_t)key[i] + 1]++;
+    for (int64_t k = 0; k < nkeys; ++k) start[(size_t)k + 1] += start[(size_t)k];
+    std::vector<int32_t> cur(start.begin(), start.end() - 1);
+    for (int64_t i = 0; i < n; ++i) out[cur[(size_t)key[i]]++] = (int32_t)i;
+    return;
+  }
+  std::vector<std::vector<int32_t>> hist((size_t)nt);
+  parallel_team(nt, [&](int t, int) {
+    std::vector<int32_t> &h = hist[(size_t)t];
+    h.assign((size_t)nkeys, 0);
+    for (int64_t i = n * t / nt, e = n * (t + 1) / nt; i < e; ++i) h[(size_t)key[i]]++;
+  });
+  for (int64_t k = 0; k < nkeys; ++k) {  // per key: the threads' shares in thread order
+    int32_t run = start[(size_t)k];
+    for (int t = 0; t < nt; ++t) { const int32_t c = hist[(size_t)t][(size_t)k]; hist[(size_t)t][(size_t)k] = run; run += c; }
+    start[(size_t)k + 1] = run;
+  }
+  parallel_team(nt, [&](int t, int) {
+    std::vector<int32_t> &cur = hist[(size_t)t];
+    for (int64_t i = n * t / nt, e = n * (t + 1) / nt; i < e; ++i) out[cur[(size_t)key[i]]++] = (int32_t)i;
+  });
+}
+
 // Barrier of a parallel_team: spins briefly, then yields (the team may share cores with other set-up threads)
 struct TeamBarrier {
   const int nt;

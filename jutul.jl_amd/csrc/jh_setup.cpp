@@ -191,13 +191,8 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
   // (on a breadth-first renumbering of the owned cells: jh_partition.cpp)
   partition_on_bfs_numbering(nc, A.ptr.data(), A.nbr.data(), nullptr, fw ? A.sface.data() : nullptr, fw, fw_scale, nparts, 0.04, max_part, label.data(),
                              [&](const char *what) { pt.lap(what); });
-  std::vector<int32_t> cnt(nparts + 1, 0);
-  for (int64_t c = 0; c < nc; ++c) cnt[label[c] + 1]++;
-  block_ptr.assign(nparts + 1, 0);
-  for (int64_t b = 0; b < nparts; ++b) block_ptr[b + 1] = block_ptr[b] + cnt[b + 1];
   perm.resize(nc);
-  std::vector<int32_t> cur(block_ptr.begin(), block_ptr.end() - 1);
-  for (int64_t c = 0; c < nc; ++c) perm[cur[label[c]]++] = (int32_t)c;
+  counting_sort_indices(label.data(), nc, nparts, block_ptr, perm.data());  // every block's cells in ascending order
   // (the blocks are disjoint: one distance array serves all threads; centre_bfs_order resets the entries of its own cells)
   std::vector<int32_t> dist;
   resize_parallel(dist, A.ptr.size() - 1);
