@@ -91,3 +91,21 @@ def test_partition_with_groups_like_the_reference_tests(ja):
             assert len(set(p[np.array(g) - 1])) == 1, (kw, g, p[np.array(g) - 1])
     with pytest.raises(ValueError):
         dd.partition(N, 49, groups=[list(range(1, 11))])               # 41 contracted cells < 49 blocks
+
+
+def test_partition_does_not_depend_on_the_thread_count(monkeypatch):
+    """jh_partition_graph builds its adjacency and sweeps its top bisection jobs on all host cores: same parts for any thread count
+    (a 355k-cell scrambled lattice: above the size from which the sweeps run on thread teams; weighted, unweighted, multigraph)."""
+    import jutul_amd as ja
+    g = ja.tet_lattice_mesh(40, 39, 38, scramble=True)
+    N, nc = g["N"], g["nc"]
+    dup = np.concatenate([N, N[:, :100]], axis=1)
+    res = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("JH_SETUP_THREADS", threads)
+        res.append((dd.partition_graph(N, nc, 8, face_weights=g["T"]), dd.partition_graph(N, nc, 37), dd.partition_graph(dup, nc, 5)))
+    for r in res[1:]:
+        for a, b in zip(res[0], r):
+            assert np.array_equal(a, b)
+    sizes = np.bincount(res[0][1])[1:]
+    assert sizes.size == 37 and sizes.min() > 0.85 * nc / 37 and sizes.max() < 1.15 * nc / 37
