@@ -97,6 +97,7 @@ def test_partition_does_not_depend_on_the_thread_count(monkeypatch):
     """jh_partition_graph builds its adjacency and sweeps its top bisection jobs on all host cores: same parts for any thread count
     (a 355k-cell scrambled lattice: above the size from which the sweeps run on thread teams; weighted, unweighted, multigraph)."""
     import jutul_amd as ja
+    from jutul_amd import dd
     g = ja.tet_lattice_mesh(40, 39, 38, scramble=True)
     N, nc = g["N"], g["nc"]
     dup = np.concatenate([N, N[:, :100]], axis=1)
