@@ -71,6 +71,8 @@ int32_t jh_synchronize(jh_context ctx); /* synchronize(ctx), context.jl:72 */
  *   fused_product (0), fuse_gather (1)
  *   ilu_jagged (1), ilu_threads (0), ilu_factor_kernel (-1 = by pattern | 0 workgroup | 1 wavefront per block),
  *   ilu_factor_threads (0 = 512; rows-form programs 256), ilu_diag_factor (1), ilu_prog (1), ilu_factor_global (0),
+ *   ilu_lean_upload (0; 1 = with the chunk-jagged layout and the pivot-only / program factor kernels the row-major structure arrays are
+ *                    not uploaded -- written in a session without a GPU, to be validated before it becomes the default),
  *   ilu_factor_wave_per_row (long rows; read when the preconditioner is created: 1 = rows-form programs (scalar matrices) | 2 = instruction-form
  *                            programs, wavefront per row | 0 = thread per row)
  *   asm_pipe (1), asm_pipe2_wgs (0), block_order (0 bisection | 1 onion), block_weights (1: use the face weights of

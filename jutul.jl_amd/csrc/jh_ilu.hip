@@ -2684,31 +2684,50 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     lap("jagged layout + programs");
     // upload
     hipStream_t s = M->ctx->stream;
+    // Option ilu_lean_upload (default 0, to be validated on a GPU: JH_OPTIONS=ilu_lean_upload=1 over the GPU suite): with the
+    // chunk-jagged layout AND a factorisation that writes it directly (pivot-only / program kernels) the device reads chunk_ptr, the
+    // j* tables, rowmap16, flev_off / flev_ptr and blk_ptr only -- the row-major structure arrays (~0.7 GB at 10M cells) stay on the host.
+    bool lean = false;
     if (lds) {  // 16-bit copies for the chunked apply
-      std::vector<uint16_t> lc(M->l_col.begin(), M->l_col.end()), uc(M->u_col.begin(), M->u_col.end()), ur(M->u_row.begin(), M->u_row.end());
       std::vector<uint16_t> rm(n);
-      M->rowmap_local = true;
-      for (int64_t b = 0; b < nb; ++b)
-        for (int32_t t = M->blk_ptr[b]; t < M->blk_ptr[b + 1]; ++t) {
-          const int32_t off = M->rowmap[t] - M->blk_ptr[b];  // device row of ilu row t, relative to the block
-          if (off < 0 || off >= M->blk_ptr[b + 1] - M->blk_ptr[b]) { M->rowmap_local = false; continue; }
-          rm[M->rowmap[t]] = (uint16_t)(t - M->blk_ptr[b]);  // device row -> position inside the block
-        }
-      M->d_l_col16.upload(lc, s); M->d_u_col16.upload(uc, s); M->d_u_row16.upload(ur, s); M->d_rowmap16.upload(rm, s);
+      std::atomic<bool> local{true};
+      parallel_ranges(nb, 64, [&](int64_t bb0, int64_t bb1) {
+        for (int64_t b = bb0; b < bb1; ++b)
+          for (int32_t t = M->blk_ptr[b]; t < M->blk_ptr[b + 1]; ++t) {
+            const int32_t off = M->rowmap[t] - M->blk_ptr[b];  // device row of ilu row t, relative to the block
+            if (off < 0 || off >= M->blk_ptr[b + 1] - M->blk_ptr[b]) { local.store(false, std::memory_order_relaxed); continue; }
+            rm[M->rowmap[t]] = (uint16_t)(t - M->blk_ptr[b]);  // device row -> position inside the block
+          }
+      });
+      M->rowmap_local = local.load();
       if (!M->rowmap_local) M->jag = false;  // the jagged kernels read and write the vector in device order
+      lean = M->jag && M->prog && M->ctx->opt.ilu_lean_upload != 0;
+      if (!lean) {
+        std::vector<uint16_t> lc(M->l_col.size()), uc(M->u_col.size()), ur(M->u_row.size());
+        parallel_ranges((int64_t)lc.size(), 1 << 18, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) lc[i] = (uint16_t)M->l_col[i]; });
+        parallel_ranges((int64_t)uc.size(), 1 << 18, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) uc[i] = (uint16_t)M->u_col[i]; });
+        parallel_ranges((int64_t)ur.size(), 1 << 18, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) ur[i] = (uint16_t)M->u_row[i]; });
+        M->d_l_col16.upload(lc, s); M->d_u_col16.upload(uc, s); M->d_u_row16.upload(ur, s);
+      }
+      M->d_rowmap16.upload(rm, s);
     } else {
       M->jag = false;
     }
     if (!M->send_ptr.empty()) {
       M->d_send_ptr.upload(M->send_ptr, s); M->d_send_local.upload(M->send_local, s); M->d_send_slot.upload(M->send_slot, s);
     }
-    M->d_l_lev.upload(M->l_lev, s); M->d_u_lev.upload(M->u_lev, s);
-    M->d_rowmap.upload(M->rowmap, s); M->d_blk_ptr.upload(M->blk_ptr, s);
+    if (!lean) {
+      M->d_l_lev.upload(M->l_lev, s); M->d_u_lev.upload(M->u_lev, s);
+      M->d_rowmap.upload(M->rowmap, s);
+    }
+    M->d_blk_ptr.upload(M->blk_ptr, s);
     M->d_flev_off.upload(M->flev_off, s); M->d_flev_ptr.upload(M->flev_ptr, s);
-    M->d_blev_off.upload(M->blev_off, s); M->d_blev_ptr.upload(M->blev_ptr, s);
-    M->d_l_ptr.upload(M->l_ptr, s); M->d_l_col.upload(M->l_col, s); M->d_l_map.upload(M->l_map, s);
-    M->d_u_ptr.upload(M->u_ptr, s); M->d_u_col.upload(M->u_col, s); M->d_u_map.upload(M->u_map, s);
-    M->d_d_map.upload(M->d_map, s); M->d_u_row.upload(M->u_row, s); M->d_upos_of.upload(M->upos_of, s);
+    if (!lean) {
+      M->d_blev_off.upload(M->blev_off, s); M->d_blev_ptr.upload(M->blev_ptr, s);
+      M->d_l_ptr.upload(M->l_ptr, s); M->d_l_col.upload(M->l_col, s); M->d_l_map.upload(M->l_map, s);
+      M->d_u_ptr.upload(M->u_ptr, s); M->d_u_col.upload(M->u_col, s); M->d_u_map.upload(M->u_map, s);
+      M->d_d_map.upload(M->d_map, s); M->d_u_row.upload(M->u_row, s); M->d_upos_of.upload(M->upos_of, s);
+    }
     const int bb = P.bs * P.bs;
     if (!(M->jag && M->prog)) {  // row-major factor arrays: only for the kernels that still use them
       M->l_val.alloc(std::max<size_t>(M->l_col.size(), 1) * bb);

@@ -399,6 +399,7 @@ struct Comm;  // RCCL state (jh_comm.cpp)
   X(ilu_factor_wave_per_row, 1)                                                                                                \
   X(ilu_diag_factor, 1)       /* pivot-only kernels for triangle-free block patterns (set before jh_ilu0_create) */            \
   X(ilu_prog, 1)              /* factorisation programs (set before jh_ilu0_create) */                                         \
+  X(ilu_lean_upload, 0)       /* jagged layout + direct factor kernels: do not upload the row-major structure arrays (set before jh_ilu0_create; NOT yet run on a GPU) */                                         \
   X(ilu_factor_global, 0)     /* force the per-level refactorisation kernels (set before jh_ilu0_create) */                    \
   X(asm_pipe, 1)              /* persistent pipelined assembly kernel (scalar laws) */                                         \
   X(asm_pipe2_wgs, 0)         /* 2x2-block laws: workgroups per XCD of the pipelined kernel, 0 = tile kernel */                \
