@@ -90,7 +90,10 @@ matrix_layout(c::HIPContext) = c.matrix_layout
 float_type(::HIPContext) = Float64          # context.jl:76
 index_type(::HIPContext) = Int64            # context.jl:77 (host side; the device uses 0-based Int32)
 synchronize(c::HIPContext) = @jh :jh_synchronize (Handle,) c.handle
-transfer(::HIPContext, v) = v               # host arrays stay on the host; device copies live behind handles
+# host arrays stay on the host (device copies live behind handles).  Only the array method is specialised: a method
+# `transfer(::HIPContext, v)` would be ambiguous with the reference's `transfer(context, v::Real / ::NamedTuple / ::AbstractDict /
+# ::AbstractFloat / ::Integer)` (context.jl:15-60), which keep doing their conversions with float_type / index_type above
+transfer(::HIPContext, v::AbstractArray) = v
 
 const HIPModel = SimulationModel{<:Any, <:Any, <:Any, HIPContext}
 
