@@ -1999,14 +1999,18 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     jh::DeviceScope dev(M->ctx);  // (planning contexts: the symbolic phase and the layouts, nothing allocated or uploaded)
     const bool timing = M->ctx->opt.setup_timing != 0;
     auto tlast = std::chrono::steady_clock::now();
+    double mblast = timing ? setup_faulted_mb() : 0.0;
     auto lap = [&](const char *what) {
       if (!timing) return;
       auto nw = std::chrono::steady_clock::now();
-      fprintf(stderr, "[jutul_hip setup] ilu0: %-22s %.3f s\n", what, std::chrono::duration<double>(nw - tlast).count());
+      const double mb = setup_faulted_mb();
+      fprintf(stderr, "[jutul_hip setup] ilu0: %-22s %.3f s  %6.0f MB first-touched\n", what, std::chrono::duration<double>(nw - tlast).count(), mb - mblast);
       tlast = nw;
+      mblast = mb;
     };
     // part id per device row
-    std::vector<int32_t> part(n, 0);
+    std::vector<int32_t> part;
+    assign_prefaulted(part, (size_t)n, (int32_t)0);
     int64_t np = 1;
     if (partition) {
       np = 0;
@@ -2040,7 +2044,8 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     // rows of every part in ascending device-row order (counting sort)
     std::vector<int64_t> pstart(np + 1, 0);
     for (int64_t b = 0; b < np; ++b) pstart[b + 1] = pstart[b] + psize[b];
-    std::vector<int32_t> prow(n);
+    std::vector<int32_t> prow;
+    resize_parallel(prow, (size_t)n);
     if (device_blocks) {  // (the counting sort below is the identity here)
       parallel_ranges(n, 1 << 18, [&](int64_t b, int64_t e) { std::iota(prow.begin() + b, prow.begin() + e, (int32_t)b); });
     } else {
@@ -2048,7 +2053,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       for (int64_t i = 0; i < n; ++i) prow[cur[part[i]]++] = (int32_t)i;
     }
     // dependency levels inside each part (forward: strict-lower entries; backward: strict-upper entries)
-    std::vector<int32_t> flev(n, 0), blev(n, 0);
+    std::vector<int32_t> flev, blev;
+    assign_prefaulted(flev, (size_t)n, (int32_t)0);
+    assign_prefaulted(blev, (size_t)n, (int32_t)0);
     parallel_ranges(np, 16, [&](int64_t p0, int64_t p1) {
       for (int64_t p = p0; p < p1; ++p) {
         for (int64_t r = pstart[p]; r < pstart[p + 1]; ++r) {
@@ -2108,9 +2115,10 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     M->blev_ptr.assign(M->blev_off[nb], 0);
     M->max_levels = maxlev;
     // ilu ordering: rows of a block by (flev, device row); U-order: its ilu rows by (blev, ilu row) -- two counting sorts
-    std::vector<int32_t> order(n), ilu_of(n), uord(n);
-    M->upos_of.resize(n);
-    M->u_row.resize(n);
+    std::vector<int32_t> order, ilu_of, uord;
+    resize_parallel(order, (size_t)n); resize_parallel(ilu_of, (size_t)n); resize_parallel(uord, (size_t)n);
+    resize_parallel(M->upos_of, (size_t)n);
+    resize_parallel(M->u_row, (size_t)n);
     parallel_ranges(nb, 16, [&](int64_t b0, int64_t b1) {
       std::vector<int32_t> cnt;
       for (int64_t b = b0; b < b1; ++b) {
@@ -2140,9 +2148,9 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
     M->rowmap = order;
     lap("row order, level pointers");
     // L (forward order) and U (backward order) storage: count, prefix, fill
-    M->l_ptr.assign(n + 1, 0);
-    M->u_ptr.assign(n + 1, 0);
-    M->d_map.resize(n);
+    assign_prefaulted(M->l_ptr, (size_t)n + 1, (int32_t)0);
+    assign_prefaulted(M->u_ptr, (size_t)n + 1, (int32_t)0);
+    resize_parallel(M->d_map, (size_t)n);
     parallel_ranges(n, 1 << 16, [&](int64_t t0, int64_t t1) {
       for (int64_t t = t0; t < t1; ++t) {
         const int32_t i = order[t], j = order[uord[t]];
@@ -2160,10 +2168,10 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
       if (sl > INT32_MAX || su > INT32_MAX) JH_THROW("ILU(0): more than 2^31 - 1 entries in a factor");
     }
     for (int64_t t = 0; t < n; ++t) { M->l_ptr[t + 1] += M->l_ptr[t]; M->u_ptr[t + 1] += M->u_ptr[t]; }
-    M->l_col.resize(M->l_ptr[n]);
-    M->l_map.resize(M->l_ptr[n]);
-    M->u_col.resize(M->u_ptr[n]);
-    M->u_map.resize(M->u_ptr[n]);
+    resize_parallel(M->l_col, (size_t)M->l_ptr[n]);
+    resize_parallel(M->l_map, (size_t)M->l_ptr[n]);
+    resize_parallel(M->u_col, (size_t)M->u_ptr[n]);
+    resize_parallel(M->u_map, (size_t)M->u_ptr[n]);
     parallel_ranges(n, 1 << 16, [&](int64_t t0, int64_t t1) {
       for (int64_t t = t0; t < t1; ++t) {
         {
@@ -2201,8 +2209,8 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         M->factor_lds_bytes = bytes;
       }
     }
-    M->l_lev.resize(n);
-    M->u_lev.resize(n);
+    resize_parallel(M->l_lev, (size_t)n);
+    resize_parallel(M->u_lev, (size_t)n);
     if (maxlev >= 65536) JH_THROW("more than 65535 dependency levels");
     parallel_ranges(n, 1 << 16, [&](int64_t b, int64_t e) {
       for (int64_t t = b; t < e; ++t) { M->l_lev[t] = (uint16_t)flev[order[t]]; M->u_lev[t] = (uint16_t)blev[order[uord[t]]]; }
@@ -2292,14 +2300,18 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         const int64_t nchunks = M->chunk_ptr[nb];
         M->j_nslots = nchunks * 64;
         std::vector<int4> fdesc(nchunks + 4, make_int4(0, 0, 0, 0)), bdesc(nchunks + 4, make_int4(0, 0, 0, 0));  // + 4: read ahead
-        std::vector<uint32_t> frow(M->j_nslots, 0xffff0000u), brow(M->j_nslots, 0xffff0000u);
+        std::vector<uint32_t> frow, brow;
+        assign_prefaulted(frow, (size_t)M->j_nslots, 0xffff0000u);
+        assign_prefaulted(brow, (size_t)M->j_nslots, 0xffff0000u);
         // the jagged order permutes the entries inside a block: block b keeps the ranges [l_ptr[b0], l_ptr[b1]) / [u_ptr[b0], u_ptr[b1]),
         // so the blocks can be laid out independently -- on all host cores
         const size_t nlent = M->l_col.size(), nuent = M->u_col.size();
-        std::vector<uint16_t> jlc(nlent + 64, 0), juc(nuent + 64, 0);  // + 64: lanes past a diagonal's count load too
-        M->jl_map.assign(nlent, 0); M->ju_map.assign(nuent, 0);
-        M->jd_map.assign(M->j_nslots, -1);
-        M->jl_of_old.assign(nlent, -1); M->ju_of_old.assign(nuent, -1); M->jd_of_old.assign(n, -1);
+        std::vector<uint16_t> jlc, juc;  // + 64: lanes past a diagonal's count load too
+        assign_prefaulted(jlc, nlent + 64, (uint16_t)0);
+        assign_prefaulted(juc, nuent + 64, (uint16_t)0);
+        assign_prefaulted(M->jl_map, nlent, (int32_t)0); assign_prefaulted(M->ju_map, nuent, (int32_t)0);
+        assign_prefaulted(M->jd_map, (size_t)M->j_nslots, (int32_t)-1);
+        assign_prefaulted(M->jl_of_old, nlent, (int32_t)-1); assign_prefaulted(M->ju_of_old, nuent, (int32_t)-1); assign_prefaulted(M->jd_of_old, (size_t)n, (int32_t)-1);
         M->blk_lbase.assign(nb + 1, 0); M->blk_ubase.assign(nb + 1, 0); M->blk_prog.assign(nb + 1, 0);
         for (int64_t b = 0; b <= nb; ++b) { M->blk_lbase[b] = M->l_ptr[M->blk_ptr[b]]; M->blk_ubase[b] = M->u_ptr[M->blk_ptr[b]]; }
         lap("  jagged: arrays");
@@ -2312,8 +2324,11 @@ extern "C" int32_t jh_ilu0_create(jh_csr A, const int64_t *partition, int64_t np
         std::vector<char> rows_ok(nb, 0);
         std::vector<int> blk_vals(nb, 0);
         std::vector<char> blk_ok(nb, 1), blk_diag(nb, 1);  // blk_diag: every update of the block targets a pivot
-        std::vector<int32_t> jt_map(nlent, -1), jf_diag(M->j_nslots, -1);
-        std::vector<uint16_t> jf_bslot(M->j_nslots, 0);
+        std::vector<int32_t> jt_map, jf_diag;
+        assign_prefaulted(jt_map, nlent, (int32_t)-1);
+        assign_prefaulted(jf_diag, (size_t)M->j_nslots, (int32_t)-1);
+        std::vector<uint16_t> jf_bslot;
+        assign_prefaulted(jf_bslot, (size_t)M->j_nslots, (uint16_t)0);
         // The programs are what the program-driven kernels read; the pivot-only kernels (every update of every block lands on a
         // pivot: triangle-free block patterns -- the lattice, Cartesian and most TPFA grids) never do.  Where the static conditions of
         // those kernels hold, a block's program is therefore generated (its size and whether it is pivot-only are needed) but not

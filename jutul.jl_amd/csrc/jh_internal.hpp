@@ -261,11 +261,42 @@ struct SpinPacer {
   }
 };
 
-// v.resize(n) for the large set-up arrays.  (Touching the pages of the fresh allocation from all host cores before the
-// zero-fill was measured on the GPU box: no gain -- page faults are not what the set-up waits for -- so this is a plain resize.)
+// MB of memory this process has touched for the first time so far (minor page faults x page size): printed per set-up phase next
+// to the seconds (setup_timing = 1).  On virtualised hosts a first touch costs 1.5-3.5 s per GB on one thread (measured on the
+// build box, round 6), which makes fresh allocations the largest single term of the set-up there.
+double setup_faulted_mb();
+
+// Fresh memory of the large set-up arrays.  A vector of tens of MB is a new mapping whose pages are faulted in one by one by the
+// thread that fills it; on a virtualised host every such fault leaves the guest (build box, round 6: 1.6-6 s per GB on one thread,
+// 12 of the 20 s of a 10M-cell set-up).  prefault_pages asks the kernel to map the whole range in ONE call
+// (madvise MADV_POPULATE_WRITE, Linux >= 5.14: 0.3-0.4 s per GB on the same box, no worse than first touch on a healthy host);
+// where the call is not available nothing happens and the pages are faulted on first touch as before.  Ranges below 4 MB are left
+// alone.  (Touching the pages from all host cores instead was measured twice, GPU box round 4 and build box round 5: no gain.)
+void prefault_pages(void *p, size_t bytes);
+// v.resize(n) / v.assign(n, value) with the new storage mapped up front
 template <class T>
 static inline void resize_parallel(std::vector<T> &v, size_t n) {
+  if (n > v.capacity()) {
+    v.reserve(n);
+    prefault_pages((void *)(v.data() + v.size()), (n - v.size()) * sizeof(T));
+  }
   v.resize(n);
+}
+template <class T>
+static inline void assign_prefaulted(std::vector<T> &v, size_t n, const T &value) {
+  if (n > v.capacity()) {
+    v.clear();
+    v.reserve(n);
+    prefault_pages((void *)v.data(), n * sizeof(T));
+  }
+  v.assign(n, value);
+}
+template <class T>
+static inline void reserve_prefaulted(std::vector<T> &v, size_t n) {
+  if (n > v.capacity()) {
+    v.reserve(n);
+    prefault_pages((void *)(v.data() + v.size()), (n - v.size()) * sizeof(T));
+  }
 }
 
 // ---- graph partitioner (jh_partition.cpp): recursive bisection + Fiduccia-Mattheyses refinement --------------------------------

@@ -38,11 +38,13 @@ void Pattern::build_jagged() {
   const bool col16 = force ? force == 16 : n >= 3000000;
   // (only the column array of the chosen width is built: the other one is 100 / 200 MB at 10M rows)
   std::vector<int32_t> base(ns + 1, 0), jc(col16 ? 0 : nnzb + 64, 0);  // + 64: lanes past a diagonal's count load too
-  std::vector<uint16_t> src(nnzb + 64, 0);                // CSR slot of a jagged entry, relative to the first slot of its slice (< 512)
+  std::vector<uint16_t> src;
+  assign_prefaulted(src, (size_t)nnzb + 64, (uint16_t)0);                // CSR slot of a jagged entry, relative to the first slot of its slice (< 512)
   std::vector<uint8_t> cnt((size_t)ns * 16, 0), perm((size_t)ns * 64, 0);
   // 16-bit column codes: a slice's columns lie almost all in a window around its rows (the device order keeps neighbours close);
   // the few outside go to a per-slice list
-  std::vector<uint16_t> jc16(col16 ? nnzb + 64 : 0, 0);
+  std::vector<uint16_t> jc16;
+  assign_prefaulted(jc16, (size_t)(col16 ? nnzb + 64 : 0), (uint16_t)0);
   std::vector<int32_t> win((size_t)ns * 2, 0), far;
   // Slices are independent (no padding: slice s starts at entry rowptr[64 s]); only the lists of far columns are appended in slice
   // order -- every range of slices collects its own and the ranges are concatenated in order afterwards.  All host cores.

@@ -8,6 +8,9 @@
 #include <queue>
 #include <string>
 #include <cstdlib>
+#include <sys/mman.h>
+#include <sys/resource.h>
+#include <unistd.h>
 
 #include "jh_internal.hpp"
 
@@ -16,6 +19,20 @@ namespace jh {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 const std::string &last_error() { return g_err; }
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+void prefault_pages(void *p, size_t bytes) {
+  static const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+  if (!p || bytes < ((size_t)4 << 20)) return;
+  const uintptr_t a = ((uintptr_t)p + page - 1) & ~(uintptr_t)(page - 1), e = ((uintptr_t)p + bytes) & ~(uintptr_t)(page - 1);
+  if (e > a) (void)madvise((void *)a, (size_t)(e - a), MADV_POPULATE_WRITE);  // EINVAL on older kernels: first touch as before
+}
+double setup_faulted_mb() {
+  struct rusage ru;
+  if (getrusage(RUSAGE_SELF, &ru) != 0) return 0.0;
+  return (double)ru.ru_minflt * (double)sysconf(_SC_PAGESIZE) / 1048576.0;
+}
 
 // --------------------------------------------------------------------------------------------------------------
 // Pattern: tiles + upload
@@ -163,11 +180,14 @@ struct PhaseTimer {
   bool on = false;
   explicit PhaseTimer(bool enabled) : on(enabled) {}
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  double mb = setup_faulted_mb();
   void lap(const char *what) {
     if (!on) return;
     auto n = std::chrono::steady_clock::now();
-    fprintf(stderr, "[jutul_hip setup] %-28s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    const double m = setup_faulted_mb();
+    fprintf(stderr, "[jutul_hip setup] %-28s %.3f s  %6.0f MB first-touched\n", what, std::chrono::duration<double>(n - t).count(), m - mb);
     t = n;
+    mb = m;
   }
 };
 }  // namespace
@@ -191,7 +211,7 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
   // (on a breadth-first renumbering of the owned cells: jh_partition.cpp)
   partition_on_bfs_numbering(nc, A.ptr.data(), A.nbr.data(), nullptr, fw ? A.sface.data() : nullptr, fw, fw_scale, nparts, 0.04, max_part, label.data(),
                              [&](const char *what) { pt.lap(what); });
-  perm.resize(nc);
+  resize_parallel(perm, (size_t)nc);
   counting_sort_indices(label.data(), nc, nparts, block_ptr, perm.data());  // every block's cells in ascending order
   // (the blocks are disjoint: one distance array serves all threads; centre_bfs_order resets the entries of its own cells)
   std::vector<int32_t> dist;

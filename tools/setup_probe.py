@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--no-timing", action="store_true")
     ap.add_argument("--heap", action="store_true", help="library option setup_heap = 1 during the set-up (freed heap memory is kept and reused)")
+    ap.add_argument("--checksum", action="store_true", help="option plan_checksum = 1: print the 64-bit checksum of every table a device would be handed (bit-identity of two builds)")
     ap.add_argument("--cache", default="", help="npz file the generated mesh is kept in between runs (N, T, nc, nf)")
     args = ap.parse_args()
     if args.threads:
@@ -43,7 +44,7 @@ def main():
     print(f"mesh: {desc}, nc={mesh['nc']} nf={mesh['nf']} in {time.time() - t0:.2f} s", flush=True)
     N = 2 if args.law == "twophase" else 1
     for rep in range(args.repeat):
-        ctx = ja.HIPContext("host", setup_timing=0 if args.no_timing else 1, setup_heap=1 if args.heap else 0)
+        ctx = ja.HIPContext("host", setup_timing=0 if args.no_timing else 1, setup_heap=1 if args.heap else 0, plan_checksum=1 if args.checksum else 0)
         f0 = resource.getrusage(resource.RUSAGE_SELF).ru_minflt
         t0 = time.time()
         disc = ja.TwoPointPotentialFlowHardCoded(ctx, mesh["N"], mesh["nc"], block_n=N, reorder="blocks", face_weights=mesh["T"])
@@ -58,6 +59,11 @@ def main():
         print(f"[probe] page faults {(resource.getrusage(resource.RUSAGE_SELF).ru_minflt - f0) * 4 // 1024} MB (4 KB pages), setup_heap {int(args.heap)}")
         print(f"[probe] discretisation {t1 - t0:.3f} s   jagged layout {t2 - t1:.3f} s   ilu symbolic {t3 - t2:.3f} s   total {t3 - t0:.3f} s"
               f"   (spmv_info {info}, ilu {prec.info()})", flush=True)
+        if args.checksum:
+            import zlib
+            import numpy as np
+            perm, bp = disc.ordering()
+            print(f"[probe] plan_checksum {ctx.plan_checksum()}  ordering crc {zlib.crc32(np.ascontiguousarray(perm).tobytes())}  blocks {len(bp) - 1}", flush=True)
         del prec, A, disc, ctx
 
 
