@@ -89,48 +89,72 @@ struct Adj {
   std::vector<int32_t> sface;  // signed face id: +(f+1) if this cell is N[1,f], -(f+1) otherwise
 };
 
-static Adj build_adjacency(int64_t nc, int64_t nf, const int64_t *N) {
-  // all host cores: counts and cursors are bumped atomically, then every row is put back into ascending face order (what a
-  // serial fill produces) so that nothing downstream depends on the thread timing
+// Nhost (optional): the 32-bit copy of N the discretisation keeps, filled in the same pass.
+static Adj build_adjacency(int64_t nc, int64_t nf, const int64_t *N, int32_t *Nhost) {
+  // The input numbering may be arbitrary (the bench grid's is scrambled): counting and filling cell by cell would be one cache
+  // miss per half-face, twice.  Instead the half-faces are first distributed over BUCKETS of consecutive cells (a counting sort on
+  // the high bits of the cell id: sequential reads, one write stream per bucket), then every bucket -- 16 384 cells, its slice of
+  // every array fits the L2 of a core -- is counted and filled on its own.  Threads take face ranges in ascending order and write a
+  // bucket's entries in thread order, so a cell's entries arrive in ascending face order: the rows are what a serial fill in face
+  // order produces, for any thread count, without a sort.
   Adj A;
-  resize_parallel(A.ptr, (size_t)nc + 1);
-  int64_t *ptr = A.ptr.data();
-  parallel_ranges(nf, 1 << 18, [&](int64_t f0, int64_t f1) {
-    for (int64_t f = f0; f < f1; ++f) {
+  constexpr int64_t BW = 16384;  // cells per bucket (cell id within a bucket: 14 bits, kept in a 16-bit side array)
+  const int64_t nbk = (nc + BW - 1) / BW;
+  int nt = setup_threads();
+  if (nf < (1 << 16)) nt = 1;
+  nt = (int)std::max<int64_t>(1, std::min<int64_t>(nt, nf / 4096 + 1));
+  std::vector<std::vector<int64_t>> hist((size_t)nt);
+  parallel_team(nt, [&](int t, int) {
+    std::vector<int64_t> &h = hist[(size_t)t];
+    h.assign((size_t)nbk, 0);
+    for (int64_t f = nf * t / nt, f1 = nf * (t + 1) / nt; f < f1; ++f) {
       const int64_t l = N[2 * f], r = N[2 * f + 1];
       if (l < 1 || l > nc || r < 1 || r > nc)
         JH_THROW("neighborship entry out of range (utils.jl:822: max(N) <= nc)");
       if (l == r) JH_THROW("face connecting a cell to itself is not supported");
-      __atomic_fetch_add(&ptr[l], 1, __ATOMIC_RELAXED);
-      __atomic_fetch_add(&ptr[r], 1, __ATOMIC_RELAXED);
+      if (Nhost) { Nhost[2 * f] = (int32_t)l; Nhost[2 * f + 1] = (int32_t)r; }
+      h[(size_t)((l - 1) / BW)]++;
+      h[(size_t)((r - 1) / BW)]++;
     }
   });
-  for (int64_t c = 0; c < nc; ++c) A.ptr[c + 1] += A.ptr[c];
-  resize_parallel(A.nbr, (size_t)A.ptr[nc]);
-  resize_parallel(A.sface, (size_t)A.ptr[nc]);
-  std::vector<int64_t> cur;
-  resize_parallel(cur, (size_t)nc);
-  parallel_ranges(nc, 1 << 18, [&](int64_t b, int64_t e) { std::copy(A.ptr.begin() + b, A.ptr.begin() + e, cur.begin() + b); });
-  int64_t *cu = cur.data();
-  parallel_ranges(nf, 1 << 18, [&](int64_t f0, int64_t f1) {
-    for (int64_t f = f0; f < f1; ++f) {
+  std::vector<int64_t> bstart((size_t)nbk + 1, 0);
+  for (int64_t b = 0; b < nbk; ++b) {  // per bucket: the threads' shares in thread order
+    int64_t run = bstart[(size_t)b];
+    for (int t = 0; t < nt; ++t) { const int64_t c = hist[(size_t)t][(size_t)b]; hist[(size_t)t][(size_t)b] = run; run += c; }
+    bstart[(size_t)b + 1] = run;
+  }
+  const int64_t nhf = bstart[(size_t)nbk];
+  resize_parallel(A.ptr, (size_t)nc + 1);
+  resize_parallel(A.nbr, (size_t)nhf);
+  resize_parallel(A.sface, (size_t)nhf);
+  std::vector<uint16_t> lcell;  // cell of an entry, relative to its bucket
+  resize_parallel(lcell, (size_t)nhf);
+  parallel_team(nt, [&](int t, int) {  // entries in bucket order (inside a bucket: face order), written into the final arrays
+    int64_t *cur = hist[(size_t)t].data();
+    for (int64_t f = nf * t / nt, f1 = nf * (t + 1) / nt; f < f1; ++f) {
       const int64_t l = N[2 * f] - 1, r = N[2 * f + 1] - 1;
-      const int64_t pl = __atomic_fetch_add(&cu[l], 1, __ATOMIC_RELAXED), pr = __atomic_fetch_add(&cu[r], 1, __ATOMIC_RELAXED);
-      A.nbr[pl] = (int32_t)r;
-      A.sface[pl] = (int32_t)(f + 1);
-      A.nbr[pr] = (int32_t)l;
-      A.sface[pr] = -(int32_t)(f + 1);
+      const int64_t pl = cur[l / BW]++;
+      A.nbr[pl] = (int32_t)r; A.sface[pl] = (int32_t)(f + 1); lcell[pl] = (uint16_t)(l % BW);
+      const int64_t pr = cur[r / BW]++;
+      A.nbr[pr] = (int32_t)l; A.sface[pr] = -(int32_t)(f + 1); lcell[pr] = (uint16_t)(r % BW);
     }
   });
-  parallel_ranges(nc, 1 << 16, [&](int64_t c0, int64_t c1) {
-    for (int64_t c = c0; c < c1; ++c)
-      for (int64_t i = A.ptr[c] + 1; i < A.ptr[c + 1]; ++i) {  // insertion sort by face (rows are short)
-        const int32_t sf = A.sface[i], nb = A.nbr[i];
-        int64_t j = i;
-        for (; j > A.ptr[c] && std::abs(A.sface[j - 1]) > std::abs(sf); --j) { A.sface[j] = A.sface[j - 1]; A.nbr[j] = A.nbr[j - 1]; }
-        A.sface[j] = sf;
-        A.nbr[j] = nb;
+  A.ptr[0] = 0;
+  parallel_ranges(nbk, 4, [&](int64_t b0, int64_t b1) {  // every bucket: count per cell, row pointers, stable scatter by cell
+    std::vector<int32_t> cnt((size_t)BW + 1), tn, tf;
+    for (int64_t b = b0; b < b1; ++b) {
+      const int64_t e0 = bstart[(size_t)b], e1 = bstart[(size_t)b + 1], c0 = b * BW, ncb = std::min(BW, nc - c0);
+      std::fill(cnt.begin(), cnt.begin() + ncb + 1, 0);
+      for (int64_t e = e0; e < e1; ++e) cnt[(size_t)lcell[e] + 1]++;
+      for (int64_t c = 0; c < ncb; ++c) { cnt[(size_t)c + 1] += cnt[(size_t)c]; A.ptr[c0 + c + 1] = e0 + cnt[(size_t)c + 1]; }
+      tn.assign(A.nbr.begin() + e0, A.nbr.begin() + e1);
+      tf.assign(A.sface.begin() + e0, A.sface.begin() + e1);
+      for (int64_t e = e0; e < e1; ++e) {
+        const int64_t w = e0 + cnt[(size_t)lcell[e]]++;
+        A.nbr[w] = tn[(size_t)(e - e0)];
+        A.sface[w] = tf[(size_t)(e - e0)];
       }
+    }
   });
   return A;
 }
@@ -410,8 +434,7 @@ extern "C" int32_t jh_tpfa_create_weighted(jh_context ctx, int64_t nc, int64_t n
     d->N = block_n;
     PhaseTimer pt(ctx->opt.setup_timing != 0);
     resize_parallel(d->Nhost, (size_t)(2 * nf));
-    parallel_ranges(2 * nf, 1 << 18, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) d->Nhost[i] = (int32_t)N[i]; });  // (validated by build_adjacency)
-    Adj A = build_adjacency(nc, nf, N);
+    Adj A = build_adjacency(nc, nf, N, d->Nhost.data());  // (validates N and fills its 32-bit copy)
     pt.lap("adjacency");
     if (n_owned <= 0 || n_owned > nc) n_owned = nc;
 
