@@ -400,11 +400,17 @@ int32_t jh_comm_ipc_export(jh_context ctx, char *handle64);
 int32_t jh_comm_ipc_attach(jh_context ctx, const char *handles, int32_t *ok);
 int32_t jh_comm_ipc_enable(jh_context ctx, int32_t enable);
 /* exclusive = 1: no two ranks of the communicator share compute units (one process per GPU -- the deployment -- or CU-masked
- * contexts on one GPU).  The host knows, the library cannot.  With mailboxes enabled the BiCGStab loop then all-reduces its dot
+ * contexts on one GPU).  With mailboxes enabled the BiCGStab loop then all-reduces its dot
  * products (ext/JutulPartitionedArraysExt/krylov.jl:51-105) inside the kernels that consume them: workgroup 0 stores the local
  * sums into the peers' mailboxes, every wavefront collects the peers' sums and adds them in rank order (identical bits on all
  * ranks), and the push halo's signal / wait / copy (consistent!, linalg.jl:37-55) runs inside the product kernel.  Where ranks
- * share compute units a chip-filling kernel waiting for a peer would keep that peer off the chip: leave it 0 (default). */
+ * share compute units a chip-filling kernel waiting for a peer would keep that peer off the chip: leave it 0 (default).
+ * The library checks the declaration against what it has seen: jh_comm_ipc_attach exchanges the PCI bus ids of the ranks' devices
+ * (in-process ranks: their device numbers), and exclusive = 1 is an ERROR when two ranks sit on one device and this context has
+ * no CU mask (jh_context_set_cu_mask).  jh_comm_devices_distinct reports the observation: 1 every rank on a device of its own,
+ * 0 at least two ranks on one device, -1 not observed (mailboxes never attached) -- a host that has no better knowledge passes
+ * `distinct == 1` on as `exclusive`. */
+int32_t jh_comm_devices_distinct(jh_context ctx, int32_t *distinct);
 int32_t jh_comm_set_exclusive(jh_context ctx, int32_t exclusive);
 /* Self-test of that path, collective (every rank calls it, after jh_comm_ipc_enable(ctx, 1)): 16 launches of 256 one-wavefront
  * workgroups in which every wavefront collects the peers' sums, waits limited to 5 s; *ok = 1 if every wavefront held the sums in

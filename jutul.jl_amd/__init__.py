@@ -172,6 +172,13 @@ class HIPContext(_Handle):
         finishes its dot products over the ranks inside the consuming kernels (five launches per BiCGStab iteration)."""
         check(_L().jh_comm_set_exclusive(self.h, 1 if exclusive else 0))
 
+    def comm_devices_distinct(self):
+        """What the library has observed about the ranks' devices: True every rank on a device of its own, False at least two ranks
+        on one device (comm_set_exclusive(True) is then refused unless this context is CU-masked), None not observed yet."""
+        d = C.c_int32(-1)
+        check(_L().jh_comm_devices_distinct(self.h, C.byref(d)))
+        return None if d.value < 0 else bool(d.value)
+
     def comm_xrank_selftest(self):
         """Collective self-test of the consumer-side all-reduce (every rank calls it); True if this rank saw every sum right."""
         ok = C.c_int32(0)

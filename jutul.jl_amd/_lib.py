@@ -125,6 +125,7 @@ SIGNATURES = {
     "jh_comm_ipc_attach": [H, C.c_char_p, C.POINTER(C.c_int32)],
     "jh_comm_ipc_enable": [H, C.c_int32],
     "jh_comm_set_exclusive": [H, C.c_int32],
+    "jh_comm_devices_distinct": [H, C.POINTER(C.c_int32)],
     "jh_comm_xrank_selftest": [H, C.POINTER(C.c_int32)],
     "jh_halo_ipc_export": [H, C.c_char_p],
     "jh_halo_ipc_attach": [H, C.c_char_p, I64P, I64P, C.POINTER(C.c_int32)],

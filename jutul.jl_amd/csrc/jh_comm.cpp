@@ -75,6 +75,7 @@ struct LocalGroup {
   std::condition_variable cv;
   int arrived = 0;
   uint64_t gen = 0;
+  std::vector<int> dev;                             // device of every rank's context (-1: planning context), jh_comm_init_local
   std::vector<std::vector<double>> slot;            // per rank contribution (allreduce)
   std::vector<std::vector<std::vector<double>>> box;  // box[src][dst] halo payload
   void barrier() {
@@ -95,6 +96,9 @@ struct Comm {
   DevBuf<Mailbox *> d_mail_peer;
   uint64_t mail_epoch = 0;  // scalar all-reduces enqueued so far (every rank enqueues the same sequence; see Mailbox)
   bool exclusive_cus = false;  // every rank has compute units of its own (jh_comm_set_exclusive): kernels may wait for peers in all wavefronts
+  // what the library has observed about the ranks' devices: -1 nothing yet, 0 all ranks on devices of their own, 1 at least two
+  // ranks on one device (PCI bus ids exchanged through the mailboxes by jh_comm_ipc_attach; in-process ranks: their device numbers)
+  int shared_device = -1, shared_a = -1, shared_b = -1;
   // time limit of the in-solve waits in 100 MHz ticks (JH_COMM_TIMEOUT_S; default 600 s: ranks may legitimately enter a reduction
   // far apart -- lazy first-solve set-up, JIT compilation on one rank, several ranks time-sharing a GPU -- and a timeout is sticky)
   uint64_t wait_ticks = 60000000000ull;
@@ -346,6 +350,7 @@ extern "C" int32_t jh_comm_local_group_create(int32_t nranks, void **group) {
     auto *G = new LocalGroup();
     G->n = nranks;
     G->slot.resize(nranks);
+    G->dev.assign((size_t)nranks, -2);  // -2: rank not initialised yet
     G->box.assign(nranks, std::vector<std::vector<double>>(nranks));
     *group = G;
   });
@@ -356,7 +361,7 @@ extern "C" int32_t jh_comm_local_group_destroy(void *group) {
 extern "C" int32_t jh_comm_init_local(jh_context ctx, void *group, int32_t rank) {
   return guard([&] {
     if (!ctx || !group) JH_THROW("null argument");
-    jh::require_device(ctx);
+    // (planning contexts may join: the communicator's bookkeeping is host state; everything that computes refuses them)
     if (ctx->comm) JH_THROW("communicator already initialised");
     auto *G = (LocalGroup *)group;
     if (rank < 0 || rank >= G->n) JH_THROW("rank out of range");
@@ -364,6 +369,10 @@ extern "C" int32_t jh_comm_init_local(jh_context ctx, void *group, int32_t rank)
     c->local = G;
     c->nranks = G->n;
     c->rank = rank;
+    {
+      std::lock_guard<std::mutex> lk(G->m);
+      G->dev[(size_t)rank] = ctx->plan_only ? -1 : ctx->device;
+    }
     ctx->comm = c.release();
   });
 }
@@ -489,8 +498,59 @@ extern "C" int32_t jh_comm_ipc_attach(jh_context ctx, const char *handles, int32
       if (c.mail_err->code) good = false;
       for (int i = 0; i < n; ++i) good = good && got[i] == want[i];
     }
+    if (good) {
+      // Which ranks sit on which device: every rank contributes a 48-bit digest of its device's PCI bus id (exact in a double) at
+      // its own position of a zero vector, sums over the ranks, MAIL_MAX_VALUES ranks per reduction.  Equal digests = one device:
+      // jh_comm_set_exclusive(ctx, 1) is then refused unless the context is CU-masked.
+      char bus[64] = {0};
+      JH_HIP(hipDeviceGetPCIBusId(bus, (int)sizeof(bus), ctx->device));
+      uint64_t h = 0xcbf29ce484222325ull;
+      for (const char *q = bus; *q; ++q) h = (h ^ (uint64_t)(unsigned char)*q) * 0x100000001b3ull;
+      const double mine = (double)(((h ^ (h >> 48)) & 0xffffffffffffull) | 1ull);
+      std::vector<double> ids((size_t)c.nranks, 0.0);
+      for (int r0 = 0; r0 < c.nranks && good; r0 += MAIL_MAX_VALUES) {
+        const int n = std::min(MAIL_MAX_VALUES, c.nranks - r0);
+        double v[MAIL_MAX_VALUES] = {0};
+        if (c.rank >= r0 && c.rank < r0 + n) v[c.rank - r0] = mine;
+        jh::copy_h2d(dev, v, sizeof(double) * n, ctx->stream);
+        mailbox_allreduce(ctx, dev, n, 0, 500000000ull);
+        jh::copy_d2h(v, dev, sizeof(double) * n, ctx->stream);
+        JH_HIP(hipStreamSynchronize(ctx->stream));
+        if (c.mail_err->code) good = false;
+        for (int i = 0; i < n; ++i) ids[(size_t)(r0 + i)] = v[i];
+      }
+      if (good) {
+        c.shared_device = 0;
+        for (int a = 0; a < c.nranks && !c.shared_device; ++a)
+          for (int b = a + 1; b < c.nranks; ++b)
+            if (ids[(size_t)a] == ids[(size_t)b]) { c.shared_device = 1; c.shared_a = a; c.shared_b = b; break; }
+      }
+    }
     if (!good) clear_mail_error(c);  // the fallback path must stay usable
     *ok = good ? 1 : 0;
+  });
+}
+
+// 1: every rank of the communicator runs on a device of its own; 0: at least two ranks share one; -1: not observed yet (the
+// mailboxes were never attached).  What jh_comm_set_exclusive checks; for hosts that want to decide themselves.
+extern "C" int32_t jh_comm_devices_distinct(jh_context ctx, int32_t *distinct) {
+  return guard([&] {
+    if (!ctx || !ctx->comm || !distinct) JH_THROW("jh_comm_devices_distinct needs a communicator");
+    Comm &c = *ctx->comm;
+    if (c.local) {  // in-process ranks: compare the device numbers the ranks registered
+      LocalGroup &G = *c.local;
+      std::lock_guard<std::mutex> lk(G.m);
+      c.shared_device = -1;
+      bool all = true;
+      for (int d : G.dev) all = all && d != -2;
+      if (all) {
+        c.shared_device = 0;
+        for (int a = 0; a < G.n && !c.shared_device; ++a)
+          for (int b = a + 1; b < G.n; ++b)
+            if (G.dev[(size_t)a] == G.dev[(size_t)b]) { c.shared_device = 1; c.shared_a = a; c.shared_b = b; break; }
+      }
+    }
+    *distinct = c.shared_device < 0 ? -1 : (c.shared_device ? 0 : 1);
   });
 }
 
@@ -500,6 +560,17 @@ extern "C" int32_t jh_comm_ipc_attach(jh_context ctx, const char *handles, int32
 extern "C" int32_t jh_comm_set_exclusive(jh_context ctx, int32_t exclusive) {
   return guard([&] {
     if (!ctx || !ctx->comm) JH_THROW("no communicator");
+    if (exclusive != 0) {
+      // the liveness assumption, checked against what the library has seen: every wavefront of the chip-filling kernels spins until
+      // all peers have pushed, so two ranks on one device without CU masks of their own can keep each other off the chip
+      int32_t distinct = -1;
+      if (jh_comm_devices_distinct(ctx, &distinct) != 0) JH_THROW(jh::last_error());
+      if (distinct == 0 && ctx->ncu >= ctx->ncu_total)
+        JH_THROW("jh_comm_set_exclusive(1) refused: ranks " + std::to_string(ctx->comm->shared_a) + " and " + std::to_string(ctx->comm->shared_b) +
+                 " of the communicator run on the same device and this context has no CU mask (jh_context_set_cu_mask): kernels that wait "
+                 "for a peer in every wavefront would keep that peer off the chip.  Leave it 0 (reduction launches) or give every rank "
+                 "compute units of its own.");
+    }
     ctx->comm->exclusive_cus = exclusive != 0;
   });
 }
@@ -655,6 +726,7 @@ extern "C" int32_t jh_allreduce(jh_context ctx, double *values, int32_t n, int32
     if (!ctx) JH_THROW("null context");
     if (!ctx->comm || ctx->comm->nranks == 1) return;
     if (n > 16) JH_THROW("jh_allreduce handles at most 16 scalars");
+    jh::require_device(ctx);
     jh::select_device(ctx);
     double *dev = ctx->scalars.p + 16;
     jh::copy_h2d(dev, values, sizeof(double) * n, ctx->stream);

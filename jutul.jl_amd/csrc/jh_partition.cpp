@@ -465,6 +465,9 @@ void partition_on_bfs_numbering(int64_t nc, const int64_t *ptr, const int32_t *n
   resize_parallel(ptr2, (size_t)nc + 1);
   parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
     for (int64_t i = b; i < e; ++i) {
+      // (ord[] is an arbitrary place of the input arrays: the loop prefetches ahead of itself, here and in the fill below)
+      if (i + 16 < e) __builtin_prefetch(&ptr[ord[i + 16]]);
+      if (i + 8 < e) __builtin_prefetch(&nbr[ptr[ord[i + 8]]]);
       const int32_t c = ord[i];
       int64_t deg = 0;
       for (int64_t k = ptr[c]; k < ptr[c + 1]; ++k) deg += nbr[k] < nc;
@@ -478,6 +481,15 @@ void partition_on_bfs_numbering(int64_t nc, const int64_t *ptr, const int32_t *n
   if (weighted) resize_parallel(w2, (size_t)ptr2[nc]);
   parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
     for (int64_t i = b; i < e; ++i) {
+      if (i + 16 < e) __builtin_prefetch(&ptr[ord[i + 16]]);
+      if (i + 12 < e) { const int64_t k12 = ptr[ord[i + 12]]; __builtin_prefetch(&nbr[k12]); if (fw && sface && !wk) __builtin_prefetch(&sface[k12]); }
+      if (i + 6 < e) {
+        const int32_t c6 = ord[i + 6];
+        for (int64_t k = ptr[c6]; k < ptr[c6 + 1]; ++k) {
+          if (nbr[k] < nc) __builtin_prefetch(&newid[nbr[k]]);
+          if (fw && sface && !wk) __builtin_prefetch(&fw[std::abs(sface[k]) - 1]);
+        }
+      }
       const int32_t c = ord[i];
       int64_t w = ptr2[i];
       for (int64_t k = ptr[c]; k < ptr[c + 1]; ++k)

@@ -163,39 +163,66 @@ static Adj build_adjacency(int64_t nc, int64_t nf, const int64_t *N, int32_t *Nh
 // device ordering: compact blocks grown by BFS; blocks in creation order, cells in growth order
 // --------------------------------------------------------------------------------------------------------------
 // breadth-first order of one block's cells from a centre of the block (middle of a longest shortest path, two sweeps): the
-// dependency depth of the block's triangular solves becomes its radius.  lab[c] == b marks the block's cells; dist / bq scratch.
-static void centre_bfs_order(const Adj &A, const std::vector<int32_t> &lab, int32_t b, int32_t *cells, int64_t n,
-                             std::vector<int32_t> &dist, std::vector<int32_t> &bq) {
+// dependency depth of the block's triangular solves becomes its radius.  cells[0 .. n): the block's cells in ascending order.
+// The three sweeps run on a private copy of the block's subgraph (local ids = positions in cells[], neighbour order as in A): the
+// cells of a block are scattered over the host numbering, so every sweep over A itself would miss the cache on every cell; the
+// copy costs one such pass.  slot[] (one entry per cell of the grid, any content on entry, shared by all threads: the blocks are
+// disjoint) maps a cell to its position; an entry is trusted only if cells[] confirms it, so stale values of other blocks are harmless.
+struct CentreScratch { std::vector<int32_t> lptr, lnbr, dist, bq, out; };
+static void centre_bfs_order(const Adj &A, int32_t *cells, int64_t n, int32_t *slot, CentreScratch &S) {
   if (n < 3) return;
+  for (int64_t j = 0; j < n; ++j) {
+    if (j + 8 < n) __builtin_prefetch(&slot[cells[j + 8]], 1);
+    __atomic_store_n(&slot[cells[j]], (int32_t)j, __ATOMIC_RELAXED);
+  }
+  S.lptr.resize((size_t)n + 1);
+  S.lnbr.clear();
+  S.lptr[0] = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    if (j + 12 < n) __builtin_prefetch(&A.ptr[cells[j + 12]]);
+    if (j + 8 < n) __builtin_prefetch(&A.nbr[A.ptr[cells[j + 8]]]);
+    if (j + 4 < n) { const int32_t c4 = cells[j + 4]; for (int64_t k = A.ptr[c4]; k < A.ptr[c4 + 1]; ++k) __builtin_prefetch(&slot[A.nbr[k]]); }
+    const int32_t c = cells[j];
+    for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k) {
+      const int32_t o = A.nbr[k];
+      const uint32_t q = (uint32_t)__atomic_load_n(&slot[o], __ATOMIC_RELAXED);
+      if (q < (uint32_t)n && cells[q] == o) S.lnbr.push_back((int32_t)q);
+    }
+    S.lptr[(size_t)j + 1] = (int32_t)S.lnbr.size();
+  }
+  const int32_t *lp = S.lptr.data(), *ln = S.lnbr.data();
+  S.dist.resize((size_t)n);
+  int32_t *dist = S.dist.data();
+  std::vector<int32_t> &bq = S.bq;
   auto sweep = [&](int32_t s) {
     bq.clear();
     bq.push_back(s);
-    for (int64_t i = 0; i < n; ++i) dist[cells[i]] = -1;
+    std::fill(dist, dist + n, -1);
     dist[s] = 0;
     for (size_t h = 0; h < bq.size(); ++h) {
       const int32_t c = bq[h];
-      for (int64_t k = A.ptr[c]; k < A.ptr[c + 1]; ++k) {
-        const int32_t o = A.nbr[k];
-        if (lab[o] == b && dist[o] < 0) { dist[o] = dist[c] + 1; bq.push_back(o); }
+      for (int32_t k = lp[c]; k < lp[c + 1]; ++k) {
+        const int32_t o = ln[k];
+        if (dist[o] < 0) { dist[o] = dist[c] + 1; bq.push_back(o); }
       }
     }
     return bq.back();
   };
-  const int32_t u = sweep(cells[0]);
+  const int32_t u = sweep(0);
   const int32_t w = sweep(u);
   int32_t m = w;
   for (int32_t step = dist[w] / 2; step > 0; --step)
-    for (int64_t k = A.ptr[m]; k < A.ptr[m + 1]; ++k) {
-      const int32_t o = A.nbr[k];
-      if (lab[o] == b && dist[o] == dist[m] - 1) { m = o; break; }
+    for (int32_t k = lp[m]; k < lp[m + 1]; ++k) {
+      const int32_t o = ln[k];
+      if (dist[o] == dist[m] - 1) { m = o; break; }
     }
   sweep(m);
-  if ((int64_t)bq.size() == n) { std::copy(bq.begin(), bq.end(), cells); return; }
-  // not connected: the reached piece first, the rest in the given order
-  std::vector<int32_t> rest;
-  for (int64_t i = 0; i < n; ++i) if (dist[cells[i]] < 0) rest.push_back(cells[i]);
-  std::copy(bq.begin(), bq.end(), cells);
-  std::copy(rest.begin(), rest.end(), cells + bq.size());
+  // the reached piece first, the rest (not connected to it) in the given order
+  S.out.clear();
+  for (int32_t q : bq) S.out.push_back(cells[q]);
+  if ((int64_t)bq.size() < n)
+    for (int64_t j = 0; j < n; ++j) if (dist[j] < 0) S.out.push_back(cells[j]);
+  std::copy(S.out.begin(), S.out.end(), cells);
 }
 
 namespace {
@@ -237,13 +264,12 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
                              [&](const char *what) { pt.lap(what); });
   resize_parallel(perm, (size_t)nc);
   counting_sort_indices(label.data(), nc, nparts, block_ptr, perm.data());  // every block's cells in ascending order
-  // (the blocks are disjoint: one distance array serves all threads; centre_bfs_order resets the entries of its own cells)
+  // (the blocks are disjoint: one cell -> position array serves all threads, see centre_bfs_order)
   std::vector<int32_t> dist;
   resize_parallel(dist, A.ptr.size() - 1);
   parallel_ranges(nparts, 8, [&](int64_t b0, int64_t b1) {
-    std::vector<int32_t> bq;
-    for (int64_t b = b0; b < b1; ++b)
-      centre_bfs_order(A, label, (int32_t)b, perm.data() + block_ptr[b], block_ptr[b + 1] - block_ptr[b], dist, bq);
+    CentreScratch S;
+    for (int64_t b = b0; b < b1; ++b) centre_bfs_order(A, perm.data() + block_ptr[b], block_ptr[b + 1] - block_ptr[b], dist.data(), S);
   });
   pt.lap("  blocks: order inside");
 }
@@ -386,16 +412,12 @@ static void order_by_partition(const Adj &A, int64_t nc, const int64_t *partitio
   std::vector<int32_t> cur(block_ptr.begin(), block_ptr.end() - 1);
   for (int64_t c = 0; c < nc; ++c) perm[cur[partition[c] - 1]++] = (int32_t)c;  // findall order inside a part
   if (bfs_inside) {  // JH_REORDER_BLOCKS with a partition: the caller's blocks, ordered inside for short dependency chains
-    std::vector<int32_t> lab(nc);
-    for (int64_t c = 0; c < nc; ++c) lab[c] = (int32_t)(partition[c] - 1);
-    // (the parts are disjoint: one distance array serves all threads, as in blocks_by_bisection -- a private one per thread would
-    // be 4 bytes x cells x threads)
+    // (the parts are disjoint: one cell -> position array serves all threads, as in blocks_by_bisection)
     std::vector<int32_t> dist;
     resize_parallel(dist, (size_t)nc);
     parallel_ranges(np, 8, [&](int64_t b0, int64_t b1) {
-      std::vector<int32_t> bq;
-      for (int64_t b = b0; b < b1; ++b)
-        centre_bfs_order(A, lab, (int32_t)b, perm.data() + block_ptr[b], block_ptr[b + 1] - block_ptr[b], dist, bq);
+      CentreScratch S;
+      for (int64_t b = b0; b < b1; ++b) centre_bfs_order(A, perm.data() + block_ptr[b], block_ptr[b + 1] - block_ptr[b], dist.data(), S);
     });
   }
 }
@@ -504,11 +526,23 @@ extern "C" int32_t jh_tpfa_create_weighted(jh_context ctx, int64_t nc, int64_t n
       resize_parallel(ucount, (size_t)nc);
       std::vector<char> dup_in_range;
       parallel_ranges(nc, 65536, [&](int64_t b, int64_t e) {
-        std::vector<int32_t> nb;
+        // distinct neighbours of every host cell (rows are short: sorted by insertion on the stack; long rows take std::sort)
+        int32_t small[64];
+        std::vector<int32_t> big;
         for (int64_t h = b; h < e; ++h) {
-          nb.assign(A.nbr.begin() + A.ptr[h], A.nbr.begin() + A.ptr[h + 1]);
-          std::sort(nb.begin(), nb.end());
-          ucount[h] = (int32_t)(std::unique(nb.begin(), nb.end()) - nb.begin());
+          const int64_t k0 = A.ptr[h], deg = A.ptr[h + 1] - k0;
+          int32_t *nb = small;
+          if (deg > 64) { big.assign(A.nbr.begin() + k0, A.nbr.begin() + k0 + deg); std::sort(big.begin(), big.end()); nb = big.data(); }
+          else
+            for (int64_t j = 0; j < deg; ++j) {
+              const int32_t v = A.nbr[k0 + j];
+              int64_t q = j;
+              for (; q > 0 && small[q - 1] > v; --q) small[q] = small[q - 1];
+              small[q] = v;
+            }
+          int32_t u = deg > 0;
+          for (int64_t j = 1; j < deg; ++j) u += nb[j] != nb[j - 1];
+          ucount[h] = u;
         }
       });
       for (int64_t h = 0; h < nc; ++h) {
@@ -519,36 +553,65 @@ extern "C" int32_t jh_tpfa_create_weighted(jh_context ctx, int64_t nc, int64_t n
     pat->nnzb_host = hrp[nc];
     if (!ident || multigraph) resize_parallel(pat->nz_hslot, (size_t)pat->nnzb);
     if (multigraph) pat->shadow_flag.assign(pat->nnzb, 0);
-    // rows are independent: sorted device columns, signed face ids, diagonal slot, host slots -- on all host cores
+    // rows are independent: sorted device columns, signed face ids, diagonal slot, host slots -- on all host cores.  Device row i
+    // is host cell perm[i], an arbitrary place of the host arrays: the loop runs ahead of itself with prefetches (row pointer of
+    // row i + 12, neighbour list of row i + 8, the neighbours' device numbers of row i + 4).
+    struct Ent { int32_t col, sf, hcol; };
     parallel_ranges(nc, 4096, [&](int64_t r_begin, int64_t r_end) {
-      std::vector<std::pair<int32_t, int32_t>> tmp, tmph;
+      Ent small[64];
+      std::vector<Ent> big;
+      int32_t rk[64];
+      std::vector<int32_t> rkbig;
+      const int32_t *perm = ident ? nullptr : pat->perm.data(), *iperm = ident ? nullptr : pat->iperm.data();
       for (int64_t i = r_begin; i < r_end; ++i) {
-        int64_t h = ident ? i : pat->perm[i];
-        tmp.clear();
-        tmp.emplace_back((int32_t)i, 0);
-        for (int64_t k = A.ptr[h]; k < A.ptr[h + 1]; ++k)
-          tmp.emplace_back(ident ? A.nbr[k] : pat->iperm[A.nbr[k]], A.sface[k]);
+        if (!ident) {
+          if (i + 12 < r_end) __builtin_prefetch(&A.ptr[perm[i + 12]]);
+          if (i + 8 < r_end) { const int64_t k8 = A.ptr[perm[i + 8]]; __builtin_prefetch(&A.nbr[k8]); __builtin_prefetch(&A.sface[k8]); }
+          if (i + 4 < r_end) { const int32_t h4 = perm[i + 4]; for (int64_t k = A.ptr[h4]; k < A.ptr[h4 + 1]; ++k) __builtin_prefetch(&iperm[A.nbr[k]]); }
+        }
+        const int64_t h = ident ? i : perm[i];
+        const int64_t k0 = A.ptr[h], deg = A.ptr[h + 1] - k0, len = deg + 1;
+        Ent *t = small;
+        if (len > 64) { big.resize((size_t)len); t = big.data(); }
         // ascending device columns; parallel faces (multigraph) by ascending face id: the last one is the pair's primary slot
-        std::sort(tmp.begin(), tmp.end(), [](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) {
-          return a.first != b.first ? a.first < b.first : std::abs(a.second) < std::abs(b.second);
-        });
-        int32_t base = pat->rowptr[i];
-        for (size_t j = 0; j < tmp.size(); ++j) {
-          pat->col[base + j] = tmp[j].first;
-          d->nz_face[base + j] = tmp[j].second;
-          if (tmp[j].first == (int32_t)i) pat->diag[i] = base + (int32_t)j;
-          if (multigraph && j + 1 < tmp.size() && tmp[j + 1].first == tmp[j].first) pat->shadow_flag[base + j] = 1;
+        auto before = [](const Ent &x, const Ent &y) { return x.col != y.col ? x.col < y.col : std::abs(x.sf) < std::abs(y.sf); };
+        t[0] = Ent{(int32_t)i, 0, (int32_t)h};
+        for (int64_t j = 0; j < deg; ++j) {
+          const int32_t o = A.nbr[k0 + j];
+          const Ent v{ident ? o : iperm[o], A.sface[k0 + j], o};
+          if (len > 64) { t[j + 1] = v; continue; }
+          int64_t q = j + 1;
+          for (; q > 0 && before(v, t[q - 1]); --q) t[q] = t[q - 1];
+          t[q] = v;
+        }
+        if (len > 64) std::sort(t, t + len, before);
+        const int32_t base = pat->rowptr[i];
+        for (int64_t j = 0; j < len; ++j) {
+          pat->col[base + j] = t[j].col;
+          d->nz_face[base + j] = t[j].sf;
+          if (t[j].col == (int32_t)i) pat->diag[i] = base + (int32_t)j;
+          if (multigraph && j + 1 < len && t[j + 1].col == t[j].col) pat->shadow_flag[base + j] = 1;
         }
         if (!ident || multigraph) {
           // host slot = position of host column in host row h (ascending distinct host columns incl. diagonal); shadow slots
           // map to the spare slot behind the host pattern (jh_csr_get/set_values)
-          tmph.clear();
-          for (size_t j = 0; j < tmp.size(); ++j) tmph.emplace_back(ident ? tmp[j].first : pat->perm[tmp[j].first], (int32_t)j);
-          std::sort(tmph.begin(), tmph.end());
+          int32_t *r = rk;
+          if (len > 64) { rkbig.resize((size_t)len); r = rkbig.data(); }
+          for (int64_t j = 0; j < len; ++j) r[j] = (int32_t)j;
+          // entries by (host column, position): equal host columns (parallel faces) share a rank
+          auto hless = [&](int32_t x, int32_t y) { return t[x].hcol != t[y].hcol ? t[x].hcol < t[y].hcol : x < y; };
+          if (len > 64) std::sort(r, r + len, hless);
+          else
+            for (int64_t j = 1; j < len; ++j) {
+              const int32_t v = r[j];
+              int64_t q = j;
+              for (; q > 0 && hless(v, r[q - 1]); --q) r[q] = r[q - 1];
+              r[q] = v;
+            }
           int64_t rank = -1;
-          for (size_t j = 0; j < tmph.size(); ++j) {
-            if (j == 0 || tmph[j].first != tmph[j - 1].first) ++rank;
-            const int32_t slot = base + tmph[j].second;
+          for (int64_t j = 0; j < len; ++j) {
+            if (j == 0 || t[r[j]].hcol != t[r[j - 1]].hcol) ++rank;
+            const int32_t slot = base + r[j];
             pat->nz_hslot[slot] = (multigraph && pat->shadow_flag[slot]) ? (int32_t)pat->nnzb_host : (int32_t)(hrp[h] + rank);
           }
         }

@@ -569,9 +569,12 @@ struct HIPDistributedExecutor <: Jutul.JutulExecutor
     nranks::Int
 end
 
-# exclusive_devices: every rank drives a GPU of its own (the deployment: one process per GPU) -- the Krylov loop then finishes its
-# dot products over the ranks inside the consuming kernels (jh_comm_set_exclusive); pass false when ranks share a device.
-function setup_distributed!(ctx::HIPContext, nranks::Integer, rank::Integer, bcast, allgather; exclusive_devices::Bool = true)
+# exclusive_devices: does every rank drive a GPU (or a CU-masked share of one) of its own?  The Krylov loop then finishes its dot
+# products over the ranks inside the consuming kernels (jh_comm_set_exclusive), whose wavefronts all wait for the peers -- on a
+# device shared without CU masks that wait can keep the peer off the chip.  `nothing` (default): what the library observed when the
+# mailboxes were attached (PCI bus ids of the ranks' devices, jh_comm_devices_distinct); `true` on a shared device is an error of
+# jh_comm_set_exclusive, not a hang.
+function setup_distributed!(ctx::HIPContext, nranks::Integer, rank::Integer, bcast, allgather; exclusive_devices::Union{Nothing, Bool} = nothing)
     id = zeros(UInt8, 128)
     if rank == 0
         @jh :jh_comm_unique_id (Ptr{UInt8},) id
@@ -586,11 +589,17 @@ function setup_distributed!(ctx::HIPContext, nranks::Integer, rank::Integer, bca
     @jh :jh_comm_ipc_attach (Handle, Ptr{UInt8}, Ref{Int32}) ctx.handle all ok
     everyone = minimum(allgather(ok[])) == 1
     @jh :jh_comm_ipc_enable (Handle, Int32) ctx.handle Int32(everyone)
+    if everyone && isnothing(exclusive_devices)
+        distinct = Ref{Int32}(-1)
+        @jh :jh_comm_devices_distinct (Handle, Ref{Int32}) ctx.handle distinct
+        exclusive_devices = minimum(allgather(distinct[])) == 1
+    end
+    exclusive = everyone && exclusive_devices === true
     xok = Ref{Int32}(0)
-    if everyone && exclusive_devices   # collective self-test of the consumer-side all-reduce: all ranks or none
+    if exclusive   # collective self-test of the consumer-side all-reduce: all ranks or none
         @jh :jh_comm_xrank_selftest (Handle, Ref{Int32}) ctx.handle xok
     end
-    @jh :jh_comm_set_exclusive (Handle, Int32) ctx.handle Int32(everyone && exclusive_devices && minimum(allgather(xok[])) == 1)
+    @jh :jh_comm_set_exclusive (Handle, Int32) ctx.handle Int32(exclusive && minimum(allgather(xok[])) == 1)
     info = zeros(Int64, 8)
     @jh :jh_comm_info (Handle, Ptr{Int64}) ctx.handle info
     info[1] == nranks && info[3] == nranks || error("communicator has $(info[1]) ranks ($(info[3]) in RCCL), expected $nranks")
