@@ -287,6 +287,10 @@ def main():
             attached_all = bool(int(flag[0]))
             mailbox = attached_all and os.environ.get("JH_BENCH_NO_MAILBOX") != "1"
             ctx.comm_ipc_enable(mailbox)
+            # the library's own observation (PCI bus ids of the ranks' devices, exchanged by the attach) overrides the launcher's
+            # guess: two ranks on one unmasked device never get the consumer-side waits (comm_set_exclusive would refuse them)
+            if mailbox and exclusive and ctx.comm_devices_distinct() is False and not cu_masked:
+                exclusive = False
             xr_ok = False
             if exclusive and mailbox:   # collective self-test of the consumer-side all-reduce: all ranks or none (like the mailboxes)
                 try:

@@ -533,24 +533,26 @@ extern "C" int32_t jh_comm_ipc_attach(jh_context ctx, const char *handles, int32
 
 // 1: every rank of the communicator runs on a device of its own; 0: at least two ranks share one; -1: not observed yet (the
 // mailboxes were never attached).  What jh_comm_set_exclusive checks; for hosts that want to decide themselves.
+static int devices_distinct(Comm &c) {
+  if (c.local) {  // in-process ranks: compare the device numbers the ranks registered
+    LocalGroup &G = *c.local;
+    std::lock_guard<std::mutex> lk(G.m);
+    c.shared_device = -1;
+    bool all = true;
+    for (int d : G.dev) all = all && d != -2;
+    if (all) {
+      c.shared_device = 0;
+      for (int a = 0; a < G.n && !c.shared_device; ++a)
+        for (int b = a + 1; b < G.n; ++b)
+          if (G.dev[(size_t)a] == G.dev[(size_t)b]) { c.shared_device = 1; c.shared_a = a; c.shared_b = b; break; }
+    }
+  }
+  return c.shared_device < 0 ? -1 : (c.shared_device ? 0 : 1);
+}
 extern "C" int32_t jh_comm_devices_distinct(jh_context ctx, int32_t *distinct) {
   return guard([&] {
     if (!ctx || !ctx->comm || !distinct) JH_THROW("jh_comm_devices_distinct needs a communicator");
-    Comm &c = *ctx->comm;
-    if (c.local) {  // in-process ranks: compare the device numbers the ranks registered
-      LocalGroup &G = *c.local;
-      std::lock_guard<std::mutex> lk(G.m);
-      c.shared_device = -1;
-      bool all = true;
-      for (int d : G.dev) all = all && d != -2;
-      if (all) {
-        c.shared_device = 0;
-        for (int a = 0; a < G.n && !c.shared_device; ++a)
-          for (int b = a + 1; b < G.n; ++b)
-            if (G.dev[(size_t)a] == G.dev[(size_t)b]) { c.shared_device = 1; c.shared_a = a; c.shared_b = b; break; }
-      }
-    }
-    *distinct = c.shared_device < 0 ? -1 : (c.shared_device ? 0 : 1);
+    *distinct = devices_distinct(*ctx->comm);
   });
 }
 
@@ -563,9 +565,7 @@ extern "C" int32_t jh_comm_set_exclusive(jh_context ctx, int32_t exclusive) {
     if (exclusive != 0) {
       // the liveness assumption, checked against what the library has seen: every wavefront of the chip-filling kernels spins until
       // all peers have pushed, so two ranks on one device without CU masks of their own can keep each other off the chip
-      int32_t distinct = -1;
-      if (jh_comm_devices_distinct(ctx, &distinct) != 0) JH_THROW(jh::last_error());
-      if (distinct == 0 && ctx->ncu >= ctx->ncu_total)
+      if (devices_distinct(*ctx->comm) == 0 && ctx->ncu >= ctx->ncu_total)
         JH_THROW("jh_comm_set_exclusive(1) refused: ranks " + std::to_string(ctx->comm->shared_a) + " and " + std::to_string(ctx->comm->shared_b) +
                  " of the communicator run on the same device and this context has no CU mask (jh_context_set_cu_mask): kernels that wait "
                  "for a peer in every wavefront would keep that peer off the chip.  Leave it 0 (reduction launches) or give every rank "

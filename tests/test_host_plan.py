@@ -302,3 +302,20 @@ def test_long_thin_graphs_do_not_pay_for_the_thread_teams(ja, monkeypatch):
             sums.append(ctx.plan_checksum())
             assert dt < 30.0, (name, threads, dt)
         assert sums[0] == sums[1], name
+
+
+def test_exclusive_ranks_on_one_device_are_refused(ja):
+    """jh_comm_set_exclusive(1) is a liveness promise (every wavefront of the chip-filling kernels spins until all peers have
+    pushed): the library checks it against the devices it has seen and refuses when two ranks share one without CU masks.  Here:
+    two in-process ranks on planning contexts (the same "device"); the host's own check of the observation works too."""
+    group = ja.LocalCommGroup(2)
+    a, b = ja.HIPContext("host"), ja.HIPContext("host")
+    a.comm_init_local(group, 0)
+    assert a.comm_devices_distinct() is None        # rank 1 has not joined yet: nothing observed
+    a.comm_set_exclusive(False)                     # (turning it off is always fine)
+    b.comm_init_local(group, 1)
+    assert a.comm_devices_distinct() is False and b.comm_devices_distinct() is False
+    with pytest.raises(ja.JutulHIPError, match="same device.*CU mask"):
+        a.comm_set_exclusive(True)
+    with pytest.raises(ja.JutulHIPError, match="has no device"):
+        a.allreduce([1.0])                          # a planning context never computes, communicator or not

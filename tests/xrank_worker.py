@@ -56,6 +56,7 @@ dist.all_reduce(ok, op=dist.ReduceOp.MIN)
 assert int(ok[0]) == 1
 ctx.comm_ipc_enable(True)
 assert ctx.comm_xrank_selftest()   # (collective)
+assert ctx.comm_devices_distinct() is False   # one GPU ... but every rank is CU-masked: the promise below is accepted
 ctx.comm_set_exclusive(True)
 assert ctx.comm_info()["consumer_allreduce"]
 disc, law, sub = dd.setup_rank_problem(ctx, g["N"], part, rank, T, g["volumes"], X0, kind=kind, block_n=nblk, sources=src,
