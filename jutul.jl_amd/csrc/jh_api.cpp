@@ -75,7 +75,8 @@ Bounce &bounce() {
 // hipStreamSynchronize directly -- the path on which round 3 saw "Memory access fault by GPU" once in ~10 runs of the GPU suite and
 // which no isolated reproducer (tools/micro/upload_lifetime.hip) could break since; kept switchable so that the second copy can
 // be measured off and the fault hunted with the real workload (tools/upload_soak.sh).
-std::atomic<int> g_upload_bounce{1};
+// (process-wide; JH_UPLOAD_BOUNCE=0 in the environment of the PROCESS sets the initial state: tools/upload_soak.sh)
+std::atomic<int> g_upload_bounce{[] { const char *e = getenv("JH_UPLOAD_BOUNCE"); return (e && e[0] == '0') ? 0 : 1; }()};
 bool page_locked(const void *host) {
   if (!g_upload_bounce.load(std::memory_order_relaxed)) return true;  // (treated like page-locked memory: copied directly)
   hipPointerAttribute_t a;
@@ -146,20 +147,20 @@ inline void check(int32_t rc) {  // nested C-ABI call failed: the message is alr
 
 // ---- options ----------------------------------------------------------------------------------------------------
 namespace jh {
-// Option setup_heap (PROCESS-WIDE, glibc): the set-up allocates and frees ~5 GB of tables and temporaries per 10M cells, and every
-// vector of more than the allocator's mmap threshold is a fresh mapping whose pages are faulted in one by one, zeroed by the kernel
-// and handed back on free -- 1.2M page faults per set-up, on the thread that fills the vector.  1: such blocks come from the heap
-// and freed heap memory is kept, so later tables reuse pages that are already mapped (10M cells: 4.2 -> 2.1 GB faulted during a
-// first set-up, ~0 during a second one while the option stays on); 0 (the default state of the process): thresholds back to glibc's
-// steady-state values and the free heap memory returned to the system (malloc_trim).  A HOST decision -- it changes how every
-// malloc of the process behaves while it is on -- hence an option, off unless asked for: bench.py switches it on around its set-up.
+// Option setup_heap (PROCESS-WIDE, glibc): the set-up allocates and frees ~4 GB of tables and temporaries per 10M cells, and every
+// vector of more than the allocator's mmap threshold is a fresh mapping handed back on free.  1: the trim threshold is raised so
+// that freed heap memory is kept and later tables reuse pages that are already mapped; 0: the free heap memory is returned to the
+// system (malloc_trim).  What it changes for the rest of the process, permanently: glibc stops adapting its mmap / trim thresholds
+// dynamically once either has been set by hand (mallopt), and switching the option off does not bring that back -- it sets the
+// values the dynamic scheme converges to in a program that has freed large blocks (32 MB / 64 MB).  A HOST decision, hence an
+// option, off unless asked for, and never read from JH_OPTIONS (a per-context seed must not flip process-wide state).  Since
+// round 6 the large tables are mapped up front (prefault_pages), which removes most of what this option was for.
 static void apply_setup_heap(bool on) {
 #if defined(__GLIBC__)
   if (on) {
-    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);  // (glibc's maximum: larger values are rejected)
     mallopt(M_TRIM_THRESHOLD, INT32_MAX);
   } else {
-    mallopt(M_MMAP_THRESHOLD, 32 << 20);  // what the dynamic thresholds converge to once a program has freed large blocks
     mallopt(M_TRIM_THRESHOLD, 64 << 20);
     malloc_trim(0);
   }
@@ -206,6 +207,10 @@ void Options::seed_from_env() {
       val = std::strtoll(b, &endp, 10);
       if (endp == b || *endp != '\0') JH_THROW("JH_OPTIONS: value of '" + key + "' is not an integer: '" + std::string(b) + "'");
     }
+    // process-wide switches are the host program's to flip, by an explicit jh_context_set_option -- not a side effect of creating
+    // a context under some environment
+    if (key == "setup_heap" || key == "upload_bounce")
+      JH_THROW("JH_OPTIONS: '" + key + "' changes process-wide state and can only be set through jh_context_set_option");
     if (!set(key.c_str(), val)) JH_THROW("JH_OPTIONS: unknown option '" + key + "'");
   }
 }

@@ -309,7 +309,7 @@ struct PGraph {
 void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t nparts, double imbalance, int64_t max_part,
                       std::vector<int32_t> &label, int32_t rim_cell);
 void partition_on_bfs_numbering(int64_t nc, const int64_t *ptr, const int32_t *nbr, const double *wk, const int32_t *sface, const double *fw,
-                                double fw_scale, int64_t nparts, double imbalance, int64_t max_part, int32_t *label_out,
+                                double fw_scale, double w_floor, int64_t nparts, double imbalance, int64_t max_part, int32_t *label_out,
                                 const std::function<void(const char *)> &lap);
 
 // ---- tiling constants for the CSR row-segment kernels ------------------------------------------------

@@ -872,6 +872,13 @@ extern "C" int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_
     // -- linear solve.  The host does not wait between the phases (every wait is an idle gap on the device): the event pairs are
     // read once at the end of the step
     hipEvent_t *ev = ctx->ev_step;
+    // (a failing factorisation / solve -- a communication time-out, say -- must not lose the deferred check: the report carries
+    // error / converged / assembly_ms as it would have with the check in front)
+    struct DeferredCheck {
+      bool armed;
+      decltype(read_check) &fn;
+      ~DeferredCheck() { if (armed) { try { (void)fn(); } catch (...) {} } }
+    } deferred{defer_check, read_check};
     JH_HIP(hipEventRecord(ev[0], st));
     if (M) ilu_factor(M);
     JH_HIP(hipEventRecord(ev[1], st));
@@ -894,7 +901,7 @@ extern "C" int32_t jh_newton_step(jh_law L, jh_csr A, jh_ilu M, jh_krylov K, jh_
       JH_HIP(hipEventRecord(ev[5], st));
     }
     JH_HIP(hipEventSynchronize(bad ? ev[3] : ev[5]));
-    if (defer_check) (void)read_check();
+    if (defer_check) { deferred.armed = false; (void)read_check(); }
     JH_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
     rep->precond_ms = ms;
     JH_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));

@@ -417,10 +417,10 @@ void partition_bisect(const PGraph &G, std::vector<int32_t> &&cells, int64_t npa
 
 // Partition of the vertices 0 .. nc-1 of the graph (ptr, nbr; neighbours >= nc are ignored) into nparts, label_out[v] in 0 .. nparts-1.
 // Weight of adjacency entry k: wk[k], or |fw[|sface[k]| - 1]| x fw_scale (a weight per face, sface = signed 1-based face id of the
-// entry; non-finite weights count as 0), or 1.
+// entry; zero and non-finite weights count as w_floor), or 1.
 // lap(name): called after each phase (set-up timing).
 void partition_on_bfs_numbering(int64_t nc, const int64_t *ptr, const int32_t *nbr, const double *wk, const int32_t *sface, const double *fw,
-                                double fw_scale, int64_t nparts, double imbalance, int64_t max_part, int32_t *label_out,
+                                double fw_scale, double w_floor, int64_t nparts, double imbalance, int64_t max_part, int32_t *label_out,
                                 const std::function<void(const char *)> &lap) {
   const bool weighted = wk || (fw && sface);
   // The input numbering may be arbitrary (the bench grid's is scrambled): every sweep of the partitioner would miss the
@@ -499,7 +499,11 @@ void partition_on_bfs_numbering(int64_t nc, const int64_t *ptr, const int32_t *n
               w2[w] = wk[k];
             } else {
               const double v = std::fabs(fw[std::abs(sface[k]) - 1]);
-              w2[w] = (std::isfinite(v) ? v : 0.0) * fw_scale;
+              // a sealed (zero) or non-finite coupling still costs something to cut: w_floor = 1e-3 of the mean, so that the
+              // refinement does not see free moves across it (the reference's integer weights have a floor of one unit = a tenth of the
+              // mean, generate_metis_graph, partitioning.jl:64-78; positive finite weights are passed on as they are)
+              const double wv = (std::isfinite(v) ? v : 0.0) * fw_scale;
+              w2[w] = wv > 0.0 ? wv : w_floor;
             }
           }
           nbr2[w++] = newid[nbr[k]];
@@ -528,7 +532,7 @@ extern "C" int32_t jh_partition_graph(int64_t nc, int64_t nf, const int64_t *N, 
   return guard([&] {
     if (nc < 1 || nf < 0 || !out || (nf > 0 && !N)) JH_THROW("bad arguments");
     if (nparts < 1 || nparts > nc) JH_THROW("nparts must be in 1..nc");
-    if (nc > 2000000000LL) JH_THROW("graph too large");
+    if (nc > 2000000000LL || nf > (int64_t)INT32_MAX - 1) JH_THROW("graph too large (cells and faces are 32-bit here)");
     if (!(imbalance >= 0.0)) imbalance = 0.03;
     // adjacency on all host cores: counts and cursors are bumped atomically, then every row is put back into ascending face order
     // (what a serial fill produces), so that nothing depends on the thread timing; faces connecting a cell to itself are skipped
@@ -577,7 +581,13 @@ extern "C" int32_t jh_partition_graph(int64_t nc, int64_t nf, const int64_t *N, 
     // weight unchanged to four digits)
     std::vector<int32_t> label;
     resize_parallel(label, (size_t)nc);
-    partition_on_bfs_numbering(nc, ptr.data(), nbr.data(), nullptr, face_weights ? face.data() : nullptr, face_weights, 1.0, nparts, imbalance, 0,
+    double w_floor = 0.0;  // 1e-3 of the mean |weight|
+    if (face_weights && nf > 0) {
+      double sum = 0.0;
+      for (int64_t f = 0; f < nf; ++f) { const double v = std::fabs(face_weights[f]); sum += std::isfinite(v) ? v : 0.0; }
+      w_floor = 1e-3 * sum / (double)nf;
+    }
+    partition_on_bfs_numbering(nc, ptr.data(), nbr.data(), nullptr, face_weights ? face.data() : nullptr, face_weights, 1.0, w_floor, nparts, imbalance, 0,
                                label.data(), [](const char *) {});
     for (int64_t c = 0; c < nc; ++c) out[c] = (int64_t)label[c] + 1;
   });

@@ -260,7 +260,7 @@ static void blocks_by_bisection(const Adj &A, int64_t nc, int64_t block_rows, st
   parallel_ranges((int64_t)label.size(), 1 << 18, [&](int64_t b, int64_t e) { std::fill(label.begin() + b, label.begin() + e, -1); });
   PhaseTimer pt(timing);
   // (on a breadth-first renumbering of the owned cells: jh_partition.cpp)
-  partition_on_bfs_numbering(nc, A.ptr.data(), A.nbr.data(), nullptr, fw ? A.sface.data() : nullptr, fw, fw_scale, nparts, 0.04, max_part, label.data(),
+  partition_on_bfs_numbering(nc, A.ptr.data(), A.nbr.data(), nullptr, fw ? A.sface.data() : nullptr, fw, fw_scale, 1e-3, nparts, 0.04, max_part, label.data(),
                              [&](const char *what) { pt.lap(what); });
   resize_parallel(perm, (size_t)nc);
   counting_sort_indices(label.data(), nc, nparts, block_ptr, perm.data());  // every block's cells in ascending order

@@ -110,3 +110,32 @@ def test_partition_does_not_depend_on_the_thread_count(monkeypatch):
             assert np.array_equal(a, b)
     sizes = np.bincount(res[0][1])[1:]
     assert sizes.size == 37 and sizes.min() > 0.85 * nc / 37 and sizes.max() < 1.15 * nc / 37
+
+
+def test_sealed_and_non_finite_faces_have_a_small_positive_weight(ja):
+    """Zero, NaN and Inf couplings count as 1e-3 of the mean weight (a sealed face is cheap to cut, not free: the reference's integer
+    Metis weights have a floor of one unit, generate_metis_graph partitioning.jl:64-78) -- the partition equals the one of the
+    same graph with those weights written out, and it is valid and balanced.  The device blocks (jh_tpfa_create_weighted) follow the
+    same rule: a grid whose sealed faces are given as 0 and one where they are given as 1e-3 x mean get the same blocks."""
+    from jutul_amd import dd
+    g = ja.tet_lattice_mesh(8, 7, 6)
+    N, nc = g["N"], g["nc"]
+    rng = np.random.default_rng(3)
+    w = rng.random(N.shape[1]) ** 2 + 0.01
+    bad = rng.choice(N.shape[1], N.shape[1] // 10, replace=False)
+    w_bad = w.copy()
+    w_bad[bad[0::3]] = 0.0
+    w_bad[bad[1::3]] = np.nan
+    w_bad[bad[2::3]] = np.inf
+    finite = np.where(np.isfinite(w_bad), np.abs(w_bad), 0.0)
+    w_floor = finite.copy()
+    w_floor[bad] = 1e-3 * finite.sum() / N.shape[1]
+    for k in (2, 7):
+        p = dd.partition_graph(N, nc, k, face_weights=w_bad)
+        sizes = np.bincount(p)[1:]
+        assert len(sizes) == k and sizes.min() >= np.floor(0.9 * nc / k) and sizes.max() <= np.ceil(1.1 * nc / k)
+        assert np.array_equal(p, dd.partition_graph(N, nc, k, face_weights=w_floor))
+    ctx = ja.HIPContext("host")
+    a = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, reorder="blocks", block_rows=64, face_weights=w_bad).ordering()
+    b = ja.TwoPointPotentialFlowHardCoded(ctx, N, nc, reorder="blocks", block_rows=64, face_weights=w_floor).ordering()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
