@@ -125,6 +125,7 @@ static MailArgs next_mail_args(jh_context ctx, uint64_t timeout_ticks) {
   A.epoch = ++c.mail_epoch; A.timeout_ticks = timeout_ticks; A.err = const_cast<MailErr *>(c.mail_err);
   return A;
 }
+uint64_t comm_mail_epoch(jh_context ctx) { return ctx->comm ? ctx->comm->mail_epoch : 0; }
 bool comm_mail_args(jh_context ctx, int n, MailArgs *out) {
   if (!ctx->comm || ctx->comm->nranks == 1 || !ctx->comm->mail_enabled || n > MAIL_MAX_VALUES) return false;
   *out = next_mail_args(ctx, ctx->comm->wait_ticks);

@@ -776,6 +776,7 @@ void k_final_reduce(jh_context ctx, int nparts, int count, int slot, bool is_max
                     const MailArgs *mail = nullptr);
 // jh_comm.cpp: fills *out (and advances the epoch) if n scalars can be all-reduced through the mailboxes right now
 bool comm_mail_args(jh_context ctx, int n, MailArgs *out);
+uint64_t comm_mail_epoch(jh_context ctx);  // scalar all-reduces enqueued so far (0 without a communicator)
 void comm_allreduce_dev(jh_context ctx, double *p, int n, int op);
 void k_unit_diag(hipStream_t s, const Pattern &P, double *val, double *r, int64_t n_owned);
 void k_zero_slots(hipStream_t s, double *val, const int32_t *slots, int64_t n, int bb);

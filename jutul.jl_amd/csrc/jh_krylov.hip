@@ -620,8 +620,22 @@ int bicgstab(jh_krylov K, jh_ilu M, int side, const double *b_in, double *x, dou
   K->last_path[0] = pend_ok; K->last_path[1] = pend_ok && xrank; K->last_path[2] = jagged; K->last_path[3] = fmul;
   K->last_path[4] = dist && disc->halo.push_enabled; K->last_path[5] = halo_fold;
   int64_t it = 0, enq = 0;
+  // Slot sets of the mailboxes / landing buffers are chosen by HOST-counted epochs, and the launches of a speculative iteration past
+  // convergence consume theirs without executing: two consecutive EXECUTED epochs are then (epochs per iteration x lag + 1) apart
+  // and must not meet in one set (MAIL_S / HALO_S, jh_internal.hpp).  Counted on the first iteration, on every rank alike; a loop
+  // that gains a fused dot or an exchange fails here instead of corrupting a neighbour's reads silently.
+  const uint64_t ar0 = comm_mail_epoch(ctx), hx0 = dist ? disc->halo.push_epoch : 0;
   while (!solved && it < itmax && status == 0) {
-    while (enq < std::min<int64_t>(itmax, it + 1 + lag)) enqueue(++enq);
+    while (enq < std::min<int64_t>(itmax, it + 1 + lag)) {
+      enqueue(++enq);
+      if (enq == 1 && lag > 0 && comm_size(ctx) > 1) {
+        const uint64_t ar = comm_mail_epoch(ctx) - ar0, hx = dist ? disc->halo.push_epoch - hx0 : 0;
+        if (ar * (uint64_t)lag + 1 >= (uint64_t)MAIL_S || hx * (uint64_t)lag + 1 >= (uint64_t)HALO_S)
+          JH_THROW("BiCGStab: " + std::to_string(ar) + " all-reduce and " + std::to_string(hx) + " halo epochs per iteration with " +
+                   std::to_string(lag) + " speculative iteration(s) do not fit the " + std::to_string(MAIL_S) + " / " +
+                   std::to_string(HALO_S) + " slot sets (MAIL_S / HALO_S)");
+      }
+    }
     ++it;
     double h[9];
     wait_published(ctx, (int)(it & 1), seq_of[it & 1], h);
