@@ -250,3 +250,49 @@ def test_submap_cells_and_discretization_mirror(oracle):
     assert np.allclose(ja.compute_face_trans(Thf, hf["faces"], g["nf"]), oracle.face_trans(Thf_o, oh["faces"], g["nf"]), rtol=1e-13)
     z = g["cell_centroids"][2]
     assert np.array_equal(ja.compute_face_gdz(g["N"], z, 9.81), oracle.face_gdz(g["N"], z, 9.81))
+
+
+@pytest.mark.parametrize("side", ["left", "right"])
+def test_oracle_rank_emulation_solves_the_global_system(oracle, side):
+    """tests/_dd_emulation.py (the oracle pin of the GPU's multi-rank Krylov loop, used by test_gpu_distributed.py and
+    xrank_worker.py) checked on its own: three ranks built from oracle assemblies, a scrambled elimination order with two
+    block-Jacobi blocks per rank, both preconditioning sides -- the owned parts of the emulated solve are the global solution."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    import jutul_amd as ja
+    from jutul_amd import dd
+    from tests import _ilu_checks as ck
+    from tests._dd_emulation import emulated_bicgstab, oracle_rank
+    o = oracle
+    g = ja.tet_lattice_mesh(7, 6, 5)
+    nc = g["nc"]
+    T = g["T"] / g["T"].mean()
+    rng = np.random.default_rng(0)
+    U0 = 1.0 + 0.1 * rng.random(nc)
+    world = 3
+    part = dd.partition_rcb(g["cell_centroids"], world)
+    ranks = []
+    subs = []
+    for r in range(world):
+        sub = dd.local_subdomain(g["N"], part, r + 1)
+        cells = sub["cells"] - 1
+        no, nl = sub["n_owned"], sub["n_local"]
+        osys = o.TPFASystem(sub["N"], nl)
+        src_c = [i + 1 for i, c in enumerate(cells[:no]) if c in (0, nc - 1)]
+        src_v = [1.0 if cells[i - 1] == 0 else -1.0 for i in src_c]
+        nz, b = osys.assemble(o.Law("poisson", 0.5), U0[cells], U0[cells], g["volumes"][cells], T[sub["faces"] - 1],
+                              src_cells=src_c or None, src_values=src_v or None)
+        nz, b = o.unit_diagonalize(nl, no, 1, osys.rowptr, osys.colidx, nz, b)
+        perm = np.concatenate([rng.permutation(no), np.arange(no, nl)]) + 1     # ghosts stay last, as on the device
+        bp = np.array([0, no // 2, no, nl])
+        ranks.append(oracle_rank(o, ck, sub, nz, b, perm, bp))
+        subs.append(sub)
+    hist, its, xs = emulated_bicgstab(o, ranks, side, 1e-11)
+    assert 3 < its < 100 and hist[-1] <= 1e-11 * hist[0] and np.all(np.diff(np.log(hist))[:3] < 0)
+    osys = o.TPFASystem(g["N"], nc)
+    nz, rhs = osys.assemble(o.Law("poisson", 0.5), U0, U0, g["volumes"], T, src_cells=[1, nc], src_values=[1.0, -1.0])
+    x_ref = spl.spsolve(sp.csr_matrix((nz, osys.colidx - 1, osys.rowptr - 1), shape=(nc, nc)).tocsc(), rhs)
+    x = np.zeros(nc)
+    for sub, xl in zip(subs, xs):
+        x[sub["cells"][: sub["n_owned"]] - 1] = xl[: sub["n_owned"]]
+    assert np.abs(x - x_ref).max() <= 1e-8 * np.abs(x_ref).max()

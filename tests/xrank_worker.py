@@ -82,6 +82,7 @@ def solve(consumer):
     return out["residuals"].copy(), lsys.dx.download().copy()
 
 
+nz_dev, b_dev = lsys.jac.nzval.copy(), lsys.r.download().copy()   # what the solves below see (ghost rows -I)
 h1, x1 = solve(1)
 h2, x2 = solve(1)
 h0, x0 = solve(0)
@@ -100,6 +101,27 @@ assert np.allclose(h1[:m], h0[:m], rtol=1e-7), (h1[:m], h0[:m])
 # (both solves stop at ||r|| <= 1e-9 ||r0||: the solutions agree to that times the conditioning -- a 2x2 system mixes pressure and
 # saturation scales)
 assert np.abs(x1 - x0).max() <= (1e-7 if nblk == 1 else 1e-5) * np.abs(x0).max()
+# ORACLE PIN of the consumer-side path (scalar systems): rank 0 gathers every rank's matrix, right-hand side, halo plan and device
+# ordering and runs the oracle-driven N-rank emulation (tests/_dd_emulation.py: consistent! before every product, dots over owned
+# entries summed over the ranks, one block-Jacobi ILU(0) per rank with the ghost input zeroed).  A converged answer is the same
+# for any correct reduction; the residual HISTORY through the granule all-reduce is what is compared: first 10 residuals to 1e-8,
+# iteration count +-1.
+if nblk == 1:
+    perm_dev, bp_dev = disc.ordering()
+    plans = [None] * world
+    dist.all_gather_object(plans, dict(sub={k: sub[k] for k in ("n_local", "n_owned", "N", "send", "recv", "neighbors")}, nz=nz_dev, b=b_dev,
+                                       perm=perm_dev, bp=bp_dev))
+    if rank == 0:
+        from oracle import oracle as o
+        from tests import _ilu_checks as ck
+        from tests._dd_emulation import emulated_bicgstab, oracle_rank
+        ranks_o = [oracle_rank(o, ck, pl["sub"], pl["nz"], pl["b"], pl["perm"], pl["bp"]) for pl in plans]
+        hist_o, its_o, _ = emulated_bicgstab(o, ranks_o, "right", rtol, itmax=300)
+        m = min(11, len(hist_o), len(h1))
+        assert m >= 6 and abs((len(h1) - 1) - its_o) <= 1, (len(h1) - 1, its_o)
+        assert np.allclose(h1[:m], hist_o[:m], rtol=1e-8, atol=0.0), (h1[:m], hist_o[:m])
+        print("XRANK_ORACLE_OK", world, its_o, len(h1) - 1, flush=True)
+    dist.barrier()
 # the Newton update through the fused step (jh_newton_step) on the consumer-side path
 ctx.set_option("xrank_consumer", 1)
 sim = ja.Simulator(law, krylov(), tolerance=1e-9)
