@@ -181,6 +181,41 @@ mutable struct HIPConservationLawStorage
     host_state_stale::Bool         # the device has updated X since storage.state was last refreshed
     host_state0_stale::Bool        # the device has updated X0 (update_after_step!) since storage.state0 was last refreshed
     registered::Dict{Symbol, Ptr{Cvoid}}  # storage.state0[k] arrays that are page-locked (jh_host_register), by address
+    assemblies::Int                # update_linearized_system_equation! calls so far
+    err_of_assembly::Int           # the assembly `err` was reduced for (convergence_criterion of several equations: one reduction)
+end
+# Several conservation laws on Cells in one model (setup_storage_equations! loops over all of model.equations, models.jl:549-572;
+# Jutul gives every equation its rows of the block through equation offsets, conservation.jl:143 `equation_offset`): on the device
+# they are ONE law with N = sum of their components -- the storage of the FIRST law (the "group") owns the discretisation, the law,
+# the Jacobian and the vectors and does all the work; every later law gets a member that names its rows of the block.  The physics
+# hooks (hip_law_kind / hip_law_source / hip_law_params) of the first law describe the whole block, components in equation order.
+mutable struct HIPEquationMember
+    group::Union{Nothing, HIPConservationLawStorage}   # linked by setup_linearized_system! (all equation storages exist by then)
+    offset::Int                                         # rows offset+1 .. offset+ne of the block
+    ne::Int
+end
+# get_diagonal_entries of a member: its rows of the group's source accumulator (apply_forces! does d[c] += v or d[e, c] += v)
+struct SourceRows <: AbstractMatrix{Float64}
+    acc::SourceAccumulator
+    offset::Int
+    ne::Int
+end
+Base.size(a::SourceRows) = (a.ne, a.acc.nc)
+Base.IndexStyle(::Type{SourceRows}) = IndexCartesian()
+Base.getindex(a::SourceRows, e::Int, c::Int) = a.acc[a.offset + e, c]
+Base.setindex!(a::SourceRows, v, e::Int, c::Int) = setindex!(a.acc, v, a.offset + e, c)
+Base.getindex(a::SourceRows, c::Int) = a[1, c]
+Base.setindex!(a::SourceRows, v, c::Int) = setindex!(a, v, 1, c)
+# the model's equations as the device sees them: (key, equation, components) in equation order -- TPFA conservation laws only
+function hip_device_laws(model)
+    laws = Tuple{Symbol, Any, Int}[]
+    for (k, e) in pairs(model.equations)
+        e isa ConservationLaw{<:Any, <:TwoPointPotentialFlowHardCoded, <:Any, <:Any} ||
+            error("JutulHIP: equation :$k is a $(typeof(e)); the device path assembles TPFA conservation laws on Cells only, " *
+                  "models mixing them with host equations are not supported")
+        push!(laws, (k, e, Jutul.number_of_equations_per_entity(model, e)))
+    end
+    return laws
 end
 # the page-locked ranges are handed back when the storage goes away (a later simulator may get the same addresses: registering a
 # range twice is an error of the runtime) -- also called by hand when a simulator is torn down
@@ -195,9 +230,17 @@ end
 function setup_equation_storage(model::HIPModel,
         eq::ConservationLaw{<:Any, <:TwoPointPotentialFlowHardCoded, <:Any, <:Any}, storage; kwarg...)
     ctx = model.context
+    laws = hip_device_laws(model)
+    if laws[1][2] !== eq     # a later law of the model: rows of the first law's block
+        i = findfirst(l -> l[2] === eq, laws)
+        isnothing(i) && error("JutulHIP: setup_equation_storage for an equation that is not in model.equations")
+        return HIPEquationMember(nothing, sum(l[3] for l in laws[1:i - 1]), laws[i][3])
+    end
     N = Jutul.get_neighborship(model.domain.representation)      # 2 x nf, Int64, 1-based (as stored)
     nc = Jutul.number_of_cells(model.domain)
-    ne = Jutul.number_of_equations_per_entity(model, eq)
+    ne = sum(l[3] for l in laws)                                  # block size: the components of all conservation laws
+    ne == length(keys(Jutul.get_primary_variables(model))) ||
+        error("JutulHIP: $ne conservation equations per cell but $(length(keys(Jutul.get_primary_variables(model)))) primary variables")
     disc = Ref{Handle}(C_NULL)
     # the face transmissibilities double as the weights of the device-block partition: weak couplings are cut first, like the Metis
     # partition of the |A|-weighted graph behind ILUZeroPreconditioner (precond/ilu.jl:37-60, partitioning.jl:64-78)
@@ -228,7 +271,7 @@ function setup_equation_storage(model::HIPModel,
     @jh :jh_vec_create (Handle, Ref{Handle}) disc[] dx
     n_owned = ctx.n_owned > 0 ? ctx.n_owned : nc
     s = HIPConservationLawStorage(disc[], law[], jac[], r[], dx[], nc, ne, n_owned, NaN, zeros(ne, nc), SourceAccumulator(ne, nc), Int64[], Float64[],
-                                  zeros(ne), false, false, false, false, Dict{Symbol, Ptr{Cvoid}}())
+                                  zeros(ne), false, false, false, false, Dict{Symbol, Ptr{Cvoid}}(), 0, -1)
     finalizer(unregister_host_arrays!, s)
     return s
 end
@@ -246,12 +289,18 @@ struct HIPLinearizedSystem <: Jutul.JutulLinearSystem
     matrix_layout
 end
 
-# the conservation law this path owns among the model's equations (other equations keep Jutul's host path and are rejected here)
+# the group among the model's equation storages (every other storage must be one of its members: hip_device_laws has already
+# rejected models with host equations); members are linked to it here, once
 function hip_equation_storage(storage)
-    found = [v for v in values(storage[:equations]) if v isa HIPConservationLawStorage]
-    length(found) == 1 || error("JutulHIP: expected exactly one TPFA conservation law on the device, found $(length(found)) " *
-                                "among $(length(values(storage[:equations]))) equations")
-    length(values(storage[:equations])) == 1 || error("JutulHIP: models mixing the device conservation law with host equations are not supported")
+    all = collect(values(storage[:equations]))
+    found = [v for v in all if v isa HIPConservationLawStorage]
+    length(found) == 1 || error("JutulHIP: expected exactly one device conservation-law group, found $(length(found)) " *
+                                "among $(length(all)) equations")
+    for v in all
+        v === found[1] && continue
+        v isa HIPEquationMember || error("JutulHIP: models mixing the device conservation laws with host equations are not supported")
+        v.group = found[1]
+    end
     return found[1]
 end
 
@@ -270,6 +319,13 @@ function Jutul.update_linearized_system!(lsys::HIPLinearizedSystem, equations, e
         update_linearized_system_equation!(nothing, nothing, model, equations[key], eqs_storage[key])
     end
 end
+
+# members of a group: the group's kernel assembles their rows, uploads their sources and reduces their errors
+update_equation!(m::HIPEquationMember, law::ConservationLaw, storage, model, dt) = nothing
+update_linearized_system_equation!(nz, r, model, law::ConservationLaw, m::HIPEquationMember) = nothing
+get_diagonal_entries(eq::ConservationLaw, m::HIPEquationMember) = SourceRows(m.group.sources, m.offset, m.ne)
+declare_pattern(model, eq::ConservationLaw, m::HIPEquationMember, ::Cells) = (Int64[], Int64[])   # (in the group's pattern)
+align_to_jacobian!(m::HIPEquationMember, eq::ConservationLaw, jac, model, u::Cells; kwarg...) = nothing
 
 # pattern / alignment: the library owns the device pattern; the host tables are available bit-exact if Jutul needs
 # them (conservation.jl:486-505, :143-216)
@@ -317,6 +373,7 @@ function update_linearized_system_equation!(nz, r, model, law::ConservationLaw, 
         s.src_cells = copy(a.cells); s.src_vals = copy(a.vals)
     end
     @jh :jh_assemble (Handle, Float64, Handle, Handle) s.law s.dt s.jac s.r
+    s.assemblies += 1
     # host copies only if the caller insists on host buffers (parity / debugging); the solve reads device memory
     if !isnothing(nz)
         @jh :jh_csr_get_values (Handle, Ptr{Float64}) s.jac nz
@@ -378,10 +435,23 @@ function get_output_state(storage, model::HIPModel)
 end
 
 # ---- convergence (seam: convergence_criterion, equations.jl:619-629, called by check_convergence, models.jl:830-883) ------
+function reduce_errors!(s::HIPConservationLawStorage)     # max |r_e| of every component of the block, once per assembly
+    if s.err_of_assembly != s.assemblies
+        @jh :jh_convergence (Handle, Handle, Int64, Ptr{Float64}) s.law s.r Int64(s.n_owned) s.err
+        s.err_of_assembly = s.assemblies
+    end
+    return s.err
+end
 function convergence_criterion(model::HIPModel, storage, eq::ConservationLaw, s::HIPConservationLawStorage, r; dt = 1.0, update_report = missing)
-    @jh :jh_convergence (Handle, Handle, Int64, Ptr{Float64}) s.law s.r Int64(s.n_owned) s.err
-    names = s.N == 1 ? "R" : map(i -> "R_$i", 1:s.N)
-    return (AbsMax = (errors = copy(s.err), names = names), )
+    ne = Jutul.number_of_equations_per_entity(model, eq)     # the group reports the rows of ITS law; members report theirs
+    err = reduce_errors!(s)[1:ne]
+    names = ne == 1 ? "R" : map(i -> "R_$i", 1:ne)
+    return (AbsMax = (errors = err, names = names), )
+end
+function convergence_criterion(model::HIPModel, storage, eq::ConservationLaw, m::HIPEquationMember, r; dt = 1.0, update_report = missing)
+    err = reduce_errors!(m.group)[m.offset + 1:m.offset + m.ne]
+    names = m.ne == 1 ? "R" : map(i -> "R_$i", 1:m.ne)
+    return (AbsMax = (errors = err, names = names), )
 end
 
 # ---- preconditioner (seams: update_preconditioner!, precond/ilu.jl:37; apply!, :62) -----------------------------------

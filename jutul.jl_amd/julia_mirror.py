@@ -41,6 +41,25 @@ class SourceAccumulator:
         self.slot, self.cells, self.vals = {}, [], []
 
 
+class SourceRows:
+    """SourceRows of the .jl file: get_diagonal_entries of a MEMBER equation -- its rows of the group's accumulator."""
+
+    def __init__(self, acc, offset, ne):
+        self.acc, self.offset, self.ne = acc, offset, ne
+
+    def add(self, cell, value, e=1):
+        assert 1 <= e <= self.ne
+        self.acc.add(cell, value, self.offset + e)
+
+
+class HIPEquationMember:
+    """HIPEquationMember of the .jl file: a later conservation law of a model with several (models.jl:549-572): rows
+    offset+1 .. offset+ne of the block the first law's storage (the group) assembles."""
+
+    def __init__(self, offset, ne):
+        self.group, self.offset, self.ne = None, int(offset), int(ne)
+
+
 class HIPConservationLawStorage:
     def __init__(self):
         self.disc, self.law, self.jac, self.r, self.dx = H(), H(), H(), H(), H()
@@ -51,6 +70,7 @@ class HIPConservationLawStorage:
         self.src_cells, self.src_vals = [], []
         self.err = None
         self.device_state_valid = self.device_state0_valid = self.host_state_stale = self.host_state0_stale = self.registered = False
+        self.assemblies, self.err_of_assembly = 0, -1
 
 
 class JuliaMirror:
@@ -94,11 +114,28 @@ class JuliaMirror:
         s.err = np.zeros(ne)
         return s
 
+    def setup_equation_storages(self, ctx, N, nc, equations, **kw):
+        """Jutul's loop over model.equations (setup_storage_equations!, models.jl:549-572) for a model with several conservation
+        laws on Cells: `equations` = components of every law, in equation order.  The first call of the .jl file's
+        setup_equation_storage builds the group (block size = all components), every later one returns a member; the members are
+        linked when hip_equation_storage first runs (setup_linearized_system!)."""
+        group = self.setup_equation_storage(ctx, N, nc, ne=int(sum(equations)), **kw)
+        group.ne_own = int(equations[0])
+        out, off = [group], int(equations[0])
+        for ne in equations[1:]:
+            with self._fn("setup_equation_storage"):      # (the member branch issues no entry point)
+                out.append(HIPEquationMember(off, ne))
+            off += int(ne)
+        for m in out[1:]:                                 # hip_equation_storage
+            m.group = group
+        return out
+
     def adopt(self, disc, law, lsys):
         """Storage over handles that already exist (jutul_amd objects): bench.py builds the problem once and times either path."""
         s = HIPConservationLawStorage()
         s.disc, s.law, s.jac, s.r, s.dx = disc.h, law.h, lsys.jac.h, lsys.r.h, lsys.dx.h
         s.nc, s.N, s.n_owned = disc.nc, law.N, disc.n_owned
+        s.ne_own = s.N
         s.X = np.zeros(s.nc * s.N)
         s.sources = SourceAccumulator(s.N, s.nc)
         s.err = np.zeros(s.N)
@@ -106,6 +143,8 @@ class JuliaMirror:
 
     # ---- update_equation! (conservation.jl:572; state_pair :549-555) -----------------------------------------------------------
     def update_equation(self, s, state, state0, dt):
+        if isinstance(s, HIPEquationMember):     # update_equation!(m::HIPEquationMember, ...) = nothing
+            return
         with self._fn("update_equation!"):
             if not s.device_state_valid:
                 check(self.L.jh_law_set_state(s.law, pf(f64(np.asarray(state).reshape(-1)))))
@@ -118,10 +157,14 @@ class JuliaMirror:
             s.dt = float(dt)
 
     def get_diagonal_entries(self, s):
+        if isinstance(s, HIPEquationMember):
+            return SourceRows(s.group.sources, s.offset, s.ne)
         return s.sources
 
     # ---- update_linearized_system_equation! (conservation.jl:298) ------------------------------------------------------------
     def update_linearized_system_equation(self, s, nz=None, r=None):
+        if isinstance(s, HIPEquationMember):     # the group's kernel has assembled the member's rows
+            return
         L, a = self.L, s.sources
         with self._fn("update_linearized_system_equation!"):
             if a.cells != s.src_cells or a.vals != s.src_vals:
@@ -129,6 +172,7 @@ class JuliaMirror:
                 check(L.jh_law_set_sources(s.law, cells.size, pi(cells) if cells.size else None, pf(vals) if vals.size else None))
                 s.src_cells, s.src_vals = list(a.cells), list(a.vals)
             check(L.jh_assemble(s.law, s.dt, s.jac, s.r))
+            s.assemblies += 1
             if nz is not None:
                 check(L.jh_csr_get_values(s.jac, pf(nz)))
             if r is not None:
@@ -168,10 +212,20 @@ class JuliaMirror:
             self.L.jh_host_unregister(v0.ctypes.data_as(C.c_void_p))
 
     # ---- convergence_criterion (equations.jl:619-629) ---------------------------------------------------------------------------
+    def reduce_errors(self, s):
+        """reduce_errors!: max |r_e| of every component of the block, once per assembly"""
+        with self._fn("reduce_errors!"):
+            if s.err_of_assembly != s.assemblies:
+                check(self.L.jh_convergence(s.law, s.r, s.n_owned, pf(s.err)))
+                s.err_of_assembly = s.assemblies
+        return s.err
+
     def convergence_criterion(self, s):
+        """the group reports the rows of its own law (all of them for a single-equation model), a member reports its rows"""
         with self._fn("convergence_criterion"):
-            check(self.L.jh_convergence(s.law, s.r, s.n_owned, pf(s.err)))
-        return s.err.copy()
+            if isinstance(s, HIPEquationMember):
+                return self.reduce_errors(s.group)[s.offset:s.offset + s.ne].copy()
+            return self.reduce_errors(s)[:getattr(s, "ne_own", s.N)].copy()
 
     # ---- update_preconditioner! (precond/ilu.jl:37) -------------------------------------------------------------------------------
     def update_preconditioner(self, prec, s):

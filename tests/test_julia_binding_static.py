@@ -348,7 +348,7 @@ def test_block_checker_catches_planted_faults():
 SUPER = {
     # the binding's own types
     "HIPModel": ["SimulationModel", "JutulModel"], "HIPContext": ["GPUJutulContext", "JutulContext"],
-    "HIPConservationLawStorage": [], "HIPLinearizedSystem": ["JutulLinearSystem"], "HIPPreconditioner": ["JutulPreconditioner"],
+    "HIPConservationLawStorage": [], "HIPEquationMember": [], "SourceRows": ["AbstractArray", "AbstractMatrix"], "HIPLinearizedSystem": ["JutulLinearSystem"], "HIPPreconditioner": ["JutulPreconditioner"],
     "HIPDistributedExecutor": ["JutulExecutor"], "SourceAccumulator": ["AbstractArray", "AbstractMatrix"],
     # reference types
     "SimulationModel": ["JutulModel"], "MultiModel": ["JutulModel"], "CompositeModel": ["SimulationModel", "JutulModel"],
