@@ -148,9 +148,9 @@ inline void check(int32_t rc) {  // nested C-ABI call failed: the message is alr
 // ---- options ----------------------------------------------------------------------------------------------------
 namespace jh {
 // Option setup_heap (PROCESS-WIDE, glibc): the set-up allocates and frees ~4 GB of tables and temporaries per 10M cells, and every
-// vector of more than the allocator's mmap threshold is a fresh mapping handed back on free.  1: the trim threshold is raised so
-// that freed heap memory is kept and later tables reuse pages that are already mapped; 0: the free heap memory is returned to the
-// system (malloc_trim).  What it changes for the rest of the process, permanently: glibc stops adapting its mmap / trim thresholds
+// vector of more than the allocator's mmap threshold is a fresh mapping handed back on free.  1: no block is mmap'ed and the trim
+// threshold is raised, so that freed heap memory is kept and later tables reuse pages that are already mapped; 0: mmap'ed blocks
+// are allowed again and the free heap memory is returned to the system (malloc_trim).  What it changes for the rest of the process, permanently: glibc stops adapting its mmap / trim thresholds
 // dynamically once either has been set by hand (mallopt), and switching the option off does not bring that back -- it sets the
 // values the dynamic scheme converges to in a program that has freed large blocks (32 MB / 64 MB).  A HOST decision, hence an
 // option, off unless asked for, and never read from JH_OPTIONS (a per-context seed must not flip process-wide state).  Since
@@ -158,9 +158,13 @@ namespace jh {
 static void apply_setup_heap(bool on) {
 #if defined(__GLIBC__)
   if (on) {
-    mallopt(M_MMAP_THRESHOLD, 32 << 20);  // (glibc's maximum: larger values are rejected)
+    // (M_MMAP_THRESHOLD cannot do this: glibc rejects values above 32 MB, and the set-up's vectors are 40-320 MB at 10M cells --
+    // round 5's mallopt(M_MMAP_THRESHOLD, 1 << 30) was a silent no-op.  With no mmap'ed blocks at all the heap grows to the PEAK of
+    // the live tables, 2.0 GB at 10M cells, instead of 4.2 GB of mappings that come and go.)
+    mallopt(M_MMAP_MAX, 0);
     mallopt(M_TRIM_THRESHOLD, INT32_MAX);
   } else {
+    mallopt(M_MMAP_MAX, 65536);  // glibc's default
     mallopt(M_TRIM_THRESHOLD, 64 << 20);
     malloc_trim(0);
   }
