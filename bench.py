@@ -224,9 +224,8 @@ def main():
     # the host's malloc policy during the set-up (library option setup_heap, process-wide): freed heap memory is kept so that later
     # tables reuse mapped pages -- half the page faults of the set-up; switched off (thresholds restored, heap trimmed) before the
     # timed region.  An explicit --option setup_heap=0 leaves the process as it is.
-    setup_heap = "setup_heap" not in options
-    if setup_heap:
-        ctx.set_option("setup_heap", 1)
+    setup_heap = bool(options.get("setup_heap"))   # (round 6: off unless asked for -- `setup_s` is what a drop-in user gets;
+    # `--option setup_heap=1` opts in, for the set-up only: it is switched off again before the timed region)
     # Several ranks on ONE device with compute units of their own (JH_BENCH_CU_MASK=1: rank r gets CUs [r*C/N, (r+1)*C/N) of the device's C):
     # the proxy of one-process-per-GPU the test box allows -- a kernel whose wavefronts wait for a peer cannot keep it off the chip
     cu_masked = shared_device and os.environ.get("JH_BENCH_CU_MASK") == "1"

@@ -42,10 +42,10 @@ PY
 }
 if [ $PART = setup ] || [ $PART = all ]; then
   ( nproc; grep -m1 "model name" /proc/cpuinfo; cat /sys/fs/cgroup/cpu.max ) > $O/setup_host.txt 2>/dev/null
-  setup_run t16_heap1 16
-  setup_run t16_heap0 16 --option setup_heap=0
-  setup_run t1_heap1 1
-  setup_run t1_heap0 1 --option setup_heap=0
+  setup_run t16_heap1 16 --option setup_heap=1
+  setup_run t16_heap0 16
+  setup_run t1_heap1 1 --option setup_heap=1
+  setup_run t1_heap0 1
 fi
 run() { tag=$1; shift; python bench.py --no-cpu "$@" > $O/bench_$tag.json 2> $O/bench_$tag.err; python - $O/bench_$tag.json $tag <<'PY'
 import json, sys
