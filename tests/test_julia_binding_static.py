@@ -482,3 +482,123 @@ def test_fields_read_from_reference_structs_exist():
     assert {"context", "domain"} <= used["SimulationModel"]
     for struct, names in used.items():
         assert names <= set(f[struct]), f"{struct} has no field(s) {sorted(names - set(f[struct]))} (reference fields: {f[struct]})"
+
+
+# ------------------------------------------------------------------------------------------------ (d) every name resolves
+# A typo in a function or type name is a run-time UndefVarError in Julia; nothing above would see `lenght(x)`.  Every identifier
+# that is CALLED and every type used in an annotation or a parametric type must be: defined in the file, imported from Jutul, a
+# function-valued argument of the enclosing function, or on the lists below -- each entry checked by hand against Julia 1.10's Base
+# / Core (the lists are closed on purpose: a new name forces a look).
+BASE_FUNCTIONS = {
+    "all", "append!", "ccall", "collect", "copy", "cumsum", "eachindex", "empty!", "enumerate", "error", "esc", "finalizer", "findfirst",
+    "first", "get", "get!", "haskey", "invoke", "isempty", "isfinite", "isnan", "isnothing", "keys", "length", "map", "max", "min",
+    "minimum", "new", "pairs", "pointer", "push!", "reduce", "similar", "size", "sizeof", "something", "sqrt", "sum", "unsafe_string",
+    "values", "zeros", "setindex!", "getindex",
+}
+BASE_TYPES = {
+    "Float64", "Int32", "Int64", "Int", "UInt8", "Bool", "String", "Symbol", "Cstring", "Cvoid", "Ptr", "Ref", "Vector", "Matrix", "Array",
+    "Dict", "Tuple", "Union", "Nothing", "Any", "Integer", "AbstractMatrix", "AbstractArray", "IndexCartesian", "Type",
+}
+FUNCTION_ARGUMENTS = {"bcast", "allgather"}     # collectives handed in by the host (setup_distributed!, set_halo!)
+KEYWORDS = {"if", "for", "while", "function", "elseif", "return", "macro", "let", "do", "where", "in", "isa", "begin"}
+
+
+def _code_only(src):
+    s = strip_comments(src)
+    s = re.sub(r'"""(?:\\.|[^\\])*?"""', lambda m: re.sub(r"[^\n]", " ", m.group(0)), s, flags=re.S)
+    return re.sub(r'"(?:\\.|[^"\\\n])*"', lambda m: " " * len(m.group(0)), s)
+
+
+def _binding_namespace(src, s):
+    defined = {n for n, _, _ in find_methods(src)}
+    defined |= set(re.findall(r"(?m)^(?:mutable[ \t]+)?struct[ \t]+(\w+)", s)) | set(re.findall(r"(?m)^abstract type[ \t]+(\w+)", s))
+    defined |= set(re.findall(r"(?m)^const[ \t]+(\w+)", s)) | set(re.findall(r"(?m)^macro[ \t]+(\w+)", s))
+    m = re.search(r"import Jutul:(.*?)\n\n", src, flags=re.S)
+    imported = {x.strip() for x in m.group(1).replace("\n", " ").split(",") if x.strip()}
+    return defined, imported
+
+
+def test_every_called_function_and_every_type_name_resolves():
+    src = strip_comments(open(JL).read())
+    s = _code_only(open(JL).read())
+    defined, imported = _binding_namespace(src, s)
+    called = set(re.findall(r"(?<![\w.:@])([A-Za-z_]\w*!?)\(", s)) - KEYWORDS
+    assert len(called) > 90
+    unknown = sorted(called - defined - imported - BASE_FUNCTIONS - BASE_TYPES - FUNCTION_ARGUMENTS)
+    assert not unknown, f"called but defined nowhere (typo, or a Base function to add to the list after checking it): {unknown}"
+    # types: `::T`, `<:T`, `T{...}`, `isa T`
+    types = set(re.findall(r"(?:::|<:|\bisa[ \t]+)[ \t]*([A-Z]\w*)(?![\w.])", s)) | set(re.findall(r"(?<![\w.])([A-Z]\w*)\{", s))   # (qualified Jutul.X: test (b))
+    assert len(types) > 25
+    unknown_t = sorted(types - defined - imported - BASE_TYPES)
+    assert not unknown_t, f"type names that resolve nowhere: {unknown_t}"
+    # fields of the binding's own structs: `x.field` where x is a conventional variable name of that struct type
+    fields = {}
+    for m in re.finditer(r"(?m)^(?:mutable[ \t]+)?struct[ \t]+(\w+)[^\n]*\n(.*?)^end", s, flags=re.S):
+        names = []
+        for ln in m.group(2).split("\n"):
+            f = re.match(r"^[ \t]+([a-z_]\w*)(?:::[^\n]*)?[ \t]*$", ln)
+            if f:
+                names.append(f.group(1))
+        fields[m.group(1)] = set(names)
+    conv = {"s": "HIPConservationLawStorage", "m": "HIPEquationMember", "ctx": "HIPContext", "ws": "HIPKrylov"}
+    for var, struct in conv.items():
+        used = set(re.findall(r"(?<![\w.])" + var + r"\.([a-z_]\w*)", s))
+        if var == "m":      # (`m` is also a regex-free loop variable nowhere; members only)
+            used = set(re.findall(r"(?<![\w.])m\.([a-z_]\w*)", s))
+        assert used, (var, struct)
+        assert used <= fields[struct], f"{struct} has no field(s) {sorted(used - fields[struct])}"
+
+
+def test_the_name_checker_catches_a_planted_typo():
+    s = _code_only("function f(x)\n    n = lenght(x)   # typo\n    return zeros(n)\nend\n")
+    called = set(re.findall(r"(?<![\w.:@])([A-Za-z_]\w*!?)\(", s)) - KEYWORDS
+    assert "lenght" in called - BASE_FUNCTIONS and "zeros" in BASE_FUNCTIONS and "f" in called
+
+
+BASE_VALUES = {"nothing", "true", "false", "C_NULL", "NaN", "missing", "undef", "vcat", "libjutul_hip", "ENV", "Base", "Jutul", "GC",
+               "LinearAlgebra"}
+MORE_KEYWORDS = {"end", "else", "try", "catch", "finally", "struct", "mutable", "const", "using", "import", "module", "abstract", "type",
+                 "local", "global", "export", "new", "quote", "break", "continue"}
+
+
+def undefined_locals(raw):
+    """{function header: names read in the body that are neither parameters, nor assigned anywhere in the body (any `x =`, tuple
+    targets, loop / lambda / do-block variables -- an over-approximation on purpose), nor module-level names, imports or Base}"""
+    src, s = strip_comments(raw), _code_only(raw)
+    defined, imported = _binding_namespace(src, s)
+    lines = s.split("\n")
+    out = {}
+    for first, last, head in top_level_definitions(raw):
+        if not head.startswith("function"):
+            continue
+        body = "\n".join(lines[first - 1:last])
+        op = body.index("(")
+        cl = match_bracket(body, op)
+        params = set()
+        for part in split_top(body[op + 1:cl].replace(";", ","), ","):
+            nm = re.split(r"::", split_top(part, "=")[0].strip().rstrip("."))[0].strip()
+            if nm:
+                params.add(nm)
+        rest = body[cl + 1:]
+        assigned = set(re.findall(r"(?<![\w.])([a-z_]\w*)[ \t]*(?:[-+*/]?=)(?!=)", rest))
+        for m in re.finditer(r"(?<![\w.])((?:[a-z_]\w*[ \t]*,[ \t]*)+[a-z_]\w*)[ \t]*=(?!=)", rest):
+            assigned |= {x.strip() for x in m.group(1).split(",")}
+        for m in re.finditer(r"\(([a-z_][\w ,()]*)\)[ \t]*(?:=(?!=)|->|in\b)", rest):
+            assigned |= set(re.findall(r"[a-z_]\w*", m.group(1)))
+        assigned |= set(re.findall(r"\bfor[ \t]+([a-z_]\w*)[ \t]+in\b", rest)) | set(re.findall(r"\bfor[ \t]+([a-z_]\w*)[ \t]*=", rest))
+        assigned |= set(re.findall(r",[ \t]*([a-z_]\w*)[ \t]+in\b", rest)) | set(re.findall(r"(?<![\w.])([a-z_]\w*)[ \t]*->", rest))
+        assigned |= set(re.findall(r"\bdo[ \t]+([a-z_]\w*)", rest))
+        used = set(re.findall(r"(?<![\w.:@$])([a-z_]\w*!?)(?![\w!]*\()", rest))
+        unk = used - params - assigned - defined - imported - BASE_VALUES - KEYWORDS - MORE_KEYWORDS - BASE_FUNCTIONS - FUNCTION_ARGUMENTS
+        if unk:
+            out[head[:80]] = sorted(unk)
+    return out
+
+
+def test_no_function_reads_a_name_that_is_defined_nowhere():
+    raw = open(JL).read()
+    assert undefined_locals(raw) == {}
+    planted = raw.replace("    n = iters[]\n", "    n = itres[]\n", 1)
+    assert planted != raw
+    bad = undefined_locals(planted)
+    assert any("itres" in v for v in bad.values()), bad
