@@ -496,3 +496,44 @@ def test_bench_cartesian_mesh_matches_the_oracle_geometry(oracle):
     gs = cartesian_mesh(*dims, size=size)                     # scrambled numbering: the same grid under a permutation
     key = lambda N, T: sorted(zip(np.minimum(N[0], N[1]).tolist(), np.maximum(N[0], N[1]).tolist()))
     assert len(set(key(gs["N"], gs["T"]))) == g["nf"] and np.isclose(np.sort(gs["T"]).sum(), np.sort(g["T"]).sum(), rtol=1e-12)
+
+
+def test_config0_simple_heat_50x50_newton_loop(oracle):
+    """BASELINE configs[0] on the CPU, at its own size: SimpleHeat on the 50 x 50 periodic grid (heat_2d.jl:7-49; initial box of
+    docs/src/index.md:38-45) through the oracle's restatement of the WHOLE per-step path -- assemble -> converged? -> ILU(0) +
+    BiCGStab -> update -> assemble -> converged (simulator.jl:392-455: a linear problem takes two assemblies and one solve) -- for
+    five implicit steps.  Checked against the independent 5-point stencil identity ((I/dt) - Lap_h) T1 = T0/dt, conservation of
+    the total, the maximum principle, and decay towards the mean."""
+    nx = ny = 50
+    nc = nx * ny
+    h = 1.0 / nx
+    N = periodic_heat_neighbors(nx, ny)
+    sysm = oracle.TPFASystem(N, nc)
+    Tf = np.full(N.shape[1], 1.0 / h ** 2)
+    T = np.zeros((ny, nx))
+    T[20:30, 20:30] = 100.0
+    T = T.reshape(-1)
+    vol = np.ones(nc)
+    dt = 1e-4
+    law = oracle.Law("poisson", dt=dt)
+    spread = []
+    for step in range(5):
+        T0 = T.copy()
+        solves = 0
+        for it in range(3):
+            nz, r = sysm.assemble(law, T, T0, vol, Tf)
+            if np.abs(r).max() < 1e-9 * 100.0 / dt and it > 0:      # (|r| starts at ~T/dt = 1e6; the solve leaves ~1e-12 of that)
+                break
+            F = oracle.ILU0(nc, 1, sysm.rowptr, sysm.colidx, nz)
+            x, info = oracle.bicgstab(nc, 1, sysm.rowptr, sysm.colidx, nz, r, prec=F, side="right", rtol=1e-12, atol=0.0, itmax=200)
+            assert info["solved"] and 1 <= info["iterations"] < 60
+            T = T - x
+            solves += 1
+        assert solves == 1 and it == 1                      # two assemblies, one solve
+        Tm, T0m = T.reshape(ny, nx), T0.reshape(ny, nx)
+        lap = (np.roll(Tm, 1, 1) + np.roll(Tm, -1, 1) + np.roll(Tm, 1, 0) + np.roll(Tm, -1, 0) - 4 * Tm) / h ** 2
+        assert np.abs((Tm - T0m) / dt - lap).max() <= 1e-7 * 100.0 / dt
+        assert np.isclose(T.sum(), T0.sum(), rtol=1e-11)    # periodic domain: the total is conserved
+        assert T.min() >= -1e-9 and T.max() <= T0.max() + 1e-9
+        spread.append(T.max() - T.min())
+    assert all(b < a for a, b in zip(spread, spread[1:]))
