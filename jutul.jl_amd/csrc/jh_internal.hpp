@@ -299,6 +299,10 @@ static inline void reserve_prefaulted(std::vector<T> &v, size_t n) {
   }
 }
 
+// adjacency of the cells from the neighbourship (jh_setup.cpp): bucketed counting sort, rows in ascending face order
+void build_adjacency_buckets(int64_t nc, int64_t nf, const int64_t *N, int32_t *Nhost, bool self_loops_ok, bool signed_faces,
+                             std::vector<int64_t> &ptr, std::vector<int32_t> &nbr, std::vector<int32_t> &sface);
+
 // ---- graph partitioner (jh_partition.cpp): recursive bisection + Fiduccia-Mattheyses refinement --------------------------------
 struct PGraph {
   int64_t n;           // cells 0 .. n-1 take part; neighbour ids >= n are ignored (ghost cells of a rank-local subdomain)

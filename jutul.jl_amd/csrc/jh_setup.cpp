@@ -89,15 +89,17 @@ struct Adj {
   std::vector<int32_t> sface;  // signed face id: +(f+1) if this cell is N[1,f], -(f+1) otherwise
 };
 
-// Nhost (optional): the 32-bit copy of N the discretisation keeps, filled in the same pass.
-static Adj build_adjacency(int64_t nc, int64_t nf, const int64_t *N, int32_t *Nhost) {
-  // The input numbering may be arbitrary (the bench grid's is scrambled): counting and filling cell by cell would be one cache
-  // miss per half-face, twice.  Instead the half-faces are first distributed over BUCKETS of consecutive cells (a counting sort on
-  // the high bits of the cell id: sequential reads, one write stream per bucket), then every bucket -- 16 384 cells, its slice of
-  // every array fits the L2 of a core -- is counted and filled on its own.  Threads take face ranges in ascending order and write a
-  // bucket's entries in thread order, so a cell's entries arrive in ascending face order: the rows are what a serial fill in face
-  // order produces, for any thread count, without a sort.
-  Adj A;
+// Adjacency of the cells from the neighbourship N (2 x nf, 1-based), without the diagonal: ptr[nc + 1], and per entry the
+// neighbour (0-based) and the face id -- signed (+(f+1) if the cell is N[1,f], -(f+1) otherwise) or plain f+1.  Rows in ascending
+// face order.  self_loops_ok: faces with N[1,f] == N[2,f] are skipped instead of refused.  Nhost (optional): the 32-bit copy of N.
+// The input numbering may be arbitrary (the bench grid's is scrambled): counting and filling cell by cell would be one cache miss
+// per half-face, twice.  Instead the half-faces are first distributed over BUCKETS of consecutive cells (a counting sort on the
+// high bits of the cell id: sequential reads, one write stream per bucket), then every bucket -- 16 384 cells, its slice of every
+// array fits the L2 of a core -- is counted and filled on its own.  Threads take face ranges in ascending order and write a
+// bucket's entries in thread order, so a cell's entries arrive in ascending face order: the rows are what a serial fill in face
+// order produces, for any thread count, without a sort.
+void build_adjacency_buckets(int64_t nc, int64_t nf, const int64_t *N, int32_t *Nhost, bool self_loops_ok, bool signed_faces,
+                             std::vector<int64_t> &ptr, std::vector<int32_t> &nbr, std::vector<int32_t> &sface) {
   constexpr int64_t BW = 16384;  // cells per bucket (cell id within a bucket: 14 bits, kept in a 16-bit side array)
   const int64_t nbk = (nc + BW - 1) / BW;
   int nt = setup_threads();
@@ -111,8 +113,11 @@ static Adj build_adjacency(int64_t nc, int64_t nf, const int64_t *N, int32_t *Nh
       const int64_t l = N[2 * f], r = N[2 * f + 1];
       if (l < 1 || l > nc || r < 1 || r > nc)
         JH_THROW("neighborship entry out of range (utils.jl:822: max(N) <= nc)");
-      if (l == r) JH_THROW("face connecting a cell to itself is not supported");
       if (Nhost) { Nhost[2 * f] = (int32_t)l; Nhost[2 * f + 1] = (int32_t)r; }
+      if (l == r) {
+        if (self_loops_ok) continue;
+        JH_THROW("face connecting a cell to itself is not supported");
+      }
       h[(size_t)((l - 1) / BW)]++;
       h[(size_t)((r - 1) / BW)]++;
     }
@@ -124,38 +129,43 @@ static Adj build_adjacency(int64_t nc, int64_t nf, const int64_t *N, int32_t *Nh
     bstart[(size_t)b + 1] = run;
   }
   const int64_t nhf = bstart[(size_t)nbk];
-  resize_parallel(A.ptr, (size_t)nc + 1);
-  resize_parallel(A.nbr, (size_t)nhf);
-  resize_parallel(A.sface, (size_t)nhf);
+  resize_parallel(ptr, (size_t)nc + 1);
+  resize_parallel(nbr, (size_t)nhf);
+  resize_parallel(sface, (size_t)nhf);
   std::vector<uint16_t> lcell;  // cell of an entry, relative to its bucket
   resize_parallel(lcell, (size_t)nhf);
   parallel_team(nt, [&](int t, int) {  // entries in bucket order (inside a bucket: face order), written into the final arrays
     int64_t *cur = hist[(size_t)t].data();
     for (int64_t f = nf * t / nt, f1 = nf * (t + 1) / nt; f < f1; ++f) {
       const int64_t l = N[2 * f] - 1, r = N[2 * f + 1] - 1;
+      if (l == r) continue;
       const int64_t pl = cur[l / BW]++;
-      A.nbr[pl] = (int32_t)r; A.sface[pl] = (int32_t)(f + 1); lcell[pl] = (uint16_t)(l % BW);
+      nbr[pl] = (int32_t)r; sface[pl] = (int32_t)(f + 1); lcell[pl] = (uint16_t)(l % BW);
       const int64_t pr = cur[r / BW]++;
-      A.nbr[pr] = (int32_t)l; A.sface[pr] = -(int32_t)(f + 1); lcell[pr] = (uint16_t)(r % BW);
+      nbr[pr] = (int32_t)l; sface[pr] = signed_faces ? -(int32_t)(f + 1) : (int32_t)(f + 1); lcell[pr] = (uint16_t)(r % BW);
     }
   });
-  A.ptr[0] = 0;
+  ptr[0] = 0;
   parallel_ranges(nbk, 4, [&](int64_t b0, int64_t b1) {  // every bucket: count per cell, row pointers, stable scatter by cell
     std::vector<int32_t> cnt((size_t)BW + 1), tn, tf;
     for (int64_t b = b0; b < b1; ++b) {
       const int64_t e0 = bstart[(size_t)b], e1 = bstart[(size_t)b + 1], c0 = b * BW, ncb = std::min(BW, nc - c0);
       std::fill(cnt.begin(), cnt.begin() + ncb + 1, 0);
       for (int64_t e = e0; e < e1; ++e) cnt[(size_t)lcell[e] + 1]++;
-      for (int64_t c = 0; c < ncb; ++c) { cnt[(size_t)c + 1] += cnt[(size_t)c]; A.ptr[c0 + c + 1] = e0 + cnt[(size_t)c + 1]; }
-      tn.assign(A.nbr.begin() + e0, A.nbr.begin() + e1);
-      tf.assign(A.sface.begin() + e0, A.sface.begin() + e1);
+      for (int64_t c = 0; c < ncb; ++c) { cnt[(size_t)c + 1] += cnt[(size_t)c]; ptr[c0 + c + 1] = e0 + cnt[(size_t)c + 1]; }
+      tn.assign(nbr.begin() + e0, nbr.begin() + e1);
+      tf.assign(sface.begin() + e0, sface.begin() + e1);
       for (int64_t e = e0; e < e1; ++e) {
         const int64_t w = e0 + cnt[(size_t)lcell[e]]++;
-        A.nbr[w] = tn[(size_t)(e - e0)];
-        A.sface[w] = tf[(size_t)(e - e0)];
+        nbr[w] = tn[(size_t)(e - e0)];
+        sface[w] = tf[(size_t)(e - e0)];
       }
     }
   });
+}
+static Adj build_adjacency(int64_t nc, int64_t nf, const int64_t *N, int32_t *Nhost) {
+  Adj A;
+  build_adjacency_buckets(nc, nf, N, Nhost, false, true, A.ptr, A.nbr, A.sface);
   return A;
 }
 
