@@ -504,7 +504,11 @@ extern "C" int32_t jh_comm_ipc_attach(jh_context ctx, const char *handles, int32
       // its own position of a zero vector, sums over the ranks, MAIL_MAX_VALUES ranks per reduction.  Equal digests = one device:
       // jh_comm_set_exclusive(ctx, 1) is then refused unless the context is CU-masked.
       char bus[64] = {0};
-      JH_HIP(hipDeviceGetPCIBusId(bus, (int)sizeof(bus), ctx->device));
+      if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), ctx->device) != hipSuccess) {
+        // (no bus id: fall back to the device ordinal -- ranks that each see "device 0" then count as sharing one, the safe answer)
+        (void)hipGetLastError();
+        snprintf(bus, sizeof(bus), "ordinal-%d", ctx->device);
+      }
       uint64_t h = 0xcbf29ce484222325ull;
       for (const char *q = bus; *q; ++q) h = (h ^ (uint64_t)(unsigned char)*q) * 0x100000001b3ull;
       const double mine = (double)(((h ^ (h >> 48)) & 0xffffffffffffull) | 1ull);
