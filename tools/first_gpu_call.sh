@@ -6,8 +6,11 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R; O=$R/gpurun_out/
 H=$(python tools/fatbin_hash.py | cut -d' ' -f1); echo "device code $H  head $(cat .git_head 2>/dev/null)"
 fail() { echo "FAILED: $1"; exit 1; }
 if [ $PART = tests ] || [ $PART = all ]; then
-  timeout 2400 python -m pytest tests -m gpu -x -q > $O/gpu_pytest_$H.log 2>&1; rc=$?; echo "pytest rc=$rc"; grep -E "passed|failed|error" $O/gpu_pytest_$H.log | tail -2
+  # (1) every test that has run on a GPU before (tests/test_gpu_zz_round6.py sorts last and holds the ones that have not)
+  timeout 2400 python -m pytest tests -m gpu -x -q --ignore=tests/test_gpu_zz_round6.py > $O/gpu_pytest_$H.log 2>&1; rc=$?; echo "pytest rc=$rc"; grep -E "passed|failed|error" $O/gpu_pytest_$H.log | tail -2
   [ $rc = 0 ] || { tail -40 $O/gpu_pytest_$H.log; fail "gpu suite"; }
+  # (2) the GPU tests written without a GPU: all of them, whatever the first one says
+  timeout 1500 python -m pytest tests/test_gpu_zz_round6.py -m gpu -q > $O/gpu_pytest_round6_new_$H.log 2>&1; rc6=$?; echo "round-6 tests rc=$rc6"; tail -25 $O/gpu_pytest_round6_new_$H.log | cut -c1-300
   python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_$H.log 2>&1; rc=$?; echo "smoke rc=$rc"; tail -1 $O/smoke_$H.log
   [ $rc = 0 ] || fail smoke
 fi
