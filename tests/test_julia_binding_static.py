@@ -602,3 +602,86 @@ def test_no_function_reads_a_name_that_is_defined_nowhere():
     assert planted != raw
     bad = undefined_locals(planted)
     assert any("itres" in v for v in bad.values()), bad
+
+
+# ------------------------------------------------------------------------------------------- (e) call sites of Jutul functions
+def jutul_call_sites():
+    """[(line, name, n_positional, [keyword names], has_splat)] of every CALL (not definition) of an imported or `Jutul.`-qualified
+    function in the binding"""
+    raw = open(JL).read()
+    src = strip_comments(raw)
+    s = _code_only(raw)
+    a = api()["names"]
+    funcs = {n for n, v in a.items() if v["methods"] and not n[0].isupper()}
+    def_starts = set()
+    for m in re.finditer(r"(?m)^[ \t]*(?:function[ \t]+)?((?:[A-Za-z_]\w*\.)*[A-Za-z_]\w*!?)[ \t]*\(", s):
+        cl = match_bracket(s, m.end() - 1)
+        if m.group(0).lstrip().startswith("function") or re.match(r"[ \t]*(?:::[^\n=]*?)?(?:where[^\n=]*?)?=(?!=)", s[cl + 1:cl + 200]):
+            def_starts.add(m.start(1))
+    out = []
+    for m in re.finditer(r"(?<![\w!])((?:Jutul\.)?)([A-Za-z_]\w*!?)\(", s):
+        name = m.group(2)
+        if name not in funcs or m.start(1) in def_starts or m.start(2) in def_starts:
+            continue
+        if s[max(0, m.start() - 1):m.start()] == ".":     # some_object.name(...)
+            continue
+        if re.search(r"invoke\($", s[max(0, m.start() - 7):m.start()]):
+            continue
+        op = m.end() - 1
+        cl = match_bracket(src, op)                         # (same offsets: _code_only keeps lengths)
+        inner = src[op + 1:cl]
+        semi = split_top(inner, ";")
+        pos = [p for p in split_top(semi[0], ",") if p]
+        kws = [p for part in semi[1:] for p in split_top(part, ",") if p]
+        npos, kwn, splat = 0, [], False
+        for p in pos:
+            if re.match(r"^[a-z_]\w*[ \t]*=(?!=)", p):
+                kwn.append(p.split("=")[0].strip())
+            elif p.endswith("..."):
+                splat = True
+            else:
+                npos += 1
+        for k in kws:
+            if k.endswith("..."):
+                splat = True
+            else:
+                kwn.append(k.split("=")[0].strip())
+        out.append((s.count("\n", 0, m.start()) + 1, name, npos, kwn, splat))
+    return out
+
+
+def test_every_call_of_a_jutul_function_fits_a_method():
+    """a call `f(a, b; k = v)` of an imported / qualified Jutul function must fit SOME method of f -- the reference's or one the
+    binding adds: positional count inside the method's range, every keyword named by the method or swallowed by its splat"""
+    a = api()["names"]
+    own = {}
+    for name, _line, sig in find_methods(open(JL).read()):
+        own.setdefault(name, []).append(dict(min=sig["min"], max=sig["max"], keywords=sig["keywords"], kwsplat=sig["kwsplat"]))
+    sites = jutul_call_sites()
+    assert len(sites) >= 25, sites
+    faults = []
+    for line, name, npos, kwn, splat in sites:
+        cands = a[name]["methods"] + own.get(name, [])
+        ok = False
+        for r in cands:
+            if npos < r["min"] and not splat:
+                continue
+            if r["max"] is not None and npos > r["max"]:
+                continue
+            if any(k not in r["keywords"] and not r["kwsplat"] for k in kwn):
+                continue
+            ok = True
+            break
+        if not ok:
+            faults.append(f"JutulHIP.jl:{line}: {name} called with {npos} positional arguments and keywords {kwn}: no method takes that "
+                          f"(shapes: {[(r['min'], r['max'], r['keywords'], r['kwsplat']) for r in cands][:6]})")
+    assert not faults, "\n".join(faults)
+
+
+def test_the_call_site_checker_sees_the_calls_it_should():
+    sites = {(n, p, tuple(k)) for _, n, p, k, _ in jutul_call_sites()}
+    assert ("linear_solve_return", 3, ("prepare",)) in sites and ("update_preconditioner!", 5, ()) in sites
+    assert ("variable_change_report", 3, ()) in sites and ("update_after_step!", 5, ()) in sites
+    a = api()["names"]
+    # a planted extra argument would fit no method of the reference
+    assert not any(r["min"] <= 4 and (r["max"] is None or 4 <= r["max"]) for r in a["variable_change_report"]["methods"])
