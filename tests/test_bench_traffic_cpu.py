@@ -6,6 +6,8 @@ import os
 import sys
 import types
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -56,3 +58,19 @@ def test_device_code_hash_reads_the_built_library():
     import bench
     h = bench.device_code_hash()
     assert isinstance(h, str) and len(h) == 16 and h == bench.device_code_hash()
+
+
+@pytest.mark.xfail(strict=True, reason="round 6 had no GPU access: no PMC table exists for the device code of the in-tree library "
+                   "(d0e55889a1673c39) -- tools/first_gpu_call.sh pmc produces them; when they are committed this test passes and the "
+                   "mark must go (strict), so that from then on a STALE table fails the CPU suite instead of the driver's bench line "
+                   "printing traffic: null")
+def test_some_committed_pmc_table_matches_the_in_tree_device_code():
+    import glob
+    import json
+    import bench
+    want = bench.device_code_hash()
+    assert want is not None
+    hashes = set()
+    for p in glob.glob(os.path.join(os.path.dirname(bench.__file__), "profiles", "r*_traffic_10M_1gpu.json")):
+        hashes.add(json.load(open(p)).get("_meta", {}).get("device_code_hash"))
+    assert want in hashes, (want, sorted(h for h in hashes if h))
