@@ -74,3 +74,17 @@ def test_some_committed_pmc_table_matches_the_in_tree_device_code():
     for p in glob.glob(os.path.join(os.path.dirname(bench.__file__), "profiles", "r*_traffic_10M_1gpu.json")):
         hashes.add(json.load(open(p)).get("_meta", {}).get("device_code_hash"))
     assert want in hashes, (want, sorted(h for h in hashes if h))
+
+
+def test_device_code_is_the_recorded_one():
+    """Rounds 5 (session 4) and 6 claim "host-side changes only": the machine code of every kernel of the in-tree library must be the
+    recorded one (tests/golden/device_code_hash.txt).  A commit that touches a kernel on purpose updates that file in the same commit
+    -- and with it the statement in DESIGN.md about which committed measurements still apply (tools/isa_identity.py says which
+    kernels changed)."""
+    import __graft_entry__ as g
+    g.build()
+    import bench
+    want = open(os.path.join(ROOT, "tests", "golden", "device_code_hash.txt")).read().split()[0]
+    got = bench.device_code_hash()
+    assert got == want, (f"device code {got}, recorded {want}: a kernel changed.  If that was intended, record the new hash, run "
+                         "tools/isa_identity.py against the old library and update DESIGN.md's evidence status")
