@@ -88,3 +88,22 @@ def test_device_code_is_the_recorded_one():
     got = bench.device_code_hash()
     assert got == want, (f"device code {got}, recorded {want}: a kernel changed.  If that was intended, record the new hash, run "
                          "tools/isa_identity.py against the old library and update DESIGN.md's evidence status")
+
+
+def test_isa_identity_tool_on_the_in_tree_library():
+    """tools/isa_identity.py (which committed measurements are measurements of the current kernels): a library against itself is
+    identical kernel by kernel; the normaliser drops padding, masks only the PC-relative literal pair behind s_getpc_b64 and keeps branch offsets."""
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_identity as ii
+    if not os.path.exists(ii.OBJDUMP) and shutil.which(ii.OBJDUMP) is None:
+        pytest.skip("llvm-objdump not on this box")
+    lib = os.path.join(ROOT, "jutul.jl_amd", "libjutul_hip.so")
+    rows = ii.compare(lib, lib)
+    assert len(rows) >= 300 and all(r[1] == "identical" for r in rows)
+    streams = ii.kernel_streams(lib)
+    k = next(n for n in streams if "spmv_jds16_kernel" in n)
+    assert len(streams[k]) > 300 and not any(i.startswith("s_nop") for i in streams[k])
+    masked = [i for s in streams.values() for i in s if "<pcrel>" in i]     # (this library has no s_getpc_b64 sequence: nothing to mask)
+    assert all(i.startswith(("s_add_u32", "s_addc_u32")) for i in masked)
+    assert any(i.startswith("s_cbranch") and i.split()[-1].lstrip("-").isdigit() for i in streams[k])    # relative offsets stay
