@@ -10,7 +10,8 @@ of a device global or of another function) is masked.  Two kernels with the same
 (register counts, LDS size, ...) execute the same instructions; measurements of one hold for the other.
 
     python tools/isa_identity.py <old libjutul_hip.so> [<new libjutul_hip.so> = the in-tree one]  [--all]
-prints the kernels that differ (with the number of differing instructions) and a summary; --all lists the identical ones too.
+prints the kernels that differ (with the number of differing instructions) and a summary; --all lists the identical ones too;
+--regions: for every differing kernel the window of instructions that holds all differences other than branch displacements.
 """
 import hashlib
 import os
@@ -121,11 +122,52 @@ def compare(old, new):
     return rows
 
 
+BRANCH = re.compile(r"^(s_cbranch_\w+|s_branch) -?\d+$")
+
+
+def changed_window(a, b):
+    """(first, last, changed, hunks, sleeps) of the instructions of b that differ from a, NOT counting branches whose only difference
+    is their displacement (a branch across a region that grew or shrank); sleeps = s_sleep instructions inside the window (the
+    cross-rank wait loop is the only place these kernels sleep)"""
+    import difflib
+    sm = difflib.SequenceMatcher(a=a, b=b, autojunk=False)
+    hunks = []
+    for tag, i1, i2, j1, j2 in sm.get_opcodes():
+        if tag == "equal":
+            continue
+        if tag == "replace" and i2 - i1 == j2 - j1 and all(BRANCH.match(x) and BRANCH.match(y) and x.split()[0] == y.split()[0]
+                                                            for x, y in zip(a[i1:i2], b[j1:j2])):
+            continue
+        hunks.append((j1, j2, i1, i2))
+    if not hunks:
+        return None
+    lo, hi = min(h[0] for h in hunks), max(h[1] for h in hunks)
+    return lo, hi, sum(max(h[1] - h[0], h[3] - h[2]) for h in hunks), len(hunks), sum(1 for x in b[lo:hi] if x.startswith("s_sleep"))
+
+
+def regions(old, new):
+    so, sn = kernel_streams(old), kernel_streams(new)
+    names = demangle(sorted(sn))
+    print("# kernels whose instruction streams differ: window [first, last) of the new kernel that holds every difference other than branch")
+    print("# displacements, instructions changed inside it, hunks, s_sleep instructions inside it (= the cross-rank wait loop)")
+    for k in sorted(sn):
+        if k not in so or so[k] == sn[k]:
+            continue
+        w = changed_window(so[k], sn[k])
+        if w is None:
+            print(f"only branch displacements                                   {len(sn[k]):6d} instructions   {names[k][:120]}")
+        else:
+            print(f"window [{w[0]:5d},{w[1]:5d}) {w[2]:4d} changed in {w[3]:3d} hunks, {w[4]} s_sleep  {len(sn[k]):6d} instructions   {names[k][:120]}")
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     old = args[0]
     new = args[1] if len(args) > 1 else os.path.join(root, "jutul.jl_amd", "libjutul_hip.so")
+    if "--regions" in sys.argv:
+        regions(old, new)
+        return
     rows = compare(old, new)
     names = demangle([r[0] for r in rows])
     same = [r for r in rows if r[1] == "identical"]
